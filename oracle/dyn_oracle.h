@@ -1,0 +1,66 @@
+/* dyn_oracle.h -- TEST INFRASTRUCTURE (see dyn_oracle.c).  PARITY UNPINNED: the reference snapshot
+ * holds no dynamics code; this restates the published mathematics only. */
+#ifndef ORACLE_DYN_H
+#define ORACLE_DYN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same field order as nsdg_mevp_params in include/nsdg.h. */
+typedef struct {
+    double rho_ice, rho_atm, rho_ocean;
+    double c_atm, c_ocean;
+    double pstar, compaction;
+    double delta_min;
+    double fc;
+    double alpha, beta;
+    double h_min; /* lower limit applied to the nodal mean thickness in the momentum equation */
+} oracle_mevp_params;
+
+void oracle_dyn_init(void);
+void oracle_mevp_default_params(oracle_mevp_params* p);
+
+/* number of DG coefficients for order 0/1/2 */
+int oracle_dg_ncoef(int order);
+
+void oracle_prepare_advection(int nx, int ny, int order, const double* u, const double* v,
+    double* vx_dg, double* vy_dg, double* un_x, double* un_y);
+
+void oracle_transport_stage(int nx, int ny, int j0, int j1, double hx, double hy, int order, double dt,
+    double a, double b, const double* phi0, const double* phis, double* out, const double* vx_dg,
+    const double* vy_dg, const double* un_x, const double* un_y);
+
+/* full SSP-RK(order+1) step on all rows; scratch = 2 * ncoef * nx * ny doubles */
+void oracle_transport_step(int nx, int ny, double hx, double hy, int order, double dt, double* phi,
+    const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y, double* scratch);
+
+void oracle_dg_to_cg(int nx, int ny, int ncoef, const double* f_dg, double* f_cg);
+
+void oracle_ice_strength(int nx, int ny, int j0, int j1, const oracle_mevp_params* p, const double* H,
+    const double* A, double* pg);
+
+/* stress update on element rows [k0,k1) */
+void oracle_mevp_stress(int nx, int ny, int k0, int k1, double hx, double hy, const oracle_mevp_params* p,
+    const double* u, const double* v, const double* pg, double* s11, double* s12, double* s22);
+
+/* velocity update on the nodes owned by element rows [j0,j1) (bottom-left ownership) */
+void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, double dt,
+    const oracle_mevp_params* p, const double* s11, const double* s12, const double* s22,
+    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0,
+    const double* v0, const double* tax, const double* tay, const double* uo, const double* vo,
+    const double* cgh, const double* cga);
+
+/* nsub full-domain sub-iterations, result left in u,v (scratch = 2 * nnodes doubles) */
+void oracle_mevp_subcycle(int nx, int ny, double hx, double hy, double dt, int nsub,
+    const oracle_mevp_params* p, double* s11, double* s12, double* s22, double* u, double* v,
+    const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
+    const double* vo, const double* cgh, const double* cga, const double* pg, double* scratch);
+
+void oracle_wind_stress(long nnodes, const oracle_mevp_params* p, const double* ua, const double* va,
+    double* tax, double* tay);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
