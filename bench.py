@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- element-steps/s of the dynamics core (mEVP sub-cycle + DG2 transport) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric "element-steps/sec (dynamics+transport)"; the >=40 % HBM-roofline
+target is stated on the DG2 mEVP inner loop at 2048x2048): 2048 x 2048 elements, DG2 advected H and A,
+CG2 velocity, 8-coefficient stress, 120 mEVP sub-iterations + one SSP-RK3 transport step per model
+step, fp64, synthetic 512 km box test.  One "step" = one model time step of the whole grid; an
+"element-step" is everything done to one element in it.  With N GPUs the SAME grid
+is split into N row blocks (strong scaling) with ghost-row send/recv over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel:
+the mEVP sub-iteration; algorithmic 896 B per element-sub-iteration, HIP-event timed in this run)
+and `cpu_baseline` (the CPU oracle = this repo's own restatement, "port", timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nextsimdg_amd import abi, rowblock, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_ELEM_SUBITER = 896  # SURVEY.md section 8(d), mEVP sub-iteration
+BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
+
+
+def cpu_baseline(nsub_full, budget_s=12.0):
+    """Time the CPU oracle (tests' checker; here only as the reported baseline) on a bounded sample
+    of the same workload: a 192 x 192 box test, a few mEVP sub-iterations and one transport step,
+    single thread (the reference itself is single-threaded), then extrapolate
+    per element: t_step = nsub * t_subiter + t_transport."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    n = 192
+    bt = synthetic.BoxTest(n, n)
+    p = O.mevp_params()
+    H, A = bt.dg_fields()
+    pg = O.ice_strength(n, n, p, H, A)
+    cgh, cga = O.dg_to_cg(n, n, H), O.dg_to_cg(n, n, A)
+    uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
+    ua, va = [np.ascontiguousarray(a) for a in bt.wind(0.0)]
+    tax, tay = O.wind_stress(p, ua, va)
+    u, v = np.zeros_like(uo), np.zeros_like(uo)
+    s = [np.zeros((8, n, n)) for _ in range(3)]
+    out = {}
+    for omp in (False, True):
+        try:
+            O.lib(omp)
+        except Exception:
+            continue
+        O.mevp_subcycle(n, n, bt.hx, bt.hy, 120.0, 1, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg, omp=omp)
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            O.mevp_subcycle(n, n, bt.hx, bt.hy, 120.0, 2, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg, omp=omp)
+            k += 2
+            if time.perf_counter() - t0 > budget_s * (0.8 if not omp else 0.2):
+                break
+        t_sub = (time.perf_counter() - t0) / (k * n * n)
+        adv = O.prepare_advection(n, n, 2, u, v)
+        t0 = time.perf_counter()
+        for f in (H.copy(), A.copy()):
+            O.transport_step(n, n, bt.hx, bt.hy, 2, 120.0, f, adv, omp=omp)
+        t_tr = (time.perf_counter() - t0) / (n * n)
+        out[omp] = (1.0 / (nsub_full * t_sub + t_tr), 1.0 / t_sub, k)
+    cores = os.cpu_count() or 1
+    res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port",
+           "sample": "oracle/dyn_oracle.c on a 192x192 box test: %d mEVP sub-iterations + 1 DG2 RK3 transport step of H and A, "
+                     "per-element costs extrapolated to %d sub-iterations/step; own CPU restatement -- the reference snapshot "
+                     "has no dynamics code to time" % (out[False][2], nsub_full),
+           "subiters_per_s": out[False][1]}
+    if True in out:
+        res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1]}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=2048)
+    ap.add_argument("--ny", type=int, default=2048)
+    ap.add_argument("--nsub", type=int, default=120)
+    ap.add_argument("--variant", type=int, default=None, help="mEVP kernel variant (default: library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the dynamics core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from nextsimdg_amd import build
+
+    if rank == 0:
+        build.build_lib(verbose=False)
+    if world > 1:
+        dist.barrier()
+
+    nx, ny, nsub = args.nx, args.ny, args.nsub
+    L = 512e3
+    dt = 120.0
+    ctx = abi.Context(device)
+    if args.variant is not None:
+        ctx.set_mevp_variant(args.variant)
+    ctx.set_mevp_params(ctx.mevp_default_params())
+    blk = rowblock.RowBlock(nx, ny, rank, world)
+    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, device)
+    bt = synthetic.BoxTest(nx, ny, L)
+    H, A = bt.dg_fields()
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    core.load_global(H, A, uo, vo, ua, va)
+    del H, A, uo, vo, ua, va
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        core.step()
+    sync()
+    # dominant-kernel timing: HIP events on the context's stream around the sub-cycle of every timed step
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        core._set_grid()
+        ev[k][0].record(ctx.stream)
+        core.momentum()
+        ev[k][1].record(ctx.stream)
+        core.transport()
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+    sub_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / nsub  # per sub-iteration, this rank
+
+    finite = bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())
+    umax = float(core.u.abs().max())
+    if not finite or umax == 0.0:
+        raise SystemExit("bench produced non-finite or trivial fields: invalid run")
+
+    if rank == 0:
+        n_elem = nx * ny
+        value = n_elem * args.steps / elapsed
+        own_elems = (blk.r1 - blk.r0) * nx
+        achieved = own_elems * BYTES_PER_ELEM_SUBITER / (sub_ms * 1e-3) / 1e9
+        line = {
+            "metric": "element-steps/sec (dynamics+transport)", "value": value, "unit": "element-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
+                                   "512 km box test, dt=120 s" % (nx, ny, nsub),
+                       "decomposition": "%d row block(s), ghost-row send/recv" % world,
+                       "mevp_variant": ctx.lib and (args.variant if args.variant is not None else "default")},
+            "roofline": {"bound": "hbm", "kernel": "mEVP sub-iteration", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": own_elems * BYTES_PER_ELEM_SUBITER,
+                         "avg_launch_ms": sub_ms},
+            "mevp_element_subiters_per_s": own_elems / (sub_ms * 1e-3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(nsub)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

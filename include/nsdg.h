@@ -1,0 +1,181 @@
+/*
+ * nsdg.h -- C ABI of the MI355X-native sea-ice dynamics / column-physics core (libnsdg.so).
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b): a host program that keeps the reference's
+ * IModelStep / IStructure / ModuleLoader surfaces (see nextsimdg_amd/host/ and INTEGRATION.md)
+ * calls these entry points once per model step; everything behind them is hand-written HIP for
+ * gfx950.  No C++ types, exceptions or torch types cross the boundary.
+ *
+ * Conventions
+ *  - Every function returns NSDG_OK (0) or a negative nsdg_status; nsdg_last_error() returns a
+ *    thread-local description of the last failure.
+ *  - All array arguments are DEVICE pointers to fp64 owned by the caller; the library never frees
+ *    or reallocates them.  Calls are asynchronous on the context's stream: a buffer may be reused by
+ *    the host after the stream has been synchronised (nsdg_ctx_synchronize or the caller's own sync).
+ *  - One context per GPU/stream.  Calls on one context must not be issued concurrently from two
+ *    host threads; different contexts are independent.  (The reference is single-threaded and
+ *    non-re-entrant: static m_dt / m_freezer, core/src/PrognosticData.cpp:12-13.)
+ *  - NaN/Inf propagate as in the reference: no clamping or input checking is added to the physics
+ *    (SURVEY.md section 8b "Errors").
+ *
+ * Data layout
+ *  - element (ix, iy) of an nx x ny local array, ix fastest:  e = iy*nx + ix.  (The reference's
+ *    restart layout is the same x-major linear index i*nx + j, core/src/DevGridIO.cpp:107-109.)
+ *  - DG field, nc coefficients: coefficient-major planes  f[c*nx*ny + e]   (nc = 1/3/6 for DG0/1/2,
+ *    8 for the stress space).
+ *  - CG2 nodal field: (2nx+1) x (2ny+1) lattice, node (gx, gy) at  n = gy*(2nx+1) + gx.
+ *  - edge-normal velocities at the ng = order+1 edge Gauss points:
+ *        un_x[g*(nx+1)*ny + iy*(nx+1) + ex]   (vertical edges, normal = +x)
+ *        un_y[g*nx*(ny+1) + ey*nx + ix]       (horizontal edges, normal = +y)
+ *  - ice strength at the 3x3 Gauss points:  pg[q*nx*ny + e], q = 3*qy + qx.
+ *  - Row ranges [j0, j1) are ELEMENT rows of the local array; the edges of the local array are the
+ *    physical boundary (zero inflow for transport, v = 0 for momentum).  A rank of a row-block
+ *    decomposition passes arrays that include its ghost rows and the range of rows it owns.
+ */
+#ifndef NSDG_H
+#define NSDG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSDG_ABI_VERSION 1
+
+typedef enum {
+    NSDG_OK = 0,
+    NSDG_ERR_ARG = -1, /* bad argument (null pointer, bad size / order / range) */
+    NSDG_ERR_HIP = -2, /* a HIP runtime call or kernel launch failed */
+    NSDG_ERR_STATE = -3, /* call sequence error (e.g. grid not set) */
+    NSDG_ERR_NODEVICE = -4 /* no usable HIP device */
+} nsdg_status;
+
+typedef struct nsdg_ctx nsdg_ctx;
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces the process-wide static state of the reference (ModuleLoader singleton,
+ * core/src/include/ModuleLoader.hpp:22-27; static physics parameters,
+ * physics/src/modules/NextsimPhysics.cpp:26-39) by an explicit per-GPU object.
+ * `stream` is a hipStream_t (NULL = the device's default stream). */
+int nsdg_abi_version(void);
+const char* nsdg_last_error(void);
+int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out);
+int nsdg_ctx_destroy(nsdg_ctx* ctx);
+int nsdg_ctx_synchronize(nsdg_ctx* ctx);
+
+/* ---- column physics (the reference's per-element step) ---------------------------------------- */
+enum { NSDG_ALBEDO_SMU = 0, NSDG_ALBEDO_SMU2 = 1, NSDG_ALBEDO_CCSM = 2 }; /* physics/src/modules/modules.json:4-8 */
+enum { NSDG_FREEZING_LINEAR = 0, NSDG_FREEZING_UNESCO = 1 }; /* core/src/modules/modules.json:4-7 */
+
+/* Every configuration value of the column path:
+ * nextsim_thermo.* (physics/src/modules/NextsimPhysics.cpp:50-58,76-82), thermoice0.*
+ * (ThermoIce0.cpp:23-31), Hibler.* (HiblerConcentration.cpp:21-29), CCSMIceAlbedo.*
+ * (CCSMIceAlbedo.cpp:40-41) and the [Modules] choices of IIceAlbedo / IFreezingPoint. */
+typedef struct {
+    double drag_ocean_q, drag_ocean_t, drag_ice_t, ocean_albedo, i0, min_conc, min_thick;
+    double ks;
+    double h0, phi_m;
+    double ccsm_ice_albedo, ccsm_snow_albedo;
+    int32_t flooding;
+    int32_t albedo_kind;
+    int32_t freezing_kind;
+    int32_t reserved;
+} nsdg_column_params;
+
+void nsdg_column_default_params(nsdg_column_params* p);
+int nsdg_column_params_set(nsdg_ctx* ctx, const nsdg_column_params* p);
+
+/* optional diagnostics: NSDG_NDIAG planes of n doubles, diag[k*n + e] */
+enum {
+    NSDG_D_RHO = 0, NSDG_D_QA, NSDG_D_QW, NSDG_D_QI, NSDG_D_CSPEC, NSDG_D_TAU, NSDG_D_HI, NSDG_D_HS,
+    NSDG_D_CNEW, NSDG_D_QIA, NSDG_D_QIO, NSDG_D_SUBL, NSDG_D_DQDT, NSDG_D_HIFROMS, NSDG_D_QOW, NSDG_NDIAG
+};
+
+/* One model step of the column physics on n independent elements; replaces the element loop of
+ * DevStep::iterate (core/src/DevStep.cpp:14-23), i.e. per element
+ *   IPhysics1d::updateDerivedData (physics/src/modules/include/IPhysics1d.hpp:33-45),
+ *   NextsimPhysics::calculate (physics/src/modules/NextsimPhysics.cpp:116-131),
+ *   PrognosticData::updateAndIntegrate (core/src/PrognosticData.cpp:63-71).
+ * hice/cice/hsnow/tice0 are updated in place; sst/sss and the forcing are read-only (the reference
+ * never updates sst/sss); newice is the per-element persistent NextsimPhysics::m_newice
+ * (NextsimPhysics.cpp:244-253) and must be carried by the caller between steps; wind is
+ * PhysicsData::windSpeed (physics/src/include/PhysicsData.hpp:44).  diag may be NULL. */
+int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hice, double* cice, double* hsnow,
+    double* tice0, const double* sst, const double* sss, const double* tair, const double* tdew,
+    const double* slp, const double* qsw, const double* qlw, const double* mld, const double* snowfall,
+    const double* wind, double* newice, double* diag);
+
+/* ---- dynamics: DG transport + mEVP (no counterpart in the reference snapshot: CMakeLists.txt:43-46
+ *      comments the dynamics component out; built from the published formulation) */
+typedef struct {
+    double rho_ice, rho_atm, rho_ocean;
+    double c_atm, c_ocean;
+    double pstar, compaction;
+    double delta_min;
+    double fc;
+    double alpha, beta;
+    double h_min;
+} nsdg_mevp_params;
+
+void nsdg_mevp_default_params(nsdg_mevp_params* p);
+int nsdg_mevp_params_set(nsdg_ctx* ctx, const nsdg_mevp_params* p);
+
+/* shape and cell size of the local element array all following calls refer to */
+int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
+
+/* kernel variant of the mEVP sub-cycle: 0 = two kernels per sub-iteration (element-wise stress,
+ * node-gather velocity), 1 = fused marching kernel.  Results are identical to fp64 round-off. */
+int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
+
+/* CG2 velocity -> DG(order) velocity and edge-normal velocities used by the transport */
+int nsdg_prepare_advection(nsdg_ctx* ctx, int32_t order, const double* u, const double* v, double* vx_dg,
+    double* vy_dg, double* un_x, double* un_y);
+
+/* one Runge-Kutta stage on element rows [j0, j1) for nfields fields advected by the same velocity:
+ *   out[f] = a*phi0[f] + b*(phis[f] + dt*L(phis[f]))
+ * phi0/phis/out are HOST arrays of nfields DEVICE pointers. */
+int nsdg_transport_stage(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, double dt, double a, double b,
+    int32_t nfields, const double* const* phi0, const double* const* phis, double* const* out,
+    const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y);
+
+/* full SSP-RK(order+1) step over all rows (single-domain convenience); scratch: 2*nfields*nc*nx*ny */
+int nsdg_transport_step(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields, double* const* phi,
+    const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y, double* scratch);
+
+/* nodal average of a DG field on the CG2 lattice (mean thickness / concentration at the nodes) */
+int nsdg_dg_to_cg(nsdg_ctx* ctx, int32_t ncoef, const double* f_dg, double* f_cg);
+
+/* P = pstar * max(H,0) * exp(-C (1 - clamp(A,0,1))) at the 3x3 Gauss points of rows [j0, j1) */
+int nsdg_ice_strength(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* H, const double* A, double* pg);
+
+/* tau_a = c_atm * rho_atm * |u_a| u_a at nnodes nodes */
+int nsdg_wind_stress(nsdg_ctx* ctx, int64_t nnodes, const double* ua, const double* va, double* tax, double* tay);
+
+/* mEVP stress update on element rows [k0, k1):  S <- (1-1/alpha) S + (1/alpha) Proj sigma(v) */
+int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, const double* v, const double* pg,
+    double* s11, double* s12, double* s22);
+
+/* mEVP velocity update of the nodes owned (bottom-left) by element rows [j0, j1) */
+int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const double* s11, const double* s12,
+    const double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
+    const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
+    const double* vo, const double* cgh, const double* cga);
+
+/* one fused sub-iteration (stress on rows [k0,k1), velocity of the nodes of rows [j0,j1)), k0 <= j0:
+ * reads u_old/v_old, writes u_new/v_new and the stresses in place.  Used by multi-rank drivers that
+ * exchange halos between sub-iterations. */
+int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, double* s11, double* s12,
+    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0,
+    const double* v0, const double* tax, const double* tay, const double* uo, const double* vo,
+    const double* cgh, const double* cga, const double* pg);
+
+/* nsub sub-iterations over the whole local array; result in u, v.  scratch: 2*(2nx+1)*(2ny+1). */
+int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u,
+    double* v, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
+    const double* vo, const double* cgh, const double* cga, const double* pg, double* scratch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSDG_H */

@@ -1,0 +1,242 @@
+"""ctypes binding of the C ABI in include/nsdg.h (libnsdg.so) for Python callers (tests, bench,
+multi-rank driver).  PyTorch is used only as the owner of device memory and streams: every call
+below passes raw device pointers through the extern "C" boundary.
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, importing the
+handle raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libnsdg.so")
+
+c_double_p = C.POINTER(C.c_double)
+NDIAG = 15
+DIAG = ["rho", "qa", "qw", "qi", "cspec", "tau", "hi", "hs", "cnew", "qia", "qio", "subl", "dqdt", "hifroms", "qow"]
+STATE = ["hice", "cice", "hsnow", "tice0"]
+FORCING = ["sst", "sss", "tair", "tdew", "slp", "qsw", "qlw", "mld", "snowfall", "wind"]
+ALBEDO = {"smu": 0, "smu2": 1, "ccsm": 2}
+FREEZING = {"linear": 0, "unesco": 1}
+
+
+class ColumnParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "drag_ocean_q", "drag_ocean_t", "drag_ice_t", "ocean_albedo", "i0", "min_conc", "min_thick",
+        "ks", "h0", "phi_m", "ccsm_ice_albedo", "ccsm_snow_albedo")] + [
+        ("flooding", C.c_int32), ("albedo_kind", C.c_int32), ("freezing_kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MevpParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "rho_ice", "rho_atm", "rho_ocean", "c_atm", "c_ocean", "pstar", "compaction", "delta_min", "fc",
+        "alpha", "beta", "h_min")]
+
+
+class NsdgError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); kept in one table so tests can check every declared symbol exists
+VP = C.c_void_p
+I32, I64, D = C.c_int32, C.c_int64, C.c_double
+SYMBOLS = {
+    "nsdg_abi_version": (C.c_int, []),
+    "nsdg_last_error": (C.c_char_p, []),
+    "nsdg_ctx_create": (C.c_int, [C.c_int, VP, C.POINTER(VP)]),
+    "nsdg_ctx_destroy": (C.c_int, [VP]),
+    "nsdg_ctx_synchronize": (C.c_int, [VP]),
+    "nsdg_column_default_params": (None, [C.POINTER(ColumnParams)]),
+    "nsdg_column_params_set": (C.c_int, [VP, C.POINTER(ColumnParams)]),
+    "nsdg_column_step": (C.c_int, [VP, I64, D] + [VP] * 16),
+    "nsdg_mevp_default_params": (None, [C.POINTER(MevpParams)]),
+    "nsdg_mevp_params_set": (C.c_int, [VP, C.POINTER(MevpParams)]),
+    "nsdg_grid_set": (C.c_int, [VP, I32, I32, D, D]),
+    "nsdg_mevp_variant_set": (C.c_int, [VP, I32]),
+    "nsdg_prepare_advection": (C.c_int, [VP, I32] + [VP] * 6),
+    "nsdg_transport_stage": (C.c_int, [VP, I32, I32, I32, D, D, D, I32, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
+    "nsdg_transport_step": (C.c_int, [VP, I32, D, I32, C.POINTER(VP)] + [VP] * 5),
+    "nsdg_dg_to_cg": (C.c_int, [VP, I32, VP, VP]),
+    "nsdg_ice_strength": (C.c_int, [VP, I32, I32, VP, VP, VP]),
+    "nsdg_wind_stress": (C.c_int, [VP, I64, VP, VP, VP, VP]),
+    "nsdg_mevp_stress": (C.c_int, [VP, I32, I32] + [VP] * 6),
+    "nsdg_mevp_velocity": (C.c_int, [VP, I32, I32, D] + [VP] * 15),
+    "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32, D] + [VP] * 16),
+    "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
+}
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """dlopen libnsdg.so and declare every entry point of include/nsdg.h.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise NsdgError("HIP library %s is missing: build it with `python -m nextsimdg_amd.build` "
+                        "(there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _check_f64(*tensors):
+    import torch
+
+    for t in tensors:
+        if t is None:
+            continue
+        if t.dtype != torch.float64 or not t.is_contiguous() or not t.is_cuda:
+            raise NsdgError("expected contiguous float64 CUDA tensors")
+
+
+def _ptr_array(tensors):
+    arr = (VP * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class Context:
+    """One nsdg_ctx bound to a torch device and (by default) torch's current stream on it, so that
+    torch.cuda.Event timing and torch.distributed collectives order correctly with the kernels."""
+
+    def __init__(self, device=None, stream=None):
+        import torch
+
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise NsdgError("no HIP device visible: the nextsimdg_amd kernels need a GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream() if stream is None else stream
+        h = VP()
+        self._call(self.lib.nsdg_ctx_create(self.device.index or 0, VP(self.stream.cuda_stream), C.byref(h)))
+        self.h = h
+        self.nx = self.ny = 0
+
+    def _call(self, rc):
+        if rc != 0:
+            raise NsdgError("nsdg error %d: %s" % (rc, self.lib.nsdg_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nsdg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._call(self.lib.nsdg_ctx_synchronize(self.h))
+
+    # ---- column physics
+    def column_default_params(self, **kw):
+        p = ColumnParams()
+        self.lib.nsdg_column_default_params(C.byref(p))
+        for k, v in kw.items():
+            if k == "albedo":
+                p.albedo_kind = ALBEDO[v]
+            elif k == "freezing":
+                p.freezing_kind = FREEZING[v]
+            else:
+                if not hasattr(p, k):
+                    raise NsdgError("unknown column parameter " + k)
+                setattr(p, k, v)
+        return p
+
+    def set_column_params(self, p):
+        self._call(self.lib.nsdg_column_params_set(self.h, C.byref(p)))
+
+    def column_step(self, dt, state, forcing, newice, diag=None):
+        ts = [state[k] for k in STATE] + [forcing[k] for k in FORCING] + [newice]
+        _check_f64(*ts, diag)
+        n = ts[0].numel()
+        self._call(self.lib.nsdg_column_step(self.h, n, float(dt), *[_ptr(t) for t in ts], _ptr(diag)))
+
+    # ---- dynamics
+    def mevp_default_params(self, **kw):
+        p = MevpParams()
+        self.lib.nsdg_mevp_default_params(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise NsdgError("unknown mEVP parameter " + k)
+            setattr(p, k, v)
+        return p
+
+    def set_mevp_params(self, p):
+        self._call(self.lib.nsdg_mevp_params_set(self.h, C.byref(p)))
+
+    def set_grid(self, nx, ny, hx, hy):
+        self._call(self.lib.nsdg_grid_set(self.h, nx, ny, float(hx), float(hy)))
+        self.nx, self.ny = nx, ny
+
+    def set_mevp_variant(self, variant):
+        self._call(self.lib.nsdg_mevp_variant_set(self.h, variant))
+
+    def prepare_advection(self, order, u, v, vx, vy, unx, uny):
+        _check_f64(u, v, vx, vy, unx, uny)
+        self._call(self.lib.nsdg_prepare_advection(self.h, order, *[_ptr(t) for t in (u, v, vx, vy, unx, uny)]))
+
+    def transport_stage(self, order, j0, j1, dt, a, b, phi0, phis, out, adv):
+        _check_f64(*phi0, *phis, *out, *adv)
+        self._call(self.lib.nsdg_transport_stage(self.h, order, j0, j1, float(dt), float(a), float(b), len(phis),
+                                                 _ptr_array(phi0), _ptr_array(phis), _ptr_array(out),
+                                                 *[_ptr(t) for t in adv]))
+
+    def transport_step(self, order, dt, fields, adv, scratch):
+        _check_f64(*fields, *adv, scratch)
+        need = 2 * sum(f.numel() for f in fields)
+        if scratch.numel() < need:
+            raise NsdgError("transport scratch too small: need %d doubles" % need)
+        self._call(self.lib.nsdg_transport_step(self.h, order, float(dt), len(fields), _ptr_array(fields),
+                                                *[_ptr(t) for t in adv], _ptr(scratch)))
+
+    def dg_to_cg(self, f_dg, f_cg):
+        _check_f64(f_dg, f_cg)
+        self._call(self.lib.nsdg_dg_to_cg(self.h, f_dg.shape[0], _ptr(f_dg), _ptr(f_cg)))
+
+    def ice_strength(self, H, A, pg, j0=0, j1=None):
+        _check_f64(H, A, pg)
+        self._call(self.lib.nsdg_ice_strength(self.h, j0, self.ny if j1 is None else j1, _ptr(H), _ptr(A), _ptr(pg)))
+
+    def wind_stress(self, ua, va, tax, tay):
+        _check_f64(ua, va, tax, tay)
+        self._call(self.lib.nsdg_wind_stress(self.h, ua.numel(), _ptr(ua), _ptr(va), _ptr(tax), _ptr(tay)))
+
+    def mevp_stress(self, k0, k1, u, v, pg, s11, s12, s22):
+        _check_f64(u, v, pg, s11, s12, s22)
+        self._call(self.lib.nsdg_mevp_stress(self.h, k0, k1, *[_ptr(t) for t in (u, v, pg, s11, s12, s22)]))
+
+    def mevp_velocity(self, j0, j1, dt, s, uv_old, uv_new, u0v0, tau, ocean, cgh, cga):
+        ts = [s[0], s[1], s[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], u0v0[0], u0v0[1], tau[0], tau[1],
+              ocean[0], ocean[1], cgh, cga]
+        _check_f64(*ts)
+        self._call(self.lib.nsdg_mevp_velocity(self.h, j0, j1, float(dt), *[_ptr(t) for t in ts]))
+
+    def mevp_iterate(self, k0, j0, j1, dt, s, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, pg):
+        ts = [s[0], s[1], s[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], u0v0[0], u0v0[1], tau[0], tau[1],
+              ocean[0], ocean[1], cgh, cga, pg]
+        _check_f64(*ts)
+        self._call(self.lib.nsdg_mevp_iterate(self.h, k0, j0, j1, float(dt), *[_ptr(t) for t in ts]))
+
+    def mevp_subcycle(self, dt, nsub, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch):
+        ts = [s[0], s[1], s[2], u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch]
+        _check_f64(*ts)
+        if scratch.numel() < 2 * u.numel():
+            raise NsdgError("mEVP scratch too small: need %d doubles" % (2 * u.numel()))
+        self._call(self.lib.nsdg_mevp_subcycle(self.h, float(dt), int(nsub), *[_ptr(t) for t in ts]))

@@ -1,0 +1,285 @@
+// column_step.hip -- the reference's per-element column-physics step as one gfx950 kernel.
+//
+// What it replaces: the element loop of DevStep::iterate (core/src/DevStep.cpp:14-23) and everything
+// it calls per element: IPhysics1d::updateDerivedData, NextsimPhysics::calculate
+// (open-water / ice-atmosphere / ice-ocean fluxes, ThermoIce0, new-ice formation, Hibler lateral
+// growth, min-c/h cut-off) and PrognosticData::updateAndIntegrate.  Formulae are cited inline
+// (paths relative to /root/reference).
+//
+// Shape: one lane per element, SoA planes, 15 coalesced fp64 loads + 5 stores per element
+// (160 B / element-step algorithmic traffic); all intermediates (the reference's
+// PhysicsData scratch and the NextsimPhysics members) live in registers.  The virtual plugin calls
+// of the reference (albedo / freezing point) become wave-uniform switches on the params struct,
+// which is passed by value as a kernel argument (SGPRs).  HBM-bound: ~0.5 kflop incl. 4 exp per
+// 160 B.
+#include "nsdg_internal.h"
+
+namespace {
+
+// core/src/include/constants.hpp:21-120
+constexpr double SIGMA = 5.670374419e-8;
+constexpr double ICE_EPSILON = 0.996;
+constexpr double ICE_KAPPA = 2.0334;
+constexpr double ICE_LF = 333.55e3;
+constexpr double ICE_RHO = 917.;
+constexpr double ICE_RHOSNOW = 330.;
+constexpr double ICE_S = 5.;
+constexpr double AIR_CP = 1004.64;
+constexpr double AIR_RA = 287.058;
+constexpr double VAP_CP = 1860.;
+constexpr double VAP_LV0 = 2500.79e3;
+constexpr double VAP_RA = 461.5;
+constexpr double WATER_CP = 4186.84;
+constexpr double WATER_MU = 0.055;
+constexpr double WATER_RHOOCEAN = 1025.;
+constexpr double WATER_TF = 273.15;
+
+__device__ __forceinline__ double kelvin(double c) { return c + WATER_TF; } // constants.hpp:128
+
+// NextsimPhysics::SpecificHumidity parameter sets, NextsimPhysics.cpp:310,346,324-325
+struct SpHum {
+    double a, b, c, d, A, B, C;
+};
+constexpr SpHum SH_WATER = { 6.1121e2, 18.729, 257.87, 227.3, 7.2e-4, 3.20e-6, 5.9e-10 };
+constexpr SpHum SH_ICE = { 6.1115e2, 23.036, 279.82, 333.7, 2.2e-4, 3.83e-6, 6.4e-10 };
+constexpr double SH_ALPHA = 0.62197;
+constexpr double SH_BETA = 1 - 0.62197;
+
+__device__ __forceinline__ double sh_f(const SpHum& s, double t, double pPa) // :371-375
+{
+    return 1 + s.A + (pPa * 0.01) * (s.B + s.C * t * t);
+}
+__device__ __forceinline__ double sh_est(const SpHum& s, double t, double sal) // :377-381
+{
+    return s.a * exp((s.b - t / s.d) * t / (t + s.c)) * (1 - 5.37e-4 * sal);
+}
+__device__ __forceinline__ double sh_q(double est, double f, double p) // :335-343
+{
+    return SH_ALPHA * f * est / (p - SH_BETA * f * est);
+}
+
+__device__ __forceinline__ double freezing_point(int kind, double sss)
+{
+    // core/src/modules/include/UnescoFreezing.hpp:28-38 / LinearFreezing.hpp:30-34
+    if (kind == NSDG_FREEZING_UNESCO)
+        return sss * (-0.0575 + 1.710523e-3 * sqrt(sss) + -2.154996e-4 * sss);
+    return -WATER_MU * sss;
+}
+
+__device__ __forceinline__ double ice_albedo(const nsdg_column_params& P, double temperature, double hs)
+{
+    constexpr double ICE_ALBEDO = 0.64, SNOW_ALBEDO = 0.85;
+    if (P.albedo_kind == NSDG_ALBEDO_CCSM) { // physics/src/modules/CCSMIceAlbedo.cpp:28-36
+        const double iceAlbedoT = P.ccsm_ice_albedo - fmax(0., 0.075 * (temperature + 1.));
+        const double snowAlbedoT = P.ccsm_snow_albedo - fmax(0., 0.124 * (temperature + 1.));
+        const double f = hs / (hs + 0.02);
+        return f * snowAlbedoT + (1 - f) * iceAlbedoT;
+    }
+    const double bare = ICE_ALBEDO + 0.4 * (1 - ICE_ALBEDO) * P.i0;
+    if (P.albedo_kind == NSDG_ALBEDO_SMU2) // SMU2IceAlbedo.cpp:21-29
+        return (hs > 0.) ? fmin(SNOW_ALBEDO, ICE_ALBEDO + (SNOW_ALBEDO - ICE_ALBEDO) * hs / 0.2) : bare;
+    return (hs > 0.) ? SNOW_ALBEDO : bare; // SMUIceAlbedo.cpp:19-26
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(256) void column_step_kernel(nsdg_column_params P, long n, double dt,
+    double* __restrict__ hice, double* __restrict__ cice, double* __restrict__ hsnow,
+    double* __restrict__ tice0, const double* __restrict__ sst_, const double* __restrict__ sss_,
+    const double* __restrict__ tair_, const double* __restrict__ tdew_, const double* __restrict__ slp_,
+    const double* __restrict__ qsw_, const double* __restrict__ qlw_, const double* __restrict__ mld_,
+    const double* __restrict__ snowfall_, const double* __restrict__ wind_, double* __restrict__ newice_,
+    double* __restrict__ diag)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n)
+        return;
+    // 15 coalesced loads, issued up front so they are all in flight together
+    const double thick = hice[e], conc = cice[e], snow = hsnow[e], tice = tice0[e];
+    const double sst = sst_[e], sss = sss_[e], tair = tair_[e], tdew = tdew_[e], slp = slp_[e];
+    const double qsw = qsw_[e], qlw = qlw_[e], mld = mld_[e], snowfall = snowfall_[e], wind = wind_[e];
+    double newice = newice_[e];
+
+    // PrognosticData.hpp:56,75,78; ExternalData.hpp:60
+    const double h_true = (conc != 0) ? thick / conc : 0;
+    const double hs_true = (conc != 0) ? snow / conc : 0;
+    const double tf = freezing_point(P.freezing_kind, sss);
+    const double mlbhc = mld * WATER_RHOOCEAN * WATER_CP;
+
+    // ---- updateDerivedData (IPhysics1d.hpp:33-45; NextsimPhysics.cpp:85-114)
+    const double q_a = sh_q(sh_est(SH_WATER, tdew, 0.), sh_f(SH_WATER, tdew, slp), slp);
+    const double q_w = sh_q(sh_est(SH_WATER, sst, sss), sh_f(SH_WATER, sst, slp), slp);
+    const double est_i = sh_est(SH_ICE, tice, 0.);
+    const double f_i = sh_f(SH_ICE, tice, slp);
+    const double q_i = sh_q(est_i, f_i, slp);
+    const double Ra_wet = AIR_RA / (1 - q_a * (1 - VAP_RA / AIR_RA));
+    const double rho = slp / (Ra_wet * kelvin(tair));
+    const double cspec = AIR_CP + q_a * VAP_CP;
+    double hs = hs_true;
+    double hi = h_true;
+
+    // ---- NextsimPhysics::calculate (:116-131)
+    const double evap = P.drag_ocean_q * rho * wind * (q_w - q_a); // :133-137
+    const double tau = rho * (1e-3 * fmax(1.0, fmin(2.0, 0.61 + 0.063 * wind))); // :139-142,291-295
+    // open water heat flux :144-162
+    const double Lw = VAP_LV0 + sst * (-2.36418e3 + sst * (1.58927 + sst * (-6.14342e-2))); // :297-302
+    const double sstK = kelvin(sst), sstK2 = sstK * sstK;
+    const double Qlhow = evap * Lw;
+    const double Qshow = P.drag_ocean_t * rho * cspec * wind * (sst - tair);
+    const double Qswow = -qsw * (1 - P.ocean_albedo);
+    const double Qlwow = ICE_EPSILON * SIGMA * (sstK2 * sstK2) - qlw; // :383-386
+    double Qow = Qlhow + Qshow + Qlwow + Qswow;
+    // ice-atmosphere :164-198
+    const double subl = P.drag_ice_t * rho * wind * (q_i - q_a);
+    const double Li = VAP_LV0 + ICE_LF - 240. + tice * (-290. + tice * (-4.)); // :304-307
+    const double Qlhi = subl * Li;
+    double dq_dT;
+    { // SpecificHumidityIce::dq_dT :356-368 (df_dT written exactly as in the reference)
+        const double df_dT = 2 * SH_ICE.C * SH_ICE.B * tice;
+        const double ct = SH_ICE.c + tice;
+        const double dest_dT = (SH_ICE.b * SH_ICE.c * SH_ICE.d - tice * (2 * SH_ICE.c + tice)) / (SH_ICE.d * (ct * ct)) * est_i;
+        const double den = slp - SH_BETA * est_i * f_i;
+        dq_dT = SH_ALPHA * slp * (f_i * dest_dT + est_i * df_dT) / (den * den);
+    }
+    const double dQlh_dT = Li * (P.drag_ice_t * rho * wind * dq_dT);
+    const double Qshi = P.drag_ice_t * rho * cspec * wind * (tice - tair);
+    const double dQsh_dT = P.drag_ice_t * rho * cspec * wind;
+    const double albedoValue = ice_albedo(P, tice, (conc > 0) ? (snow / conc) : 0.);
+    const double Qswi = -qsw * (1. - P.i0) * (1 - albedoValue);
+    const double ticeK = kelvin(tice), ticeK2 = ticeK * ticeK;
+    const double sb_i = ICE_EPSILON * SIGMA * (ticeK2 * ticeK2);
+    const double Qlwi = sb_i - qlw;
+    const double dQlw_dT = 4 / ticeK * sb_i;
+    const double Qia = Qlhi + Qshi + Qlwi + Qswi;
+    const double dQ_dT = dQlh_dT + dQsh_dT + dQlw_dT;
+    // ice-ocean :222-226 -> BasicIceOceanHeatFlux.cpp:16-25
+    double Qio = (sst - tf) * mlbhc / dt;
+
+    // ---- massFluxIceOcean :200-220
+    double hifroms = 0;
+    double Tnew;
+    { // ThermoIce0::calculate, ThermoIce0.cpp:34-133
+        constexpr double freezingPointIce = -WATER_MU * ICE_S;
+        constexpr double bulkLHFusionSnow = ICE_LF * ICE_RHOSNOW;
+        constexpr double bulkLHFusionIce = ICE_LF * ICE_RHO;
+        if (thick == 0 || conc == 0) { // :45-51
+            hi = 0;
+            hs = 0;
+            Tnew = freezingPointIce;
+        } else {
+            const double k_lSlab = P.ks * ICE_KAPPA / (P.ks * h_true + ICE_KAPPA * hs_true); // :58-59
+            const double QIceConduction = k_lSlab * (tf - tice); // :60
+            const double remainingFlux = QIceConduction - Qia; // :61
+            Tnew = tice + remainingFlux / (k_lSlab + dQ_dT); // :62-63
+            Tnew = fmin((hs_true > 0.) ? 0. : freezingPointIce, Tnew); // :66-68
+            const double snowMeltRate = fmin(-remainingFlux, 0.) / bulkLHFusionSnow; // :71
+            const double snowSublRate = subl / ICE_RHOSNOW; // :72
+            hs += (snowMeltRate - snowSublRate) * dt; // :74
+            const double excessIceMelt = fmin(hs, 0.) * bulkLHFusionSnow / bulkLHFusionIce; // :76-77
+            hs = fmax(hs, 0.); // :79
+            hs += snowfall * dt / ICE_RHOSNOW; // :81
+            const double iceBottomChange = (QIceConduction - Qio) * dt / bulkLHFusionIce; // :84-85
+            hi += excessIceMelt + iceBottomChange; // :87-88
+            const double iceDraught = (hi * ICE_RHO + hs * ICE_RHOSNOW) / WATER_RHOOCEAN; // :95-97
+            if (P.flooding && iceDraught > hi) { // :98-106
+                const double newIce = iceDraught - hi;
+                hifroms += newIce;
+                hi = iceDraught;
+                hs -= newIce * ICE_RHO / ICE_RHOSNOW;
+            }
+            if (hi < P.min_thick) { // :108-132
+                hifroms = 0;
+                Qio += hi * bulkLHFusionIce / dt + hs * bulkLHFusionSnow / dt;
+                hi = 0;
+                hs = 0;
+                Tnew = freezingPointIce;
+            }
+        }
+    }
+    { // newIceFormation :228-254; newice keeps its old value when the branch is not taken (A.7 quirk 1)
+        const double coolingFlux = Qow;
+        const double deltaTml = -coolingFlux / mlbhc * dt;
+        const double t1 = sst + deltaTml;
+        if (t1 < tf) {
+            const double sensibleFlux = (tf - sst) / deltaTml * coolingFlux;
+            const double latentFlux = coolingFlux - sensibleFlux;
+            Qow = sensibleFlux;
+            newice = latentFlux * dt * (1 - conc) / (ICE_LF * ICE_RHO);
+        }
+    }
+    double c_new;
+    { // lateralGrowth :262-289 with HiblerConcentration.cpp:32-47
+        double del_c = newice * (1. / P.h0);
+        if (hi < h_true && !(conc >= 1))
+            del_c += (hi - h_true) * conc * P.phi_m / h_true;
+        c_new = conc + del_c;
+        if (c_new >= P.min_conc) {
+            hi += (newice - hi * del_c) / (conc + del_c); // updateThickness :257-260
+            if (del_c < 0)
+                Qow -= del_c * hs * ICE_LF * ICE_RHOSNOW / dt;
+            else
+                hs += (0. - hs * del_c) / (conc + del_c);
+        }
+    }
+    if (c_new < P.min_conc || hi < P.min_thick) { // :211-219
+        Qow += c_new * ICE_LF * (hi * ICE_RHO + hs * ICE_RHOSNOW) / dt;
+        c_new = 0;
+        hi = 0;
+        hs = 0;
+    }
+
+    // ---- PrognosticData::updateAndIntegrate (core/src/PrognosticData.cpp:63-71; PhysicsData.hpp:61,66)
+    hice[e] = hi * c_new;
+    cice[e] = c_new;
+    hsnow[e] = hs * c_new;
+    tice0[e] = Tnew;
+    newice_[e] = newice;
+
+    if (DIAG) {
+        double d[NSDG_NDIAG];
+        d[NSDG_D_RHO] = rho;
+        d[NSDG_D_QA] = q_a;
+        d[NSDG_D_QW] = q_w;
+        d[NSDG_D_QI] = q_i;
+        d[NSDG_D_CSPEC] = cspec;
+        d[NSDG_D_TAU] = tau;
+        d[NSDG_D_HI] = hi;
+        d[NSDG_D_HS] = hs;
+        d[NSDG_D_CNEW] = c_new;
+        d[NSDG_D_QIA] = Qia;
+        d[NSDG_D_QIO] = Qio;
+        d[NSDG_D_SUBL] = subl;
+        d[NSDG_D_DQDT] = dQ_dT;
+        d[NSDG_D_HIFROMS] = hifroms;
+        d[NSDG_D_QOW] = Qow;
+#pragma unroll
+        for (int k = 0; k < NSDG_NDIAG; ++k)
+            diag[(long)k * n + e] = d[k];
+    }
+}
+
+} // namespace
+
+extern "C" int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hice, double* cice, double* hsnow,
+    double* tice0, const double* sst, const double* sss, const double* tair, const double* tdew,
+    const double* slp, const double* qsw, const double* qlw, const double* mld, const double* snowfall,
+    const double* wind, double* newice, double* diag)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(n >= 0, "negative element count");
+    if (n == 0)
+        return NSDG_OK;
+    NSDG_CHECK_ARG(hice && cice && hsnow && tice0 && sst && sss && tair && tdew && slp && qsw && qlw && mld
+            && snowfall && wind && newice,
+        "null field pointer");
+    NSDG_CHECK_ARG(n < (1LL << 31) * 256, "element count too large for one launch");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const dim3 block(256), grid(nsdg_div_up(n, 256));
+    if (diag)
+        hipLaunchKernelGGL(column_step_kernel<true>, grid, block, 0, ctx->stream, ctx->column, (long)n, dt, hice, cice,
+            hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice, diag);
+    else
+        hipLaunchKernelGGL(column_step_kernel<false>, grid, block, 0, ctx->stream, ctx->column, (long)n, dt, hice, cice,
+            hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice, diag);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}

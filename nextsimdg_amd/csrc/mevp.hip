@@ -1,0 +1,478 @@
+// mevp.hip -- mEVP stress / velocity sub-cycle on a uniform rectangular mesh (CG2 velocity,
+// 8-coefficient DG stress, 3x3 Gauss points) and the per-step helper kernels around it.
+//
+// No counterpart in the reference snapshot (CMakeLists.txt:43-46); the scheme is stated in
+// DESIGN.md section 3.2 and restated on the CPU in oracle/dyn_oracle.c (parity unpinned).
+//
+// Variant 0 ("two-kernel"): per sub-iteration
+//   mevp_stress_kernel   one lane per element: gathers its 9 nodal velocities, forms the strain-rate
+//                        coefficients (sparse 8x9 constant operators folded into the instruction
+//                        stream), evaluates the VP law at the 9 Gauss points, relaxes the 3x8 stress
+//                        coefficients in place.
+//   mevp_velocity_kernel one lane per element = its 4 bottom-left-owned nodes: gathers the stress
+//                        of the (up to) 4 adjacent elements -- a node-centred gather, no atomics,
+//                        deterministic and independent of the decomposition -- and applies the
+//                        momentum update.
+// Variant 1 ("fused march") lives in mevp_fused.hip.
+#include "dg_tables.h"
+#include "nsdg_internal.h"
+
+namespace nsdg_mevp_detail {
+
+using namespace nsdg_tab;
+
+#define FMA_TAB(acc, tab, val)   \
+    do {                         \
+        const double t_ = (tab); \
+        if (t_ != 0.0)           \
+            acc += t_ * (val);   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// stress of one element from its 9 nodal velocities: S <- (1-1/alpha) S + (1/alpha) Proj sigma(v)
+__device__ __forceinline__ void stress_update(const double (&ul)[9], const double (&vl)[9], const double (&P)[9],
+    double ihx, double ihy, double ialpha, double dmin2, double (&s11)[8], double (&s12)[8], double (&s22)[8])
+{
+    double E11[8], E12[8], E22[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double uxx = 0., uyy = 0., vxx = 0., vyy = 0.;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            FMA_TAB(uxx, DX[i][a], ul[a]);
+            FMA_TAB(uyy, DY[i][a], ul[a]);
+            FMA_TAB(vxx, DX[i][a], vl[a]);
+            FMA_TAB(vyy, DY[i][a], vl[a]);
+        }
+        E11[i] = uxx * ihx;
+        E22[i] = vyy * ihy;
+        E12[i] = 0.5 * (uyy * ihy + vxx * ihx);
+    }
+    double r11[8], r12[8], r22[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        r11[i] = r12[i] = r22[i] = 0.;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        double e11 = 0., e12 = 0., e22 = 0.;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            FMA_TAB(e11, PSI_G3[q][i], E11[i]);
+            FMA_TAB(e12, PSI_G3[q][i], E12[i]);
+            FMA_TAB(e22, PSI_G3[q][i], E22[i]);
+        }
+        const double d2 = dmin2 + 1.25 * (e11 * e11 + e22 * e22) + 1.5 * e11 * e22 + e12 * e12;
+        const double pd = P[q] * rsqrt(d2);
+        const double t11 = pd * (0.625 * e11 + 0.375 * e22) - 0.5 * P[q];
+        const double t22 = pd * (0.625 * e22 + 0.375 * e11) - 0.5 * P[q];
+        const double t12 = pd * 0.25 * e12;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            FMA_TAB(r11[i], W_G3[q] * PSI_G3[q][i] * IMASS[i], t11);
+            FMA_TAB(r12[i], W_G3[q] * PSI_G3[q][i] * IMASS[i], t12);
+            FMA_TAB(r22[i], W_G3[q] * PSI_G3[q][i] * IMASS[i], t22);
+        }
+    }
+    const double keep = 1. - ialpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s11[i] = keep * s11[i] + ialpha * r11[i];
+        s12[i] = keep * s12[i] + ialpha * r12[i];
+        s22[i] = keep * s22[i] + ialpha * r22[i];
+    }
+}
+
+// -(sigma, grad phi_a)_K for local node A of an element with stress coefficients s11/s12/s22
+template <int A>
+__device__ __forceinline__ void node_contrib(const double (&s11)[8], const double (&s12)[8], const double (&s22)[8],
+    double hx, double hy, double& cx, double& cy)
+{
+    double gx11 = 0., gy12 = 0., gx12 = 0., gy22 = 0.;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        FMA_TAB(gx11, MASS[i] * DX[i][A], s11[i]);
+        FMA_TAB(gy12, MASS[i] * DY[i][A], s12[i]);
+        FMA_TAB(gx12, MASS[i] * DX[i][A], s12[i]);
+        FMA_TAB(gy22, MASS[i] * DY[i][A], s22[i]);
+    }
+    cx = -(hy * gx11 + hx * gy12);
+    cy = -(hy * gx12 + hx * gy22);
+}
+
+struct NodeIn {
+    const double *u_old, *v_old, *u0, *v0, *tax, *tay, *uo, *vo, *cgh, *cga;
+};
+
+// momentum update of one interior node (eq. for v^p)
+__device__ __forceinline__ void node_update(const nsdg_mevp_params& P, double dt, const NodeIn& in, long n, double divx,
+    double divy, double ilumped, double& un, double& vn)
+{
+    const double uu = in.u_old[n], vv = in.v_old[n];
+    const double uoc = in.uo[n], voc = in.vo[n];
+    const double du = uoc - uu, dv = voc - vv;
+    const double absocn = sqrt(du * du + dv * dv);
+    const double h = fmax(in.cgh[n], P.h_min);
+    const double a_ = fmin(fmax(in.cga[n], 0.), 1.);
+    const double mdt = P.rho_ice * h / dt;
+    const double cdrag = a_ * (P.c_ocean * P.rho_ocean) * absocn;
+    const double denom = 1. / (mdt * (1. + P.beta) + cdrag);
+    const double cor = P.rho_ice * h * P.fc;
+    un = denom * (mdt * (P.beta * uu + in.u0[n]) + a_ * in.tax[n] + cdrag * uoc + cor * (vv - voc) + divx * ilumped);
+    vn = denom * (mdt * (P.beta * vv + in.v0[n]) + a_ * in.tay[n] + cdrag * voc - cor * (uu - uoc) + divy * ilumped);
+}
+
+__global__ __launch_bounds__(256) void mevp_stress_kernel(int nx, int ny, int k0, int k1, double ihx, double ihy,
+    double ialpha, double dmin2, const double* __restrict__ u, const double* __restrict__ v,
+    const double* __restrict__ pg, double* __restrict__ S11, double* __restrict__ S12, double* __restrict__ S22)
+{
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy = k0 + blockIdx.y * 4 + threadIdx.y;
+    if (ix >= nx || iy >= k1)
+        return;
+    const long N = (long)nx * ny;
+    const long e = (long)iy * nx + ix;
+    const int nn = 2 * nx + 1;
+    double ul[9], vl[9], P[9], s11[8], s12[8], s22[8];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        const long n = (long)(2 * iy + a / 3) * nn + 2 * ix + a % 3;
+        ul[a] = u[n];
+        vl[a] = v[n];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+        P[q] = pg[q * N + e];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s11[i] = S11[i * N + e];
+        s12[i] = S12[i * N + e];
+        s22[i] = S22[i * N + e];
+    }
+    stress_update(ul, vl, P, ihx, ihy, ialpha, dmin2, s11, s12, s22);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        S11[i * N + e] = s11[i];
+        S12[i * N + e] = s12[i];
+        S22[i * N + e] = s22[i];
+    }
+}
+
+__device__ __forceinline__ void load_stress(const double* __restrict__ S11, const double* __restrict__ S12,
+    const double* __restrict__ S22, long N, long e, double (&s11)[8], double (&s12)[8], double (&s22)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s11[i] = S11[i * N + e];
+        s12[i] = S12[i * N + e];
+        s22[i] = S22[i * N + e];
+    }
+}
+
+__global__ __launch_bounds__(256) void mevp_velocity_kernel(nsdg_mevp_params P, int nx, int ny, int j0, int j1, double hx,
+    double hy, double dt, const double* __restrict__ S11, const double* __restrict__ S12, const double* __restrict__ S22,
+    NodeIn in, double* __restrict__ u_new, double* __restrict__ v_new)
+{
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
+    if (ix >= nx || iy >= j1)
+        return;
+    const long N = (long)nx * ny;
+    const long e = (long)iy * nx + ix;
+    const int nn = 2 * nx + 1;
+    const double area = hx * hy;
+    double s11[8], s12[8], s22[8];
+    double cx, cy;
+    // node sums, accumulated in the order below-left, below, left, own (same as the oracle)
+    double vx_ = 0., vy_ = 0., exx = 0., exy = 0., eyx = 0., eyy = 0., ccx, ccy;
+    const bool hasL = ix > 0, hasB = iy > 0;
+    if (hasL && hasB) {
+        load_stress(S11, S12, S22, N, e - nx - 1, s11, s12, s22);
+        node_contrib<8>(s11, s12, s22, hx, hy, cx, cy);
+        vx_ += cx, vy_ += cy;
+    }
+    if (hasB) {
+        load_stress(S11, S12, S22, N, e - nx, s11, s12, s22);
+        node_contrib<6>(s11, s12, s22, hx, hy, cx, cy);
+        vx_ += cx, vy_ += cy;
+        node_contrib<7>(s11, s12, s22, hx, hy, cx, cy);
+        exx += cx, exy += cy;
+    }
+    if (hasL) {
+        load_stress(S11, S12, S22, N, e - 1, s11, s12, s22);
+        node_contrib<2>(s11, s12, s22, hx, hy, cx, cy);
+        vx_ += cx, vy_ += cy;
+        node_contrib<5>(s11, s12, s22, hx, hy, cx, cy);
+        eyx += cx, eyy += cy;
+    }
+    load_stress(S11, S12, S22, N, e, s11, s12, s22);
+    node_contrib<0>(s11, s12, s22, hx, hy, cx, cy);
+    vx_ += cx, vy_ += cy;
+    node_contrib<1>(s11, s12, s22, hx, hy, cx, cy);
+    exx += cx, exy += cy;
+    node_contrib<3>(s11, s12, s22, hx, hy, cx, cy);
+    eyx += cx, eyy += cy;
+    node_contrib<4>(s11, s12, s22, hx, hy, ccx, ccy);
+
+    const long nV = (long)(2 * iy) * nn + 2 * ix; // vertex; EX = nV+1; EY = nV+nn; C = nV+nn+1
+    double un, vn;
+    // vertex node (4 elements, lumped = 4/36 area)
+    if (hasL && hasB) {
+        node_update(P, dt, in, nV, vx_, vy_, 1. / (area * (4. * LUMP[0])), un, vn);
+    } else
+        un = vn = 0.;
+    u_new[nV] = un, v_new[nV] = vn;
+    // bottom edge-mid node (2 elements)
+    if (hasB) {
+        node_update(P, dt, in, nV + 1, exx, exy, 1. / (area * (2. * LUMP[1])), un, vn);
+    } else
+        un = vn = 0.;
+    u_new[nV + 1] = un, v_new[nV + 1] = vn;
+    // left edge-mid node (2 elements)
+    if (hasL) {
+        node_update(P, dt, in, nV + nn, eyx, eyy, 1. / (area * (2. * LUMP[3])), un, vn);
+    } else
+        un = vn = 0.;
+    u_new[nV + nn] = un, v_new[nV + nn] = vn;
+    // centre node (1 element)
+    node_update(P, dt, in, nV + nn + 1, ccx, ccy, 1. / (area * LUMP[4]), un, vn);
+    u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
+    // right column / top row of the local lattice are boundary nodes (v = 0)
+    if (ix == nx - 1) {
+        u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
+        u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
+    }
+    if (iy == ny - 1) {
+        u_new[nV + 2 * nn] = 0., v_new[nV + 2 * nn] = 0.;
+        u_new[nV + 2 * nn + 1] = 0., v_new[nV + 2 * nn + 1] = 0.;
+        if (ix == nx - 1)
+            u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double psi_rt(int c, double x, double y)
+{
+    switch (c) {
+    case 0: return 1.;
+    case 1: return x;
+    case 2: return y;
+    case 3: return x * x - 1. / 12.;
+    case 4: return y * y - 1. / 12.;
+    default: return x * y;
+    }
+}
+
+// nodal average of a DG field: one lane per CG2 node, gathers the 1/2/4 adjacent elements
+__global__ __launch_bounds__(256) void dg_to_cg_kernel(int nx, int ny, int nc, const double* __restrict__ f, double* __restrict__ g)
+{
+    const int gx = blockIdx.x * 64 + threadIdx.x;
+    const int gy = blockIdx.y * 4 + threadIdx.y;
+    const int nn = 2 * nx + 1, nm = 2 * ny + 1;
+    if (gx >= nn || gy >= nm)
+        return;
+    const long N = (long)nx * ny;
+    const int ix_hi = gx / 2, ix_lo = (gx % 2 == 0) ? gx / 2 - 1 : gx / 2;
+    const int iy_hi = gy / 2, iy_lo = (gy % 2 == 0) ? gy / 2 - 1 : gy / 2;
+    double s = 0.;
+    int cnt = 0;
+    for (int iy = iy_lo; iy <= iy_hi; ++iy)
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+            if (ix < 0 || ix >= nx || iy < 0 || iy >= ny)
+                continue;
+            const double x = -0.5 + 0.5 * (gx - 2 * ix), y = -0.5 + 0.5 * (gy - 2 * iy);
+            const long e = (long)iy * nx + ix;
+            double val = 0.;
+            for (int c = 0; c < nc; ++c)
+                val += f[c * N + e] * psi_rt(c, x, y);
+            s += val;
+            ++cnt;
+        }
+    g[(long)gy * nn + gx] = s / cnt;
+}
+
+__global__ __launch_bounds__(256) void ice_strength_kernel(int nx, int ny, int j0, int j1, double pstar, double compaction,
+    const double* __restrict__ H, const double* __restrict__ A, double* __restrict__ pg)
+{
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
+    if (ix >= nx || iy >= j1)
+        return;
+    const long N = (long)nx * ny;
+    const long e = (long)iy * nx + ix;
+    double hc[6], ac[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        hc[c] = H[c * N + e];
+        ac[c] = A[c * N + e];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        double h = 0., a = 0.;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            FMA_TAB(h, PSI_G3[q][c], hc[c]);
+            FMA_TAB(a, PSI_G3[q][c], ac[c]);
+        }
+        h = fmax(h, 0.);
+        a = fmin(fmax(a, 0.), 1.);
+        pg[q * N + e] = pstar * h * exp(-compaction * (1. - a));
+    }
+}
+
+__global__ __launch_bounds__(256) void wind_stress_kernel(long n, double f_atm, const double* __restrict__ ua,
+    const double* __restrict__ va, double* __restrict__ tax, double* __restrict__ tay)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double a = ua[i], b = va[i];
+    const double m = sqrt(a * a + b * b);
+    tax[i] = f_atm * m * a;
+    tay[i] = f_atm * m * b;
+}
+
+} // namespace nsdg_mevp_detail
+
+using namespace nsdg_mevp_detail;
+
+// defined in mevp_fused.hip
+int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, double dt, double* s11, double* s12, double* s22,
+    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
+    const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh, const double* cga,
+    const double* pg);
+
+extern "C" {
+
+int nsdg_dg_to_cg(nsdg_ctx* ctx, int32_t ncoef, const double* f_dg, double* f_cg)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(ncoef == 1 || ncoef == 3 || ncoef == 6, "ncoef must be 1, 3 or 6");
+    NSDG_CHECK_ARG(f_dg && f_cg, "null field pointer");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const dim3 block(64, 4), grid(nsdg_div_up(2 * ctx->nx + 1, 64), nsdg_div_up(2 * ctx->ny + 1, 4));
+    hipLaunchKernelGGL(dg_to_cg_kernel, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, ncoef, f_dg, f_cg);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
+int nsdg_ice_strength(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* H, const double* A, double* pg)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
+    NSDG_CHECK_ARG(H && A && pg, "null field pointer");
+    if (j0 == j1)
+        return NSDG_OK;
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4));
+    hipLaunchKernelGGL(ice_strength_kernel, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, ctx->mevp.pstar,
+        ctx->mevp.compaction, H, A, pg);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
+int nsdg_wind_stress(nsdg_ctx* ctx, int64_t nnodes, const double* ua, const double* va, double* tax, double* tay)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(nnodes >= 0, "negative node count");
+    NSDG_CHECK_ARG(ua && va && tax && tay, "null field pointer");
+    if (nnodes == 0)
+        return NSDG_OK;
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(wind_stress_kernel, dim3(nsdg_div_up(nnodes, 256)), dim3(256), 0, ctx->stream, (long)nnodes,
+        ctx->mevp.c_atm * ctx->mevp.rho_atm, ua, va, tax, tay);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
+int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, const double* v, const double* pg, double* s11,
+    double* s12, double* s22)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(0 <= k0 && k0 <= k1 && k1 <= ctx->ny, "row range outside the local array");
+    NSDG_CHECK_ARG(u && v && pg && s11 && s12 && s22, "null field pointer");
+    if (k0 == k1)
+        return NSDG_OK;
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(k1 - k0, 4));
+    hipLaunchKernelGGL(mevp_stress_kernel, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, k0, k1, 1. / ctx->hx, 1. / ctx->hy,
+        1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, u, v, pg, s11, s12, s22);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
+int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const double* s11, const double* s12,
+    const double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0,
+    const double* v0, const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh,
+    const double* cga)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
+    NSDG_CHECK_ARG(s11 && s12 && s22 && u_old && v_old && u_new && v_new && u0 && v0 && tax && tay && uo && vo && cgh && cga,
+        "null field pointer");
+    NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
+    NSDG_CHECK_ARG(dt > 0, "dt must be positive");
+    if (j0 == j1)
+        return NSDG_OK;
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const NodeIn in = { u_old, v_old, u0, v0, tax, tay, uo, vo, cgh, cga };
+    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4));
+    hipLaunchKernelGGL(mevp_velocity_kernel, grid, block, 0, ctx->stream, ctx->mevp, ctx->nx, ctx->ny, j0, j1, ctx->hx, ctx->hy,
+        dt, s11, s12, s22, in, u_new, v_new);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
+int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, double* s11, double* s12, double* s22,
+    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
+    const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh, const double* cga,
+    const double* pg)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(0 <= k0 && k0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "need 0 <= k0 <= j0 <= j1 <= ny");
+    NSDG_CHECK_ARG(j0 - k0 <= 1, "at most one redundant stress row below the owned rows");
+    if (ctx->mevp_variant == 1) {
+        NSDG_CHECK_ARG(s11 && s12 && s22 && u_old && v_old && u_new && v_new && u0 && v0 && tax && tay && uo && vo && cgh
+                && cga && pg,
+            "null field pointer");
+        NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
+        NSDG_CHECK_ARG(dt > 0, "dt must be positive");
+        if (k0 == j1)
+            return NSDG_OK;
+        NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+        return nsdg_launch_mevp_fused(ctx, k0, j0, j1, dt, s11, s12, s22, u_old, v_old, u_new, v_new, u0, v0, tax, tay, uo, vo,
+            cgh, cga, pg);
+    }
+    int rc = nsdg_mevp_stress(ctx, k0, j1, u_old, v_old, pg, s11, s12, s22);
+    if (rc)
+        return rc;
+    return nsdg_mevp_velocity(ctx, j0, j1, dt, s11, s12, s22, u_old, v_old, u_new, v_new, u0, v0, tax, tay, uo, vo, cgh, cga);
+}
+
+int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u, double* v,
+    const double* u0, const double* v0, const double* tax, const double* tay, const double* uo, const double* vo,
+    const double* cgh, const double* cga, const double* pg, double* scratch)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(nsub >= 0, "negative sub-iteration count");
+    NSDG_CHECK_ARG(u && v && scratch, "null field pointer");
+    NSDG_CHECK_ARG(u0 != u && v0 != v, "u0/v0 (velocity at step start) must not alias the iterate u/v");
+    const long nnodes = (long)(2 * ctx->nx + 1) * (2 * ctx->ny + 1);
+    double* ua = u;
+    double* va = v;
+    double* ub = scratch;
+    double* vb = scratch + nnodes;
+    for (int it = 0; it < nsub; ++it) {
+        int rc = nsdg_mevp_iterate(ctx, 0, 0, ctx->ny, dt, s11, s12, s22, ua, va, ub, vb, u0, v0, tax, tay, uo, vo, cgh, cga, pg);
+        if (rc)
+            return rc;
+        double* t = ua; ua = ub; ub = t;
+        t = va; va = vb; vb = t;
+    }
+    if (ua != u) { // odd number of sub-iterations: the result sits in scratch
+        NSDG_CHECK_HIP(hipMemcpyAsync(u, ua, nnodes * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        NSDG_CHECK_HIP(hipMemcpyAsync(v, va, nnodes * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return NSDG_OK;
+}
+
+} // extern "C"

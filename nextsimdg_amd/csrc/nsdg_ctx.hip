@@ -1,0 +1,138 @@
+// nsdg_ctx.hip -- context, parameters and error reporting of libnsdg.so.
+#include <cstring>
+
+#include "nsdg_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void nsdg_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int nsdg_abi_version(void) { return NSDG_ABI_VERSION; }
+
+const char* nsdg_last_error(void) { return g_err; }
+
+void nsdg_column_default_params(nsdg_column_params* p)
+{
+    // defaults of the reference: physics/src/modules/NextsimPhysics.cpp:76-82, ThermoIce0.cpp:30-31,
+    // HiblerConcentration.cpp:28-29, CCSMIceAlbedo.cpp:22-23; default module = first listed
+    // (core/src/ModuleLoader.cpp:51-54): SMUIceAlbedo, LinearFreezing.
+    p->drag_ocean_q = 1.5e-3;
+    p->drag_ocean_t = 0.83e-3;
+    p->drag_ice_t = 1.3e-3;
+    p->ocean_albedo = 0.07;
+    p->i0 = 0.17;
+    p->min_conc = 1e-12;
+    p->min_thick = 0.01;
+    p->ks = 0.3096;
+    p->h0 = 0.25;
+    p->phi_m = 0.5;
+    p->ccsm_ice_albedo = 0.538;
+    p->ccsm_snow_albedo = 0.8256;
+    p->flooding = 1;
+    p->albedo_kind = NSDG_ALBEDO_SMU;
+    p->freezing_kind = NSDG_FREEZING_LINEAR;
+    p->reserved = 0;
+}
+
+void nsdg_mevp_default_params(nsdg_mevp_params* p)
+{
+    p->rho_ice = 900.;
+    p->rho_atm = 1.3;
+    p->rho_ocean = 1026.;
+    p->c_atm = 1.2e-3;
+    p->c_ocean = 5.5e-3;
+    p->pstar = 27.5e3;
+    p->compaction = 20.;
+    p->delta_min = 2e-9;
+    p->fc = 1.46e-4;
+    p->alpha = 1500.;
+    p->beta = 1500.;
+    p->h_min = 1e-4;
+}
+
+int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
+{
+    NSDG_CHECK_ARG(out != nullptr, "null output pointer");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        nsdg_set_error("nsdg_ctx_create: no HIP device available");
+        return NSDG_ERR_NODEVICE;
+    }
+    NSDG_CHECK_ARG(device_id >= 0 && device_id < ndev, "device id out of range");
+    NSDG_CHECK_HIP(hipSetDevice(device_id));
+    nsdg_ctx* c = new nsdg_ctx();
+    c->device = device_id;
+    c->stream = (hipStream_t)stream;
+    nsdg_column_default_params(&c->column);
+    nsdg_mevp_default_params(&c->mevp);
+    c->nx = c->ny = 0;
+    c->hx = c->hy = 0.;
+    c->mevp_variant = 0;
+    c->d_ptrs = nullptr;
+    *out = c;
+    return NSDG_OK;
+}
+
+int nsdg_ctx_destroy(nsdg_ctx* ctx)
+{
+    if (!ctx)
+        return NSDG_OK;
+    delete ctx;
+    return NSDG_OK;
+}
+
+int nsdg_ctx_synchronize(nsdg_ctx* ctx)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return NSDG_OK;
+}
+
+int nsdg_column_params_set(nsdg_ctx* ctx, const nsdg_column_params* p)
+{
+    NSDG_CHECK_ARG(ctx && p, "null argument");
+    NSDG_CHECK_ARG(p->albedo_kind >= 0 && p->albedo_kind <= 2, "albedo_kind must be 0 (SMU), 1 (SMU2) or 2 (CCSM)");
+    NSDG_CHECK_ARG(p->freezing_kind >= 0 && p->freezing_kind <= 1, "freezing_kind must be 0 (linear) or 1 (UNESCO)");
+    ctx->column = *p;
+    return NSDG_OK;
+}
+
+int nsdg_mevp_params_set(nsdg_ctx* ctx, const nsdg_mevp_params* p)
+{
+    NSDG_CHECK_ARG(ctx && p, "null argument");
+    NSDG_CHECK_ARG(p->alpha > 0 && p->beta > 0, "alpha and beta must be positive");
+    ctx->mevp = *p;
+    return NSDG_OK;
+}
+
+int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(nx > 0 && ny > 0, "nx and ny must be positive");
+    NSDG_CHECK_ARG(hx > 0 && hy > 0, "cell sizes must be positive");
+    NSDG_CHECK_ARG((long)(2 * (long)nx + 1) * (2 * (long)ny + 1) < (1L << 31), "grid too large for 32-bit node indices");
+    ctx->nx = nx;
+    ctx->ny = ny;
+    ctx->hx = hx;
+    ctx->hy = hy;
+    return NSDG_OK;
+}
+
+int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(variant == 0 || variant == 1, "variant must be 0 or 1");
+    ctx->mevp_variant = variant;
+    return NSDG_OK;
+}
+
+} // extern "C"

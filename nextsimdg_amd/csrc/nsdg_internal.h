@@ -1,0 +1,52 @@
+// nsdg_internal.h -- shared by the translation units of libnsdg.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/nsdg.h"
+
+struct nsdg_ctx {
+    int device;
+    hipStream_t stream;
+    nsdg_column_params column;
+    nsdg_mevp_params mevp;
+    int nx, ny; // local element array
+    double hx, hy;
+    int mevp_variant;
+    // device scratch for small host->device tables (field pointer lists of the transport stage)
+    double** d_ptrs;
+};
+
+void nsdg_set_error(const char* fmt, ...);
+
+#define NSDG_CHECK_ARG(cond, msg)                                        \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            nsdg_set_error("%s: %s", __func__, msg);                    \
+            return NSDG_ERR_ARG;                                         \
+        }                                                                \
+    } while (0)
+
+#define NSDG_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            nsdg_set_error("%s: %s failed: %s", __func__, #expr, hipGetErrorString(e_)); \
+            return NSDG_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define NSDG_CHECK_LAUNCH() NSDG_CHECK_HIP(hipGetLastError())
+
+#define NSDG_NEED_GRID(ctx)                                             \
+    do {                                                                \
+        NSDG_CHECK_ARG(ctx != nullptr, "null context");                 \
+        if ((ctx)->nx <= 0) {                                           \
+            nsdg_set_error("%s: nsdg_grid_set was not called", __func__); \
+            return NSDG_ERR_STATE;                                      \
+        }                                                               \
+    } while (0)
+
+static inline int nsdg_div_up(long a, long b) { return (int)((a + b - 1) / b); }

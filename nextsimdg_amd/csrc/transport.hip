@@ -1,0 +1,323 @@
+// transport.hip -- DG upwind transport on a uniform rectangular mesh: advection-velocity preparation
+// and the Runge-Kutta stage kernel (DG0 / DG1 / DG2).
+//
+// No counterpart in the reference snapshot (CMakeLists.txt:43-46 comments the dynamics component
+// out); the scheme is the one stated in DESIGN.md section 3.1 and restated on the CPU in
+// oracle/dyn_oracle.c (parity unpinned).
+//
+// Stage kernel shape: one lane per element, gather formulation -- every element evaluates the
+// upwind flux on its own four edges (a shared edge is evaluated twice with bit-identical
+// arithmetic), so there are no write conflicts and the result does not depend on the launch
+// geometry or on a row-block decomposition.  Coefficients are coefficient-major planes, so each of
+// the nc + 4*nc neighbour loads and the nc stores is a unit-stride wave access.  Basis values at the
+// quadrature points are compile-time constants (tools/gen_tables.py) folded into the instruction
+// stream by full unrolling; zero entries cost nothing.  HBM-bound: 1008 B / element-step for
+// DG2 x 2 fields x RK3.
+#include "dg_tables.h"
+#include "nsdg_internal.h"
+
+namespace {
+
+using namespace nsdg_tab;
+
+template <int ORDER>
+struct DG {
+    static constexpr int NC = ORDER == 0 ? 1 : (ORDER == 1 ? 3 : 6);
+    static constexpr int NG = ORDER + 1; // edge Gauss points
+    static constexpr int NQ = (ORDER + 1) * (ORDER + 1); // volume Gauss points
+};
+
+// table accessors resolved at compile time after unrolling
+template <int ORDER> __device__ __forceinline__ constexpr double t_psi(int q, int i) { return ORDER == 1 ? PSI_G2[q & 3][i] : PSI_G3[q][i]; }
+template <int ORDER> __device__ __forceinline__ constexpr double t_psix(int q, int i) { return ORDER == 1 ? PSIX_G2[q & 3][i] : PSIX_G3[q][i]; }
+template <int ORDER> __device__ __forceinline__ constexpr double t_psiy(int q, int i) { return ORDER == 1 ? PSIY_G2[q & 3][i] : PSIY_G3[q][i]; }
+template <int ORDER> __device__ __forceinline__ constexpr double t_w(int q) { return ORDER == 1 ? W_G2[q & 3] : W_G3[q]; }
+template <int ORDER> __device__ __forceinline__ constexpr double t_gw(int g) { return ORDER == 0 ? GW1[0] : (ORDER == 1 ? GW2[g & 1] : GW3[g]); }
+template <int ORDER> __device__ __forceinline__ constexpr double t_l(int g, int i) { return ORDER == 0 ? PSI_L1[0][i] : (ORDER == 1 ? PSI_L2[g & 1][i] : PSI_L3[g][i]); }
+template <int ORDER> __device__ __forceinline__ constexpr double t_r(int g, int i) { return ORDER == 0 ? PSI_R1[0][i] : (ORDER == 1 ? PSI_R2[g & 1][i] : PSI_R3[g][i]); }
+template <int ORDER> __device__ __forceinline__ constexpr double t_b(int g, int i) { return ORDER == 0 ? PSI_B1[0][i] : (ORDER == 1 ? PSI_B2[g & 1][i] : PSI_B3[g][i]); }
+template <int ORDER> __device__ __forceinline__ constexpr double t_t(int g, int i) { return ORDER == 0 ? PSI_T1[0][i] : (ORDER == 1 ? PSI_T2[g & 1][i] : PSI_T3[g][i]); }
+template <int ORDER> __device__ __forceinline__ constexpr double t_le(int g, int k) { return ORDER == 0 ? L_E1[0][k] : (ORDER == 1 ? L_E2[g & 1][k] : L_E3[g][k]); }
+
+#define MAXF 4
+struct FieldPtrs {
+    const double* phi0[MAXF];
+    const double* phis[MAXF];
+    double* out[MAXF];
+};
+
+// acc += tab * val where tab is a compile-time table entry: after full unrolling the load of the
+// constexpr table folds to a literal and the branch disappears, so zero entries cost nothing.
+#define FMA_TAB(acc, tab, val)   \
+    do {                         \
+        const double t_ = (tab); \
+        if (t_ != 0.0)           \
+            acc += t_ * (val);   \
+    } while (0)
+
+template <int ORDER>
+__global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, int j0, int j1, double ihx, double ihy,
+    double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
+    const double* __restrict__ un_x, const double* __restrict__ un_y)
+{
+    constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG, NQ = DG<ORDER>::NQ;
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
+    if (ix >= nx || iy >= j1)
+        return;
+    const double* __restrict__ phis = fp.phis[blockIdx.z];
+    const double* __restrict__ phi0 = fp.phi0[blockIdx.z];
+    double* __restrict__ out = fp.out[blockIdx.z];
+    const long N = (long)nx * ny;
+    const long e = (long)iy * nx + ix;
+    const bool hasL = ix > 0, hasR = ix + 1 < nx, hasB = iy > 0, hasT = iy + 1 < ny;
+
+    double c[NC], cl[NC], cr[NC], cb[NC], ct[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        c[k] = phis[k * N + e];
+        cl[k] = hasL ? phis[k * N + e - 1] : 0.;
+        cr[k] = hasR ? phis[k * N + e + 1] : 0.;
+        cb[k] = hasB ? phis[k * N + e - nx] : 0.;
+        ct[k] = hasT ? phis[k * N + e + nx] : 0.;
+    }
+    double rhs[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+        rhs[k] = 0.;
+
+    if constexpr (ORDER > 0) { // cell term: int phi v . grad psi_i
+        double vx[NC], vy[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            vx[k] = vx_dg[k * N + e] * ihx;
+            vy[k] = vy_dg[k * N + e] * ihy;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            double f = 0., wx = 0., wy = 0.;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                FMA_TAB(f, t_psi<ORDER>(q, k), c[k]);
+                FMA_TAB(wx, t_psi<ORDER>(q, k), vx[k]);
+                FMA_TAB(wy, t_psi<ORDER>(q, k), vy[k]);
+            }
+            const double fx = f * wx, fy = f * wy;
+#pragma unroll
+            for (int i = 1; i < NC; ++i) {
+                FMA_TAB(rhs[i], t_w<ORDER>(q) * t_psix<ORDER>(q, i), fx);
+                FMA_TAB(rhs[i], t_w<ORDER>(q) * t_psiy<ORDER>(q, i), fy);
+            }
+        }
+    }
+    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
+    const long exl = (long)iy * (nx + 1) + ix; // left vertical edge; right = exl + 1
+    const long eyb = (long)iy * nx + ix; // bottom horizontal edge; top = eyb + nx
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const double unl = un_x[g * NEX + exl], unr = un_x[g * NEX + exl + 1];
+        const double unb = un_y[g * NEY + eyb], unt = un_y[g * NEY + eyb + nx];
+        double in_r = 0., in_l = 0., in_t = 0., in_b = 0., out_r = 0., out_l = 0., out_t = 0., out_b = 0.;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            FMA_TAB(in_r, t_r<ORDER>(g, k), c[k]);
+            FMA_TAB(in_l, t_l<ORDER>(g, k), c[k]);
+            FMA_TAB(in_t, t_t<ORDER>(g, k), c[k]);
+            FMA_TAB(in_b, t_b<ORDER>(g, k), c[k]);
+            FMA_TAB(out_r, t_l<ORDER>(g, k), cr[k]);
+            FMA_TAB(out_l, t_r<ORDER>(g, k), cl[k]);
+            FMA_TAB(out_t, t_b<ORDER>(g, k), ct[k]);
+            FMA_TAB(out_b, t_t<ORDER>(g, k), cb[k]);
+        }
+        // upwind fluxes (outward normal velocity is +un on right/top, the flux direction is +x/+y)
+        const double fr = (fmax(unr, 0.) * in_r + fmin(unr, 0.) * out_r) * ihx;
+        const double fl = (fmax(unl, 0.) * out_l + fmin(unl, 0.) * in_l) * ihx;
+        const double ft = (fmax(unt, 0.) * in_t + fmin(unt, 0.) * out_t) * ihy;
+        const double fb = (fmax(unb, 0.) * out_b + fmin(unb, 0.) * in_b) * ihy;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            FMA_TAB(rhs[i], -t_gw<ORDER>(g) * t_r<ORDER>(g, i), fr);
+            FMA_TAB(rhs[i], t_gw<ORDER>(g) * t_l<ORDER>(g, i), fl);
+            FMA_TAB(rhs[i], -t_gw<ORDER>(g) * t_t<ORDER>(g, i), ft);
+            FMA_TAB(rhs[i], t_gw<ORDER>(g) * t_b<ORDER>(g, i), fb);
+        }
+    }
+    if (a != 0.) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            out[i * N + e] = a * phi0[i * N + e] + b * (c[i] + dt * IMASS[i] * rhs[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            out[i * N + e] = b * (c[i] + dt * IMASS[i] * rhs[i]);
+    }
+}
+
+// CG2 nodal velocity -> DG velocity (L2 projection) per element, and edge-normal velocities at the
+// edge Gauss points.  One lane per element; the lane also owns its left and bottom edge, the last
+// column / row additionally writes the right / top boundary edge.
+template <int ORDER>
+__global__ __launch_bounds__(256) void prepare_advection_kernel(int nx, int ny, const double* __restrict__ u,
+    const double* __restrict__ v, double* __restrict__ vx_dg, double* __restrict__ vy_dg, double* __restrict__ un_x,
+    double* __restrict__ un_y)
+{
+    constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy = blockIdx.y * 4 + threadIdx.y;
+    if (ix >= nx || iy >= ny)
+        return;
+    const long N = (long)nx * ny;
+    const long e = (long)iy * nx + ix;
+    const int nn = 2 * nx + 1;
+    double ul[9], vl[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+        const long n = (long)(2 * iy + a / 3) * nn + 2 * ix + a % 3;
+        ul[a] = u[n];
+        vl[a] = v[n];
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        double sx = 0., sy = 0.;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            FMA_TAB(sx, PV[i][a], ul[a]);
+            FMA_TAB(sy, PV[i][a], vl[a]);
+        }
+        vx_dg[i * N + e] = sx;
+        vy_dg[i * N + e] = sy;
+    }
+    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        double sl = 0., sr = 0., sb = 0., st = 0.;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            FMA_TAB(sl, t_le<ORDER>(g, k), ul[3 * k]);
+            FMA_TAB(sr, t_le<ORDER>(g, k), ul[3 * k + 2]);
+            FMA_TAB(sb, t_le<ORDER>(g, k), vl[k]);
+            FMA_TAB(st, t_le<ORDER>(g, k), vl[6 + k]);
+        }
+        un_x[g * NEX + (long)iy * (nx + 1) + ix] = sl;
+        if (ix == nx - 1)
+            un_x[g * NEX + (long)iy * (nx + 1) + nx] = sr;
+        un_y[g * NEY + (long)iy * nx + ix] = sb;
+        if (iy == ny - 1)
+            un_y[g * NEY + (long)ny * nx + ix] = st;
+    }
+}
+
+template <int ORDER>
+int launch_stage(nsdg_ctx* ctx, int j0, int j1, double dt, double a, double b, int nfields, const FieldPtrs& fp,
+    const double* vx, const double* vy, const double* unx, const double* uny)
+{
+    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4), nfields);
+    hipLaunchKernelGGL(transport_stage_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, 1. / ctx->hx,
+        1. / ctx->hy, dt, a, b, fp, vx, vy, unx, uny);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
+int stage_dispatch(nsdg_ctx* ctx, int order, int j0, int j1, double dt, double a, double b, int nfields, const FieldPtrs& fp,
+    const double* vx, const double* vy, const double* unx, const double* uny)
+{
+    switch (order) {
+    case 0: return launch_stage<0>(ctx, j0, j1, dt, a, b, nfields, fp, vx, vy, unx, uny);
+    case 1: return launch_stage<1>(ctx, j0, j1, dt, a, b, nfields, fp, vx, vy, unx, uny);
+    default: return launch_stage<2>(ctx, j0, j1, dt, a, b, nfields, fp, vx, vy, unx, uny);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int nsdg_prepare_advection(nsdg_ctx* ctx, int32_t order, const double* u, const double* v, double* vx_dg, double* vy_dg,
+    double* un_x, double* un_y)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(order >= 0 && order <= 2, "order must be 0, 1 or 2");
+    NSDG_CHECK_ARG(u && v && vx_dg && vy_dg && un_x && un_y, "null field pointer");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(ctx->ny, 4));
+    if (order == 0)
+        hipLaunchKernelGGL(prepare_advection_kernel<0>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, u, v, vx_dg, vy_dg, un_x, un_y);
+    else if (order == 1)
+        hipLaunchKernelGGL(prepare_advection_kernel<1>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, u, v, vx_dg, vy_dg, un_x, un_y);
+    else
+        hipLaunchKernelGGL(prepare_advection_kernel<2>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, u, v, vx_dg, vy_dg, un_x, un_y);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
+int nsdg_transport_stage(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, double dt, double a, double b, int32_t nfields,
+    const double* const* phi0, const double* const* phis, double* const* out, const double* vx_dg, const double* vy_dg,
+    const double* un_x, const double* un_y)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(order >= 0 && order <= 2, "order must be 0, 1 or 2");
+    NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
+    NSDG_CHECK_ARG(nfields >= 1 && nfields <= MAXF, "nfields must be 1..4");
+    NSDG_CHECK_ARG(phi0 && phis && out && vx_dg && vy_dg && un_x && un_y, "null pointer");
+    if (j0 == j1)
+        return NSDG_OK;
+    FieldPtrs fp;
+    for (int f = 0; f < MAXF; ++f) {
+        const int s = f < nfields ? f : 0;
+        NSDG_CHECK_ARG(phi0[s] && phis[s] && out[s], "null field pointer");
+        NSDG_CHECK_ARG(out[s] != phis[s], "out must not alias phis (neighbours are read)");
+        fp.phi0[f] = phi0[s];
+        fp.phis[f] = phis[s];
+        fp.out[f] = out[s];
+    }
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    return stage_dispatch(ctx, order, j0, j1, dt, a, b, nfields, fp, vx_dg, vy_dg, un_x, un_y);
+}
+
+int nsdg_transport_step(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields, double* const* phi, const double* vx_dg,
+    const double* vy_dg, const double* un_x, const double* un_y, double* scratch)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(order >= 0 && order <= 2, "order must be 0, 1 or 2");
+    NSDG_CHECK_ARG(nfields >= 1 && nfields <= MAXF, "nfields must be 1..4");
+    NSDG_CHECK_ARG(phi && scratch && vx_dg && vy_dg && un_x && un_y, "null pointer");
+    const int nc = order == 0 ? 1 : (order == 1 ? 3 : 6);
+    const long M = (long)nc * ctx->nx * ctx->ny;
+    const double *p0[MAXF], *ps[MAXF];
+    double *t1[MAXF], *t2[MAXF], *ph[MAXF];
+    for (int f = 0; f < nfields; ++f) {
+        NSDG_CHECK_ARG(phi[f] != nullptr, "null field pointer");
+        ph[f] = phi[f];
+        t1[f] = scratch + (2 * f) * M;
+        t2[f] = scratch + (2 * f + 1) * M;
+        p0[f] = phi[f];
+    }
+    const int ny = ctx->ny;
+    int rc;
+    // SSP Runge-Kutta of order (order+1): Euler / Heun / Shu-Osher RK3; the last stage writes phi
+    if (order == 0) {
+        for (int f = 0; f < nfields; ++f) ps[f] = phi[f];
+        if ((rc = nsdg_transport_stage(ctx, order, 0, ny, dt, 0., 1., nfields, p0, ps, t1, vx_dg, vy_dg, un_x, un_y))) return rc;
+        for (int f = 0; f < nfields; ++f)
+            NSDG_CHECK_HIP(hipMemcpyAsync(phi[f], t1[f], M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (order == 1) {
+        for (int f = 0; f < nfields; ++f) ps[f] = phi[f];
+        if ((rc = nsdg_transport_stage(ctx, order, 0, ny, dt, 0., 1., nfields, p0, ps, t1, vx_dg, vy_dg, un_x, un_y))) return rc;
+        for (int f = 0; f < nfields; ++f) ps[f] = t1[f];
+        if ((rc = nsdg_transport_stage(ctx, order, 0, ny, dt, 0.5, 0.5, nfields, p0, ps, t2, vx_dg, vy_dg, un_x, un_y))) return rc;
+        for (int f = 0; f < nfields; ++f)
+            NSDG_CHECK_HIP(hipMemcpyAsync(phi[f], t2[f], M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        for (int f = 0; f < nfields; ++f) ps[f] = phi[f];
+        if ((rc = nsdg_transport_stage(ctx, order, 0, ny, dt, 0., 1., nfields, p0, ps, t1, vx_dg, vy_dg, un_x, un_y))) return rc;
+        for (int f = 0; f < nfields; ++f) ps[f] = t1[f];
+        if ((rc = nsdg_transport_stage(ctx, order, 0, ny, dt, 0.75, 0.25, nfields, p0, ps, t2, vx_dg, vy_dg, un_x, un_y))) return rc;
+        for (int f = 0; f < nfields; ++f) ps[f] = t2[f];
+        if ((rc = nsdg_transport_stage(ctx, order, 0, ny, dt, 1. / 3., 2. / 3., nfields, p0, ps, t1, vx_dg, vy_dg, un_x, un_y))) return rc;
+        for (int f = 0; f < nfields; ++f)
+            NSDG_CHECK_HIP(hipMemcpyAsync(phi[f], t1[f], M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return NSDG_OK;
+}
+
+} // extern "C"

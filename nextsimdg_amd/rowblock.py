@@ -1,0 +1,188 @@
+"""Row-block decomposition of the structured mesh over the ranks of one node and the per-step driver
+of the dynamics core (mEVP sub-cycle + DG2 transport of H and A).
+
+One process per GPU; rank r owns the contiguous element rows [r*ny/R, (r+1)*ny/R) of the x-major
+index e = iy*nx + ix (the reference's restart order i*nx + j, core/src/DevGridIO.cpp:107-109) and
+keeps one ghost element row on each interior side.  The only communication is nearest-neighbour
+send/recv of ghost rows through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests) -- there is no collective on the data path:
+
+  per mEVP sub-iteration : velocity node rows   up: 2 rows x (u,v) x (2nx+1)     down: 1 row x (u,v)
+                           (the stress of the ghost row below is NOT exchanged: it is updated
+                            redundantly by the rank itself, bit-identically to its owner)
+  per RK stage           : one ghost element row of each advected field in both directions
+
+Ownership of CG2 nodes is bottom-left: rank r owns node rows [2*r0, 2*r1); the global top node row is a
+Dirichlet boundary.  Node rows of a [rows, cols] array are contiguous, so velocity halos are sent
+straight out of / received straight into the field arrays without packing.
+
+The numerical kernels are reached through an `ops` object with the method names of
+nextsimdg_amd.abi.Context (the C-ABI binding).  Nothing here computes on the host.
+"""
+import torch
+import torch.distributed as dist
+
+
+def split_rows(ny, world, rank):
+    return (rank * ny) // world, ((rank + 1) * ny) // world
+
+
+class RowBlock:
+    """index bookkeeping of one rank's local array"""
+
+    def __init__(self, nx, ny, rank=0, world=1):
+        if ny < world:
+            raise ValueError("fewer element rows than ranks")
+        self.nx, self.ny_glob, self.rank, self.world = nx, ny, rank, world
+        self.r0, self.r1 = split_rows(ny, world, rank)
+        self.gb = 1 if rank > 0 else 0  # ghost element row below
+        self.gt = 1 if rank < world - 1 else 0  # ghost element row above
+        self.lo, self.hi = self.r0 - self.gb, self.r1 + self.gt  # global rows held locally
+        self.ny = self.hi - self.lo  # local element rows
+        self.j0, self.j1 = self.gb, self.ny - self.gt  # owned local rows
+        self.k0 = 0  # stress is updated from the ghost row below (if any)
+        self.below = rank - 1 if rank > 0 else None
+        self.above = rank + 1 if rank < world - 1 else None
+
+    def elem_slice(self):
+        return slice(self.lo, self.hi)
+
+    def node_slice(self):
+        return slice(2 * self.lo, 2 * self.hi + 1)
+
+
+class HaloExchanger:
+    def __init__(self, blk, group=None):
+        self.blk, self.group = blk, group
+
+    def _run(self, ops):
+        if not ops:
+            return
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+    def nodal(self, fields):
+        """refresh the ghost node rows of CG2 arrays [2ny+1, 2nx+1] (after a velocity update)"""
+        b = self.blk
+        if b.world == 1:
+            return
+        ops = []
+        for f in fields:
+            if b.above is not None:
+                # my two top owned node rows become the lower ghost rows of the rank above
+                ops.append(dist.P2POp(dist.isend, f[2 * b.j1 - 2:2 * b.j1], b.above, self.group))
+                ops.append(dist.P2POp(dist.irecv, f[2 * b.j1:2 * b.j1 + 1], b.above, self.group))
+            if b.below is not None:
+                ops.append(dist.P2POp(dist.isend, f[2 * b.j0:2 * b.j0 + 1], b.below, self.group))
+                ops.append(dist.P2POp(dist.irecv, f[0:2], b.below, self.group))
+        self._run(ops)
+
+    def element(self, fields):
+        """refresh the ghost element rows of DG arrays [nc, ny, nx] (after a transport stage)"""
+        b = self.blk
+        if b.world == 1:
+            return
+        ops, unpack = [], []
+        for f in fields:
+            if b.above is not None:
+                sbuf = f[:, b.j1 - 1, :].contiguous()
+                rbuf = torch.empty_like(sbuf)
+                ops.append(dist.P2POp(dist.isend, sbuf, b.above, self.group))
+                ops.append(dist.P2POp(dist.irecv, rbuf, b.above, self.group))
+                unpack.append((f, b.j1, rbuf))
+            if b.below is not None:
+                sbuf = f[:, b.j0, :].contiguous()
+                rbuf = torch.empty_like(sbuf)
+                ops.append(dist.P2POp(dist.isend, sbuf, b.below, self.group))
+                ops.append(dist.P2POp(dist.irecv, rbuf, b.below, self.group))
+                unpack.append((f, 0, rbuf))
+        self._run(ops)
+        for f, row, rbuf in unpack:
+            f[:, row, :] = rbuf
+
+
+class DynamicsCore:
+    """State and time step of the dynamics core on one rank's row block.
+
+    step() = one model time step: nodal means of H and A, ice strength at the Gauss points, wind
+    stress, `nsub` mEVP sub-iterations (velocity halo after each), advection-velocity preparation and
+    one SSP-RK3 DG2 transport step of H and A (element halo after each stage)."""
+
+    ORDER = 2
+
+    def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None):
+        self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
+        self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
+        nx, ny = blk.nx, blk.ny
+        z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
+        nodal = (2 * ny + 1, 2 * nx + 1)
+        self.H, self.A = z(6, ny, nx), z(6, ny, nx)
+        self.s = [z(8, ny, nx) for _ in range(3)]
+        self.pg = z(9, ny, nx)
+        self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
+        self.u0, self.v0 = z(*nodal), z(*nodal)
+        self.ua, self.va, self.tax, self.tay = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
+        self.uo, self.vo, self.cgh, self.cga = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
+        self.adv = (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
+        self.t1 = [z(6, ny, nx), z(6, ny, nx)]
+        self.t2 = [z(6, ny, nx), z(6, ny, nx)]
+
+    def load_global(self, H, A, uo, vo, ua, va, u=None, v=None):
+        """fill the local arrays (ghost rows included) from global numpy arrays"""
+        es, ns = self.blk.elem_slice(), self.blk.node_slice()
+        put = lambda dst, src: dst.copy_(torch.from_numpy(src).to(dst.device))
+        import numpy as np
+
+        put(self.H, np.ascontiguousarray(H[:, es]))
+        put(self.A, np.ascontiguousarray(A[:, es]))
+        for dst, src in ((self.uo, uo), (self.vo, vo), (self.ua, ua), (self.va, va)):
+            put(dst, np.ascontiguousarray(src[ns]))
+        if u is not None:
+            put(self.u, np.ascontiguousarray(u[ns]))
+            put(self.v, np.ascontiguousarray(v[ns]))
+
+    def _set_grid(self):
+        self.ops.set_grid(self.blk.nx, self.blk.ny, self.hx, self.hy)
+
+    def momentum(self):
+        ops, b = self.ops, self.blk
+        ops.dg_to_cg(self.H, self.cgh)
+        ops.dg_to_cg(self.A, self.cga)
+        ops.ice_strength(self.H, self.A, self.pg, 0, b.ny)
+        ops.wind_stress(self.ua, self.va, self.tax, self.tay)
+        self.u0.copy_(self.u)
+        self.v0.copy_(self.v)
+        for _ in range(self.nsub):
+            ops.mevp_iterate(b.k0, b.j0, b.j1, self.dt, self.s, (self.u, self.v), (self.ub, self.vb),
+                             (self.u0, self.v0), (self.tax, self.tay), (self.uo, self.vo), self.cgh, self.cga, self.pg)
+            self.halo.nodal((self.ub, self.vb))
+            self.u, self.ub = self.ub, self.u
+            self.v, self.vb = self.vb, self.v
+
+    def transport(self):
+        ops, b = self.ops, self.blk
+        ops.prepare_advection(self.ORDER, self.u, self.v, *self.adv)
+        f = [self.H, self.A]
+        # Shu-Osher SSP-RK3: out = a*phi0 + b*(phis + dt L(phis))
+        ops.transport_stage(self.ORDER, b.j0, b.j1, self.dt, 0.0, 1.0, f, f, self.t1, self.adv)
+        self.halo.element(self.t1)
+        ops.transport_stage(self.ORDER, b.j0, b.j1, self.dt, 0.75, 0.25, f, self.t1, self.t2, self.adv)
+        self.halo.element(self.t2)
+        ops.transport_stage(self.ORDER, b.j0, b.j1, self.dt, 1.0 / 3.0, 2.0 / 3.0, f, self.t2, self.t1, self.adv)
+        self.halo.element(self.t1)
+        # the new state is t1 (ghost rows refreshed); swap buffers instead of copying
+        self.H, self.t1[0] = self.t1[0], self.H
+        self.A, self.t1[1] = self.t1[1], self.A
+
+    def step(self):
+        self._set_grid()
+        self.momentum()
+        self.transport()
+
+    def owned(self, f):
+        """owned element rows of a DG array / owned node rows of a nodal array (for gathering)"""
+        b = self.blk
+        if f.dim() == 3:
+            return f[:, b.j0:b.j1]
+        top = 2 * b.j1 + (1 if b.above is None else 0)
+        return f[2 * b.j0:top]

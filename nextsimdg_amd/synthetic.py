@@ -1,0 +1,84 @@
+"""Synthetic inputs: the seeded column-physics fields of SURVEY.md section 8(d) and the 512 km box
+test (cyclone wind over a circular ocean current) used for BASELINE configs 3-5.  numpy only."""
+import numpy as np
+
+from . import basis
+
+COLUMN_SEED = 0x5EA1CE
+
+
+def column_fields(n, seed=COLUMN_SEED):
+    """state (hice,cice,hsnow,tice0), forcing (10 arrays) and newice for n elements."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi: rng.uniform(lo, hi, n)
+    hice = u(0, 3)
+    hice[rng.random(n) < 0.10] = 0.0
+    cice = u(0, 1)
+    r = rng.random(n)
+    cice[r < 0.10] = 0.0
+    cice[(r >= 0.10) & (r < 0.15)] = 1.0
+    hsnow = u(0, 0.5) * cice
+    tice0 = u(-30, 0)
+    tair = u(-35, 5)
+    state = dict(hice=hice, cice=cice, hsnow=hsnow, tice0=tice0)
+    forcing = dict(sst=u(-1.9, 2), sss=u(28, 36), tair=tair, tdew=tair - u(0, 5), slp=u(9.6e4, 1.04e5),
+                   qsw=u(0, 300), qlw=u(150, 350), mld=u(5, 50), snowfall=u(0, 1e-4), wind=u(0, 25))
+    return state, forcing, np.zeros(n)
+
+
+class BoxTest:
+    """Square box of side L (default 512 km), closed boundaries (v = 0).  Fields follow the usual
+    VP/mEVP benchmark set-up: H0 = 0.3 + 0.005 (sin(6e-5 x) + sin(3e-5 y)), A0 = 1, circular ocean
+    current of 0.01 m/s, a cyclone with 15 m/s-scale winds at time t."""
+
+    def __init__(self, nx, ny, L=512e3):
+        self.nx, self.ny, self.L = nx, ny, L
+        self.hx, self.hy = L / nx, L / ny
+
+    def H0(self, x, y):
+        return 0.3 + 0.005 * (np.sin(6e-5 * x) + np.sin(3e-5 * y))
+
+    def A0(self, x, y):
+        return 1.0 + 0 * x
+
+    def dg_fields(self, ncoef=6):
+        H = basis.project_dg(self.H0, self.nx, self.ny, self.L, self.L, ncoef, nq=3)
+        A = basis.project_dg(self.A0, self.nx, self.ny, self.L, self.L, ncoef, nq=3)
+        A[1:] = 0.0
+        return H, A
+
+    def ocean(self):
+        X, Y = basis.node_coords(self.nx, self.ny, self.L, self.L)
+        vmax = 0.01
+        return vmax * (2 * Y - self.L) / self.L, vmax * (self.L - 2 * X) / self.L
+
+    def wind(self, t=0.0):
+        X, Y = basis.node_coords(self.nx, self.ny, self.L, self.L)
+        cm = 0.5 * self.L + 0.1 * self.L * t / 86400.0 / 4.0
+        alpha = np.deg2rad(72.0)
+        dx, dy = (cm - X), (cm - Y)
+        r = np.sqrt(dx * dx + dy * dy)
+        s = 15.0 * np.exp(-r / (0.2 * self.L)) / (0.2 * self.L) * 1.0
+        ua = s * (np.cos(alpha) * dx + np.sin(alpha) * dy) * (0.2 * self.L) / 1e5
+        va = s * (-np.sin(alpha) * dx + np.cos(alpha) * dy) * (0.2 * self.L) / 1e5
+        return ua, va
+
+
+def rotating_patch(nx, ny, order, kind="bump"):
+    """BASELINE config 2: unit square, rigid rotation (omega = 2 pi) about the centre multiplied by a
+    smooth cut-off so that v = 0 on the boundary; initial patch centred at (0.5, 0.25)."""
+    def phi0(x, y):
+        r2 = (x - 0.5) ** 2 + (y - 0.25) ** 2
+        if kind == "bump":
+            return np.exp(-50.0 * r2 / 0.25)
+        r = np.sqrt(r2) / 0.15
+        return np.where(r < 1, 0.5 * (1 + np.cos(np.pi * np.minimum(r, 1))), 0.0)
+
+    X, Y = basis.node_coords(nx, ny, 1.0, 1.0)
+    w = 2 * np.pi
+    r = np.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2)
+    cut = np.where(r < 0.4, 1.0, np.where(r < 0.5, 0.5 * (1 + np.cos(np.pi * (r - 0.4) / 0.1)), 0.0))
+    u = -w * (Y - 0.5) * cut
+    v = w * (X - 0.5) * cut
+    phi = basis.project_dg(phi0, nx, ny, 1.0, 1.0, basis.NCOEF[order], nq=4)
+    return phi, np.ascontiguousarray(u), np.ascontiguousarray(v), phi0

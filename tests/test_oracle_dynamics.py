@@ -1,0 +1,218 @@
+"""Analytic / self-consistency checks of the dynamics oracle (oracle/dyn_oracle.c).
+
+PARITY UNPINNED: the reference snapshot contains no DG transport or mEVP implementation, test or
+fixture, so these tests pin the oracle to the mathematics it restates rather than
+to reference outputs."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from nextsimdg_amd import basis, synthetic
+
+
+def const_velocity(nx, ny, ux, vy):
+    u = np.full((2 * ny + 1, 2 * nx + 1), ux)
+    v = np.full((2 * ny + 1, 2 * nx + 1), vy)
+    return u, v
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_transport_constant_state_in_uniform_flow(order):
+    nx, ny = 12, 10
+    u, v = const_velocity(nx, ny, 1.0, 0.5)
+    adv = O.prepare_advection(nx, ny, order, u, v)
+    nc = O.ncoef(order)
+    phi = np.zeros((nc, ny, nx))
+    phi[0] = 1.0
+    O.transport_step(nx, ny, 0.1, 0.1, order, 0.005, phi, adv)
+    # away from the inflow boundaries (left, bottom; one cell per RK stage) the constant is
+    # reproduced to round-off
+    k = order + 1
+    assert np.max(np.abs(phi[0, k:, k:] - 1.0)) < 1e-14
+    if nc > 1:
+        assert np.max(np.abs(phi[1:, k:, k:])) < 1e-13
+    # zero-inflow boundary: the first column/row loses mass
+    assert np.all(phi[0, :, 0] < 1.0) and np.all(phi[0, 0, :] < 1.0)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_transport_mass_conservation_closed_domain(order):
+    nx, ny = 24, 20
+    phi, u, v, _ = synthetic.rotating_patch(nx, ny, order)
+    adv = O.prepare_advection(nx, ny, order, u, v)
+    m0 = basis.mass_total(phi, 1 / nx, 1 / ny)
+    dt = 0.1 / (2 * order + 1) * (1 / nx) / np.pi
+    for _ in range(20):
+        O.transport_step(nx, ny, 1 / nx, 1 / ny, order, dt, phi, adv)
+    m1 = basis.mass_total(phi, 1 / nx, 1 / ny)
+    assert abs(m1 - m0) <= 1e-13 * abs(m0)
+
+
+def test_transport_dg0_upwind_monotone():
+    nx, ny = 20, 20
+    phi, u, v, _ = synthetic.rotating_patch(nx, ny, 0, kind="cosbell")
+    adv = O.prepare_advection(nx, ny, 0, u, v)
+    lo, hi = phi.min(), phi.max()
+    dt = 0.2 * (1 / nx) / np.pi
+    for _ in range(30):
+        O.transport_step(nx, ny, 1 / nx, 1 / ny, 0, dt, phi, adv)
+    assert phi.min() >= lo - 1e-12 and phi.max() <= hi + 1e-12
+
+
+def rotate_error(n, order, frac=0.25):
+    phi, u, v, phi0 = synthetic.rotating_patch(n, n, order)
+    adv = O.prepare_advection(n, n, order, u, v)
+    T = frac
+    dt0 = 0.15 / (2 * order + 1) * (1 / n) / np.pi
+    steps = int(np.ceil(T / dt0))
+    dt = T / steps
+    for _ in range(steps):
+        O.transport_step(n, n, 1 / n, 1 / n, order, dt, phi, adv)
+    th = 2 * np.pi * T
+
+    def exact(x, y):  # rigid rotation by th about the centre (the patch stays inside the uncut core)
+        xr = 0.5 + np.cos(th) * (x - 0.5) + np.sin(th) * (y - 0.5)
+        yr = 0.5 - np.sin(th) * (x - 0.5) + np.cos(th) * (y - 0.5)
+        return phi0(xr, yr)
+
+    return basis.l2_error(phi, exact, 1.0, 1.0)
+
+
+def test_transport_convergence_orders():
+    # quarter revolution of the smooth bump; expected L2 orders ~ p+1 (a bit less on coarse grids)
+    e1 = [rotate_error(n, 1) for n in (16, 32)]
+    e2 = [rotate_error(n, 2) for n in (16, 32)]
+    r1 = np.log2(e1[0] / e1[1])
+    r2 = np.log2(e2[0] / e2[1])
+    assert r1 > 1.6, (e1, r1)
+    assert r2 > 2.5, (e2, r2)
+    assert e2[1] < e1[1]
+
+
+def box(nx=16, ny=12):
+    bt = synthetic.BoxTest(nx, ny)
+    p = O.mevp_params()
+    H, A = bt.dg_fields()
+    return bt, p, H, A
+
+
+def test_dg_to_cg_reproduces_linear_field():
+    nx, ny = 7, 5
+    f = basis.project_dg(lambda x, y: 2 + 3 * x - y, nx, ny, 1.0, 1.0, 6)
+    g = O.dg_to_cg(nx, ny, f)
+    X, Y = basis.node_coords(nx, ny, 1.0, 1.0)
+    assert np.max(np.abs(g - (2 + 3 * X - Y))) < 1e-13
+
+
+def test_strain_of_linear_velocity_and_rigid_motion():
+    nx, ny = 6, 5
+    hx, hy = 2.0, 3.0
+    X, Y = basis.node_coords(nx, ny, nx * hx, ny * hy)
+    p = O.mevp_params(alpha=1.0)  # alpha = 1: the new stress is exactly the projected sigma(v)
+    pg = np.ones((9, ny, nx))
+    a, b, c, d = 1e-6, -2e-6, 3e-6, 0.5e-6
+    u = np.ascontiguousarray(a * X + b * Y + 0.3)
+    v = np.ascontiguousarray(c * X + d * Y - 0.1)
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    O.mevp_stress(nx, ny, 0, ny, hx, hy, p, u, v, pg, *s)
+    e11, e22, e12 = a, d, 0.5 * (b + c)
+    delta = np.sqrt(p.delta_min ** 2 + 1.25 * (e11 ** 2 + e22 ** 2) + 1.5 * e11 * e22 + e12 ** 2)
+    want11 = (0.625 * e11 + 0.375 * e22) / delta - 0.5
+    want22 = (0.625 * e22 + 0.375 * e11) / delta - 0.5
+    want12 = 0.25 * e12 / delta
+    for S, w in zip(s, (want11, want12, want22)):
+        assert np.max(np.abs(S[0] - w)) < 1e-10
+        assert np.max(np.abs(S[1:])) < 1e-9
+    # rigid translation: zero strain => sigma = -P/2 exactly
+    u[:] = 0.7
+    v[:] = -0.2
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    O.mevp_stress(nx, ny, 0, ny, hx, hy, p, u, v, pg, *s)
+    # (round-off strain ~1e-17 divided by delta_min = 2e-9)
+    assert np.max(np.abs(s[0][0] + 0.5)) < 1e-7 and np.max(np.abs(s[2][0] + 0.5)) < 1e-7
+    assert np.max(np.abs(s[1])) < 1e-7
+
+
+def test_stress_relaxation_rate_at_rest():
+    # v = 0 => sigma(v) = -P/2; S^p = (1-1/alpha) S^{p-1} + (1/alpha)(-P/2)
+    bt, p, H, A = box()
+    nx, ny = bt.nx, bt.ny
+    pg = O.ice_strength(nx, ny, p, H, A)
+    u = np.zeros((2 * ny + 1, 2 * nx + 1))
+    v = np.zeros_like(u)
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    O.mevp_stress(nx, ny, 0, ny, bt.hx, bt.hy, p, u, v, pg, *s)
+    first = s[0].copy()
+    O.mevp_stress(nx, ny, 0, ny, bt.hx, bt.hy, p, u, v, pg, *s)
+    np.testing.assert_allclose(s[0], first * (1 + (1 - 1 / p.alpha)), rtol=1e-12, atol=1e-9)
+    assert np.max(np.abs(s[1])) == 0.0
+
+
+def test_uniform_stress_has_no_divergence_and_ice_stays_at_rest():
+    nx, ny = 8, 6
+    bt = synthetic.BoxTest(nx, ny)
+    p = O.mevp_params()
+    N = (2 * ny + 1, 2 * nx + 1)
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    s[0][0] = -5.0
+    s[2][0] = -7.0
+    s[1][0] = 2.0
+    z = np.zeros(N)
+    un, vn = np.ones(N), np.ones(N)
+    O.mevp_velocity(nx, ny, 0, ny, bt.hx, bt.hy, 120.0, p, s, (z, z), (un, vn), (z, z), (z, z), (z, z),
+                    np.full(N, 0.3), np.ones(N))
+    assert np.max(np.abs(un)) < 1e-18 and np.max(np.abs(vn)) < 1e-18
+
+
+def run_box(nx, ny, nsub, wind_t=0.0, flip=False, alpha=1500.0):
+    bt = synthetic.BoxTest(nx, ny)
+    p = O.mevp_params(alpha=alpha, beta=alpha)
+    H, A = bt.dg_fields()
+    if flip:
+        H = np.ascontiguousarray(H[:, :, :])
+    pg = O.ice_strength(nx, ny, p, H, A)
+    cgh, cga = O.dg_to_cg(nx, ny, H), O.dg_to_cg(nx, ny, A)
+    uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
+    ua, va = [np.ascontiguousarray(a) for a in bt.wind(wind_t)]
+    tax, tay = O.wind_stress(p, ua, va)
+    u, v = np.zeros_like(uo), np.zeros_like(uo)
+    u0, v0 = u.copy(), v.copy()
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    hist = []
+    for _ in range(nsub):
+        up = u.copy()
+        O.mevp_subcycle(nx, ny, bt.hx, bt.hy, 120.0, 1, p, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg)
+        hist.append(np.max(np.abs(u - up)))
+    return u, v, s, hist
+
+
+def test_mevp_subcycle_converges_and_respects_dirichlet():
+    u, v, s, hist = run_box(16, 16, 250, alpha=300.0)
+    assert np.all(np.isfinite(u)) and np.all(np.isfinite(v))
+    for a in (u, v):
+        assert np.all(a[0] == 0) and np.all(a[-1] == 0) and np.all(a[:, 0] == 0) and np.all(a[:, -1] == 0)
+    assert np.max(np.abs(u)) > 1e-4  # the wind moves the ice
+    assert np.max(np.abs(u)) < 1.0
+    # the pseudo-time iteration contracts: the update size decays (slowly: mEVP needs O(alpha) sweeps)
+    assert hist[-1] < 0.35 * hist[0]
+
+
+def test_mevp_point_symmetry():
+    # with a uniform ice cover the box set-up (cyclone centred in the box, circular current) is
+    # invariant under the point reflection x -> L - x, y -> L - y with v -> -v
+    nx = ny = 10
+    bt = synthetic.BoxTest(nx, ny)
+    p = O.mevp_params()
+    H = np.zeros((6, ny, nx)); H[0] = 0.3
+    A = np.zeros((6, ny, nx)); A[0] = 0.9
+    pg = O.ice_strength(nx, ny, p, H, A)
+    cgh, cga = O.dg_to_cg(nx, ny, H), O.dg_to_cg(nx, ny, A)
+    uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
+    ua, va = [np.ascontiguousarray(a) for a in bt.wind(0.0)]
+    tax, tay = O.wind_stress(p, ua, va)
+    u, v = np.zeros_like(uo), np.zeros_like(uo)
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    O.mevp_subcycle(nx, ny, bt.hx, bt.hy, 120.0, 25, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg)
+    assert np.max(np.abs(u)) > 1e-5
+    np.testing.assert_allclose(u, -u[::-1, ::-1], rtol=0, atol=1e-12 * np.max(np.abs(u)))
+    np.testing.assert_allclose(v, -v[::-1, ::-1], rtol=0, atol=1e-12 * np.max(np.abs(v)))
