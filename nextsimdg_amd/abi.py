@@ -73,6 +73,11 @@ def load_library(path=LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    # Device pointers and streams come from PyTorch, so the kernels must be launched through the
+    # SAME HIP runtime instance torch uses: import torch first so that its libamdhip64 is the one
+    # already mapped when libnsdg.so's dependency on that soname is resolved.
+    import torch  # noqa: F401
+
     if not os.path.exists(path):
         raise NsdgError("HIP library %s is missing: build it with `python -m nextsimdg_amd.build` "
                         "(there is no CPU fallback)" % path)
