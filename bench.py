@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--ny", type=int, default=2048)
     ap.add_argument("--nsub", type=int, default=120)
     ap.add_argument("--variant", type=int, default=None, help="mEVP kernel variant (default: library default)")
+    ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,6 +127,8 @@ def main():
     ctx = abi.Context(device)
     if args.variant is not None:
         ctx.set_mevp_variant(args.variant)
+    if args.strip_rows is not None:
+        ctx.set_mevp_strip_rows(args.strip_rows)
     ctx.set_mevp_params(ctx.mevp_default_params())
     blk = rowblock.RowBlock(nx, ny, rank, world)
     core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, device)

@@ -152,7 +152,7 @@ int nsdg_ice_strength(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* H, co
 /* tau_a = c_atm * rho_atm * |u_a| u_a at nnodes nodes */
 int nsdg_wind_stress(nsdg_ctx* ctx, int64_t nnodes, const double* ua, const double* va, double* tax, double* tay);
 
-/* mEVP stress update on element rows [k0, k1):  S <- (1-1/alpha) S + (1/alpha) Proj sigma(v) */
+/* mEVP stress update (in place) on element rows [k0, k1):  S <- (1-1/alpha) S + (1/alpha) Proj sigma(v) */
 int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, const double* v, const double* pg,
     double* s11, double* s12, double* s22);
 
@@ -162,18 +162,26 @@ int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const d
     const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
     const double* vo, const double* cgh, const double* cga);
 
-/* one fused sub-iteration (stress on rows [k0,k1), velocity of the nodes of rows [j0,j1)), k0 <= j0:
- * reads u_old/v_old, writes u_new/v_new and the stresses in place.  Used by multi-rank drivers that
- * exchange halos between sub-iterations. */
-int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, double* s11, double* s12,
-    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0,
-    const double* v0, const double* tax, const double* tay, const double* uo, const double* vo,
-    const double* cgh, const double* cga, const double* pg);
+/* one complete sub-iteration: stress on element rows [k0, j1) (S_out <- relax(S_in, u_old)), then the
+ * velocity of the nodes owned by rows [j0, j1) from S_out.  Out-of-place in both the stress and the
+ * velocity, so a row may be updated redundantly by two owners (a rank and its neighbour, or two row
+ * strips of the fused kernel) with bit-identical results.  k0 == j0 - 1 (one redundant ghost row below)
+ * or k0 == j0 == 0 (rows start at the physical boundary).  Used by multi-rank drivers that exchange
+ * velocity halos between sub-iterations. */
+int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, const double* s11_in,
+    const double* s12_in, const double* s22_in, double* s11_out, double* s12_out, double* s22_out,
+    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
+    const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh,
+    const double* cga, const double* pg);
 
-/* nsub sub-iterations over the whole local array; result in u, v.  scratch: 2*(2nx+1)*(2ny+1). */
+/* nsub sub-iterations over the whole local array; result in s11/s12/s22 and u, v.
+ * scratch: 2*(2nx+1)*(2ny+1) + 24*nx*ny doubles (ping-pong copies of the velocity and the stress). */
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u,
     double* v, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
     const double* vo, const double* cgh, const double* cga, const double* pg, double* scratch);
+
+/* rows per strip of the fused marching kernel (performance knob; results do not depend on it) */
+int nsdg_mevp_strip_rows_set(nsdg_ctx* ctx, int32_t rows);
 
 #ifdef __cplusplus
 }

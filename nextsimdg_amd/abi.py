@@ -61,7 +61,8 @@ SYMBOLS = {
     "nsdg_wind_stress": (C.c_int, [VP, I64, VP, VP, VP, VP]),
     "nsdg_mevp_stress": (C.c_int, [VP, I32, I32] + [VP] * 6),
     "nsdg_mevp_velocity": (C.c_int, [VP, I32, I32, D] + [VP] * 15),
-    "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32, D] + [VP] * 16),
+    "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32, D] + [VP] * 19),
+    "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
 }
 
@@ -193,6 +194,9 @@ class Context:
     def set_mevp_variant(self, variant):
         self._call(self.lib.nsdg_mevp_variant_set(self.h, variant))
 
+    def set_mevp_strip_rows(self, rows):
+        self._call(self.lib.nsdg_mevp_strip_rows_set(self.h, rows))
+
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):
         _check_f64(u, v, vx, vy, unx, uny)
         self._call(self.lib.nsdg_prepare_advection(self.h, order, *[_ptr(t) for t in (u, v, vx, vy, unx, uny)]))
@@ -233,8 +237,8 @@ class Context:
         _check_f64(*ts)
         self._call(self.lib.nsdg_mevp_velocity(self.h, j0, j1, float(dt), *[_ptr(t) for t in ts]))
 
-    def mevp_iterate(self, k0, j0, j1, dt, s, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, pg):
-        ts = [s[0], s[1], s[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], u0v0[0], u0v0[1], tau[0], tau[1],
+    def mevp_iterate(self, k0, j0, j1, dt, s_in, s_out, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, pg):
+        ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], u0v0[0], u0v0[1], tau[0], tau[1],
               ocean[0], ocean[1], cgh, cga, pg]
         _check_f64(*ts)
         self._call(self.lib.nsdg_mevp_iterate(self.h, k0, j0, j1, float(dt), *[_ptr(t) for t in ts]))
@@ -242,6 +246,7 @@ class Context:
     def mevp_subcycle(self, dt, nsub, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch):
         ts = [s[0], s[1], s[2], u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch]
         _check_f64(*ts)
-        if scratch.numel() < 2 * u.numel():
-            raise NsdgError("mEVP scratch too small: need %d doubles" % (2 * u.numel()))
+        need = 2 * u.numel() + 3 * s[0].numel()
+        if scratch.numel() < need:
+            raise NsdgError("mEVP scratch too small: need %d doubles" % need)
         self._call(self.lib.nsdg_mevp_subcycle(self.h, float(dt), int(nsub), *[_ptr(t) for t in ts]))

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnsdg.so")
 SOURCES = ["nsdg_ctx.hip", "column_step.hip", "transport.hip", "mevp.hip", "mevp_fused.hip"]
-HEADERS = ["nsdg_internal.h", "dg_tables.h", os.path.join("..", "..", "include", "nsdg.h")]
+HEADERS = ["nsdg_internal.h", "dg_tables.h", "mevp_common.h", os.path.join("..", "..", "include", "nsdg.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-fno-signed-zeros", "-Wall", "-Wno-unused-function"]
 
 

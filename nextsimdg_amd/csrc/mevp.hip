@@ -14,117 +14,16 @@
 //                        deterministic and independent of the decomposition -- and applies the
 //                        momentum update.
 // Variant 1 ("fused march") lives in mevp_fused.hip.
-#include "dg_tables.h"
-#include "nsdg_internal.h"
+#include "mevp_common.h"
 
 namespace nsdg_mevp_detail {
 
-using namespace nsdg_tab;
-
-#define FMA_TAB(acc, tab, val)   \
-    do {                         \
-        const double t_ = (tab); \
-        if (t_ != 0.0)           \
-            acc += t_ * (val);   \
-    } while (0)
-
-// ---------------------------------------------------------------------------------------------
-// stress of one element from its 9 nodal velocities: S <- (1-1/alpha) S + (1/alpha) Proj sigma(v)
-__device__ __forceinline__ void stress_update(const double (&ul)[9], const double (&vl)[9], const double (&P)[9],
-    double ihx, double ihy, double ialpha, double dmin2, double (&s11)[8], double (&s12)[8], double (&s22)[8])
-{
-    double E11[8], E12[8], E22[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        double uxx = 0., uyy = 0., vxx = 0., vyy = 0.;
-#pragma unroll
-        for (int a = 0; a < 9; ++a) {
-            FMA_TAB(uxx, DX[i][a], ul[a]);
-            FMA_TAB(uyy, DY[i][a], ul[a]);
-            FMA_TAB(vxx, DX[i][a], vl[a]);
-            FMA_TAB(vyy, DY[i][a], vl[a]);
-        }
-        E11[i] = uxx * ihx;
-        E22[i] = vyy * ihy;
-        E12[i] = 0.5 * (uyy * ihy + vxx * ihx);
-    }
-    double r11[8], r12[8], r22[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        r11[i] = r12[i] = r22[i] = 0.;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        double e11 = 0., e12 = 0., e22 = 0.;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            FMA_TAB(e11, PSI_G3[q][i], E11[i]);
-            FMA_TAB(e12, PSI_G3[q][i], E12[i]);
-            FMA_TAB(e22, PSI_G3[q][i], E22[i]);
-        }
-        const double d2 = dmin2 + 1.25 * (e11 * e11 + e22 * e22) + 1.5 * e11 * e22 + e12 * e12;
-        const double pd = P[q] * rsqrt(d2);
-        const double t11 = pd * (0.625 * e11 + 0.375 * e22) - 0.5 * P[q];
-        const double t22 = pd * (0.625 * e22 + 0.375 * e11) - 0.5 * P[q];
-        const double t12 = pd * 0.25 * e12;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            FMA_TAB(r11[i], W_G3[q] * PSI_G3[q][i] * IMASS[i], t11);
-            FMA_TAB(r12[i], W_G3[q] * PSI_G3[q][i] * IMASS[i], t12);
-            FMA_TAB(r22[i], W_G3[q] * PSI_G3[q][i] * IMASS[i], t22);
-        }
-    }
-    const double keep = 1. - ialpha;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        s11[i] = keep * s11[i] + ialpha * r11[i];
-        s12[i] = keep * s12[i] + ialpha * r12[i];
-        s22[i] = keep * s22[i] + ialpha * r22[i];
-    }
-}
-
-// -(sigma, grad phi_a)_K for local node A of an element with stress coefficients s11/s12/s22
-template <int A>
-__device__ __forceinline__ void node_contrib(const double (&s11)[8], const double (&s12)[8], const double (&s22)[8],
-    double hx, double hy, double& cx, double& cy)
-{
-    double gx11 = 0., gy12 = 0., gx12 = 0., gy22 = 0.;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        FMA_TAB(gx11, MASS[i] * DX[i][A], s11[i]);
-        FMA_TAB(gy12, MASS[i] * DY[i][A], s12[i]);
-        FMA_TAB(gx12, MASS[i] * DX[i][A], s12[i]);
-        FMA_TAB(gy22, MASS[i] * DY[i][A], s22[i]);
-    }
-    cx = -(hy * gx11 + hx * gy12);
-    cy = -(hy * gx12 + hx * gy22);
-}
-
-struct NodeIn {
-    const double *u_old, *v_old, *u0, *v0, *tax, *tay, *uo, *vo, *cgh, *cga;
-};
-
-// momentum update of one interior node (eq. for v^p)
-__device__ __forceinline__ void node_update(const nsdg_mevp_params& P, double dt, const NodeIn& in, long n, double divx,
-    double divy, double ilumped, double& un, double& vn)
-{
-    const double uu = in.u_old[n], vv = in.v_old[n];
-    const double uoc = in.uo[n], voc = in.vo[n];
-    const double du = uoc - uu, dv = voc - vv;
-    const double absocn = sqrt(du * du + dv * dv);
-    const double h = fmax(in.cgh[n], P.h_min);
-    const double a_ = fmin(fmax(in.cga[n], 0.), 1.);
-    const double mdt = P.rho_ice * h / dt;
-    const double cdrag = a_ * (P.c_ocean * P.rho_ocean) * absocn;
-    const double denom = 1. / (mdt * (1. + P.beta) + cdrag);
-    const double cor = P.rho_ice * h * P.fc;
-    un = denom * (mdt * (P.beta * uu + in.u0[n]) + a_ * in.tax[n] + cdrag * uoc + cor * (vv - voc) + divx * ilumped);
-    vn = denom * (mdt * (P.beta * vv + in.v0[n]) + a_ * in.tay[n] + cdrag * voc - cor * (uu - uoc) + divy * ilumped);
-}
-
 __global__ __launch_bounds__(256) void mevp_stress_kernel(int nx, int ny, int k0, int k1, double ihx, double ihy,
     double ialpha, double dmin2, const double* __restrict__ u, const double* __restrict__ v,
-    const double* __restrict__ pg, double* __restrict__ S11, double* __restrict__ S12, double* __restrict__ S22)
+    const double* __restrict__ pg, const double* S11i, const double* S12i, const double* S22i, double* S11, double* S12,
+    double* S22)
 {
+    // S??i may alias S?? (in-place update): every lane reads only its own element before writing it
     const int ix = blockIdx.x * 64 + threadIdx.x;
     const int iy = k0 + blockIdx.y * 4 + threadIdx.y;
     if (ix >= nx || iy >= k1)
@@ -144,9 +43,9 @@ __global__ __launch_bounds__(256) void mevp_stress_kernel(int nx, int ny, int k0
         P[q] = pg[q * N + e];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s11[i] = S11[i * N + e];
-        s12[i] = S12[i * N + e];
-        s22[i] = S22[i * N + e];
+        s11[i] = S11i[i * N + e];
+        s12[i] = S12i[i * N + e];
+        s22[i] = S22i[i * N + e];
     }
     stress_update(ul, vl, P, ihx, ihy, ialpha, dmin2, s11, s12, s22);
 #pragma unroll
@@ -336,8 +235,8 @@ __global__ __launch_bounds__(256) void wind_stress_kernel(long n, double f_atm, 
 using namespace nsdg_mevp_detail;
 
 // defined in mevp_fused.hip
-int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, double dt, double* s11, double* s12, double* s22,
-    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
+int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, double dt, const double* s11i, const double* s12i,
+    const double* s22i, double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
     const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh, const double* cga,
     const double* pg);
 
@@ -384,6 +283,16 @@ int nsdg_wind_stress(nsdg_ctx* ctx, int64_t nnodes, const double* ua, const doub
     return NSDG_OK;
 }
 
+static int launch_stress(nsdg_ctx* ctx, int k0, int k1, const double* u, const double* v, const double* pg, const double* s11i,
+    const double* s12i, const double* s22i, double* s11, double* s12, double* s22)
+{
+    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(k1 - k0, 4));
+    hipLaunchKernelGGL(mevp_stress_kernel, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, k0, k1, 1. / ctx->hx, 1. / ctx->hy,
+        1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, u, v, pg, s11i, s12i, s22i, s11, s12, s22);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
+
 int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, const double* v, const double* pg, double* s11,
     double* s12, double* s22)
 {
@@ -393,11 +302,7 @@ int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, con
     if (k0 == k1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(k1 - k0, 4));
-    hipLaunchKernelGGL(mevp_stress_kernel, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, k0, k1, 1. / ctx->hx, 1. / ctx->hy,
-        1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, u, v, pg, s11, s12, s22);
-    NSDG_CHECK_LAUNCH();
-    return NSDG_OK;
+    return launch_stress(ctx, k0, k1, u, v, pg, s11, s12, s22, s11, s12, s22);
 }
 
 int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const double* s11, const double* s12,
@@ -422,27 +327,27 @@ int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const d
     return NSDG_OK;
 }
 
-int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, double* s11, double* s12, double* s22,
-    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
-    const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh, const double* cga,
-    const double* pg)
+int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, const double* s11i, const double* s12i,
+    const double* s22i, double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new,
+    double* v_new, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
+    const double* vo, const double* cgh, const double* cga, const double* pg)
 {
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(0 <= k0 && k0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "need 0 <= k0 <= j0 <= j1 <= ny");
-    NSDG_CHECK_ARG(j0 - k0 <= 1, "at most one redundant stress row below the owned rows");
-    if (ctx->mevp_variant == 1) {
-        NSDG_CHECK_ARG(s11 && s12 && s22 && u_old && v_old && u_new && v_new && u0 && v0 && tax && tay && uo && vo && cgh
-                && cga && pg,
-            "null field pointer");
-        NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
-        NSDG_CHECK_ARG(dt > 0, "dt must be positive");
-        if (k0 == j1)
-            return NSDG_OK;
-        NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-        return nsdg_launch_mevp_fused(ctx, k0, j0, j1, dt, s11, s12, s22, u_old, v_old, u_new, v_new, u0, v0, tax, tay, uo, vo,
-            cgh, cga, pg);
-    }
-    int rc = nsdg_mevp_stress(ctx, k0, j1, u_old, v_old, pg, s11, s12, s22);
+    NSDG_CHECK_ARG(k0 == j0 - 1 || (k0 == 0 && j0 == 0), "need k0 == j0 - 1 (one ghost row below) or k0 == j0 == 0");
+    NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && u0 && v0 && tax && tay && uo
+            && vo && cgh && cga && pg,
+        "null field pointer");
+    NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
+    NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
+    NSDG_CHECK_ARG(dt > 0, "dt must be positive");
+    if (k0 == j1)
+        return NSDG_OK;
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (ctx->mevp_variant == 1)
+        return nsdg_launch_mevp_fused(ctx, k0, j0, j1, dt, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, u0, v0,
+            tax, tay, uo, vo, cgh, cga, pg);
+    int rc = launch_stress(ctx, k0, j1, u_old, v_old, pg, s11i, s12i, s22i, s11, s12, s22);
     if (rc)
         return rc;
     return nsdg_mevp_velocity(ctx, j0, j1, dt, s11, s12, s22, u_old, v_old, u_new, v_new, u0, v0, tax, tay, uo, vo, cgh, cga);
@@ -454,23 +359,28 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
 {
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(nsub >= 0, "negative sub-iteration count");
-    NSDG_CHECK_ARG(u && v && scratch, "null field pointer");
+    NSDG_CHECK_ARG(u && v && s11 && s12 && s22 && scratch, "null field pointer");
     NSDG_CHECK_ARG(u0 != u && v0 != v, "u0/v0 (velocity at step start) must not alias the iterate u/v");
     const long nnodes = (long)(2 * ctx->nx + 1) * (2 * ctx->ny + 1);
-    double* ua = u;
-    double* va = v;
-    double* ub = scratch;
-    double* vb = scratch + nnodes;
+    const long M = 8L * ctx->nx * ctx->ny;
+    double *ua = u, *va = v, *ub = scratch, *vb = scratch + nnodes;
+    double *sa[3] = { s11, s12, s22 };
+    double *sb[3] = { scratch + 2 * nnodes, scratch + 2 * nnodes + M, scratch + 2 * nnodes + 2 * M };
     for (int it = 0; it < nsub; ++it) {
-        int rc = nsdg_mevp_iterate(ctx, 0, 0, ctx->ny, dt, s11, s12, s22, ua, va, ub, vb, u0, v0, tax, tay, uo, vo, cgh, cga, pg);
+        int rc = nsdg_mevp_iterate(ctx, 0, 0, ctx->ny, dt, sa[0], sa[1], sa[2], sb[0], sb[1], sb[2], ua, va, ub, vb, u0, v0, tax, tay,
+            uo, vo, cgh, cga, pg);
         if (rc)
             return rc;
         double* t = ua; ua = ub; ub = t;
         t = va; va = vb; vb = t;
+        for (int k = 0; k < 3; ++k) { t = sa[k]; sa[k] = sb[k]; sb[k] = t; }
     }
-    if (ua != u) { // odd number of sub-iterations: the result sits in scratch
+    if (ua != u) { // odd number of sub-iterations: the results sit in scratch
         NSDG_CHECK_HIP(hipMemcpyAsync(u, ua, nnodes * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         NSDG_CHECK_HIP(hipMemcpyAsync(v, va, nnodes * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        NSDG_CHECK_HIP(hipMemcpyAsync(s11, sa[0], M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        NSDG_CHECK_HIP(hipMemcpyAsync(s12, sa[1], M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        NSDG_CHECK_HIP(hipMemcpyAsync(s22, sa[2], M * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
     return NSDG_OK;
 }

@@ -1,0 +1,282 @@
+// mevp_common.h -- per-element / per-node device functions shared by the two mEVP kernel variants
+// (mevp.hip: two kernels per sub-iteration; mevp_fused.hip: fused marching kernel).  Using the very
+// same inlined functions in both variants keeps their results bit-identical.
+#pragma once
+#include "dg_tables.h"
+#include "nsdg_internal.h"
+
+namespace nsdg_mevp_detail {
+
+using namespace nsdg_tab;
+
+#define FMA_TAB(acc, tab, val)   \
+    do {                         \
+        const double t_ = (tab); \
+        if (t_ != 0.0)           \
+            acc += t_ * (val);   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Sum-factorised element operators.  Every 2-D basis function is a product of 1-D ones,
+//   psi_i(xi,eta) = p_a(xi) p_b(eta),  p0 = 1, p1 = s, p2 = s^2 - 1/12,
+//   i -> (a,b):  0:(0,0) 1:(1,0) 2:(0,1) 3:(2,0) 4:(0,2) 5:(1,1) 6:(2,1) 7:(1,2)
+//   phi_n(xi,eta) = L_ax(xi) L_ay(eta), n = 3*ay + ax (quadratic Lagrange),
+// so the dense 8x9 / 9x8 element matrices of dg_tables.h (DX, DY, PSI_G3, ...) factor into two sweeps
+// of 3x3 one-dimensional operators.  Compared with the dense tables this halves the flop count and,
+// more importantly on CDNA, needs a handful of distinct fp64 literals instead of ~100 (fp64
+// literals live in SGPR pairs; the dense form spilled >300 SGPRs).  The 1-D operators are
+//   int p_a L'_n / m_a :  a=0: (-1, 0, 1)        a=1: (4, -8, 4)       a=2: 0
+//   int p_a L_n  / m_a :  a=0: (1, 4, 1)/6       a=1: (-1, 0, 1)       a=2: (2, -4, 2)
+// and the same without the 1/m_a for the divergence.  tests compare against the oracle's dense,
+// quadrature-built operators.
+constexpr double SF_G = 0.3872983346207417; // Gauss abscissa sqrt(3/5)/2 on [-1/2, 1/2]
+constexpr double SF_P2E = 1. / 15.; // p2 at the outer Gauss points
+constexpr double SF_P2M = -1. / 12.; // p2 at the middle Gauss point
+constexpr double SF_W0 = 5. / 18., SF_W1 = 8. / 18.; // Gauss weights
+
+// DG8 coefficients of d/dxi and d/deta of a CG2 function given by its 9 nodal values
+__device__ __forceinline__ void sf_grad(const double (&U)[9], double (&dxi)[8], double (&deta)[8])
+{
+    double d[3], Q[3], B0[3];
+#pragma unroll
+    for (int ay = 0; ay < 3; ++ay) {
+        const double u0 = U[3 * ay], u1 = U[3 * ay + 1], u2 = U[3 * ay + 2];
+        const double sm = u0 + u2;
+        d[ay] = u2 - u0; // = (int p0 L') . U          (also int p1 L / m1)
+        Q[ay] = sm - 2. * u1; // (int p1 L')/m1 = 4Q,   (int p2 L)/m2 = 2Q
+        B0[ay] = (sm + 4. * u1) * (1. / 6.); // int p0 L
+    }
+    // d/dxi: x-operator L' (a = 0: d, a = 1: 4Q), y-operator L (b = 0, 1, 2)
+    {
+        const double sd = d[0] + d[2], sq = Q[0] + Q[2];
+        dxi[0] = (sd + 4. * d[1]) * (1. / 6.);
+        dxi[2] = d[2] - d[0];
+        dxi[4] = 2. * (sd - 2. * d[1]);
+        dxi[1] = (sq + 4. * Q[1]) * (4. / 6.);
+        dxi[5] = 4. * (Q[2] - Q[0]);
+        dxi[7] = 8. * (sq - 2. * Q[1]);
+        dxi[3] = 0.;
+        dxi[6] = 0.;
+    }
+    // d/deta: x-operator L (a = 0: B0, a = 1: d, a = 2: 2Q), y-operator L' (b = 0, 1)
+    deta[0] = B0[2] - B0[0];
+    deta[2] = 4. * ((B0[0] + B0[2]) - 2. * B0[1]);
+    deta[1] = d[2] - d[0];
+    deta[5] = 4. * ((d[0] + d[2]) - 2. * d[1]);
+    deta[3] = 2. * (Q[2] - Q[0]);
+    deta[6] = 8. * ((Q[0] + Q[2]) - 2. * Q[1]);
+    deta[4] = 0.;
+    deta[7] = 0.;
+}
+
+// values of a DG8 function at the 3x3 Gauss points, V[3*qy + qx]
+__device__ __forceinline__ void sf_eval(const double (&c)[8], double (&V)[9])
+{
+    double T0[3], T1[3], T2[3]; // T_b[qx] = sum_a C[a][b] p_a(xi_qx)
+    {
+        const double S = c[0] + SF_P2E * c[3], D = SF_G * c[1];
+        T0[0] = S - D, T0[2] = S + D, T0[1] = c[0] + SF_P2M * c[3];
+    }
+    {
+        const double S = c[2] + SF_P2E * c[6], D = SF_G * c[5];
+        T1[0] = S - D, T1[2] = S + D, T1[1] = c[2] + SF_P2M * c[6];
+    }
+    {
+        const double D = SF_G * c[7];
+        T2[0] = c[4] - D, T2[2] = c[4] + D, T2[1] = c[4];
+    }
+#pragma unroll
+    for (int qx = 0; qx < 3; ++qx) {
+        const double S = T0[qx] + SF_P2E * T2[qx], D = SF_G * T1[qx];
+        V[qx] = S - D;
+        V[6 + qx] = S + D;
+        V[3 + qx] = T0[qx] + SF_P2M * T2[qx];
+    }
+}
+
+// L2 projection of Gauss-point values t[3*qy+qx] on the DG8 basis: R_i = (1/m_i) sum_q w_q psi_i(q) t_q
+__device__ __forceinline__ void sf_project(const double (&t)[9], double (&R)[8])
+{
+    constexpr double K1 = 12. * SF_W0 * SF_G; // (1/m1) w0 p1(g)
+    constexpr double K2S = 180. * SF_W0 * SF_P2E, K2M = 180. * SF_W1 * SF_P2M; // (1/m2) w p2
+    double Y0[3], Y1[3], Y2[3]; // Y_b[qx] = (1/m_b) sum_qy w_qy p_b(eta_qy) t(qx,qy)
+#pragma unroll
+    for (int qx = 0; qx < 3; ++qx) {
+        const double t0 = t[qx], t1 = t[3 + qx], t2 = t[6 + qx];
+        const double sm = t0 + t2;
+        Y0[qx] = SF_W0 * sm + SF_W1 * t1;
+        Y1[qx] = K1 * (t2 - t0);
+        Y2[qx] = K2S * sm + K2M * t1;
+    }
+    {
+        const double sm = Y0[0] + Y0[2];
+        R[0] = SF_W0 * sm + SF_W1 * Y0[1];
+        R[1] = K1 * (Y0[2] - Y0[0]);
+        R[3] = K2S * sm + K2M * Y0[1];
+    }
+    {
+        const double sm = Y1[0] + Y1[2];
+        R[2] = SF_W0 * sm + SF_W1 * Y1[1];
+        R[5] = K1 * (Y1[2] - Y1[0]);
+        R[6] = K2S * sm + K2M * Y1[1];
+    }
+    {
+        const double sm = Y2[0] + Y2[2];
+        R[4] = SF_W0 * sm + SF_W1 * Y2[1];
+        R[7] = K1 * (Y2[2] - Y2[0]);
+    }
+}
+
+// G[3*ay+ax] = int_ref S d/dxi phi_n  for a DG8 function S (x-operator int p_a L', y-operator int p_b L)
+__device__ __forceinline__ void sf_gxi(const double (&c)[8], double (&G)[9])
+{
+    double X0[3], X1[3], X2[3]; // X_b[ax]
+    {
+        const double t = c[1] * (1. / 3.);
+        X0[0] = t - c[0], X0[1] = -2. * t, X0[2] = t + c[0];
+    }
+    {
+        const double t = c[5] * (1. / 3.);
+        X1[0] = t - c[2], X1[1] = -2. * t, X1[2] = t + c[2];
+    }
+    {
+        const double t = c[7] * (1. / 3.);
+        X2[0] = t - c[4], X2[1] = -2. * t, X2[2] = t + c[4];
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const double p = X0[ax] * (1. / 6.), q = X1[ax] * (1. / 12.), r = X2[ax] * (1. / 90.);
+        const double pr = p + r;
+        G[ax] = pr - q;
+        G[3 + ax] = 4. * p - 2. * r;
+        G[6 + ax] = pr + q;
+    }
+}
+
+// G[3*ay+ax] = int_ref S d/deta phi_n  (x-operator int p_a L, y-operator int p_b L')
+__device__ __forceinline__ void sf_geta(const double (&c)[8], double (&G)[9])
+{
+    double X0[3], X1[3]; // X_b[ax], b = 0, 1
+    {
+        const double p = c[0] * (1. / 6.), q = c[1] * (1. / 12.), r = c[3] * (1. / 90.);
+        const double pr = p + r;
+        X0[0] = pr - q, X0[1] = 4. * p - 2. * r, X0[2] = pr + q;
+    }
+    {
+        const double p = c[2] * (1. / 6.), q = c[5] * (1. / 12.), r = c[6] * (1. / 90.);
+        const double pr = p + r;
+        X1[0] = pr - q, X1[1] = 4. * p - 2. * r, X1[2] = pr + q;
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const double t = X1[ax] * (1. / 3.);
+        G[ax] = t - X0[ax];
+        G[3 + ax] = -2. * t;
+        G[6 + ax] = t + X0[ax];
+    }
+}
+
+// stress of one element from its 9 nodal velocities: S <- (1-1/alpha) S + (1/alpha) Proj sigma(v)
+__device__ __forceinline__ void stress_update(const double (&ul)[9], const double (&vl)[9], const double (&P)[9],
+    double ihx, double ihy, double ialpha, double dmin2, double (&s11)[8], double (&s12)[8], double (&s22)[8])
+{
+    double E11[8], E12[8], E22[8];
+    {
+        double uxi[8], ueta[8], vxi[8], veta[8];
+        sf_grad(ul, uxi, ueta);
+        sf_grad(vl, vxi, veta);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            E11[i] = uxi[i] * ihx;
+            E22[i] = veta[i] * ihy;
+            E12[i] = 0.5 * (ueta[i] * ihy + vxi[i] * ihx);
+        }
+    }
+    double e11[9], e12[9], e22[9];
+    sf_eval(E11, e11);
+    sf_eval(E12, e12);
+    sf_eval(E22, e22);
+    double t11[9], t12[9], t22[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const double d2 = dmin2 + 1.25 * (e11[q] * e11[q] + e22[q] * e22[q]) + 1.5 * e11[q] * e22[q] + e12[q] * e12[q];
+        const double pd = P[q] * rsqrt(d2);
+        t11[q] = pd * (0.625 * e11[q] + 0.375 * e22[q]) - 0.5 * P[q];
+        t22[q] = pd * (0.625 * e22[q] + 0.375 * e11[q]) - 0.5 * P[q];
+        t12[q] = pd * 0.25 * e12[q];
+    }
+    double r11[8], r12[8], r22[8];
+    sf_project(t11, r11);
+    sf_project(t12, r12);
+    sf_project(t22, r22);
+    const double keep = 1. - ialpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s11[i] = keep * s11[i] + ialpha * r11[i];
+        s12[i] = keep * s12[i] + ialpha * r12[i];
+        s22[i] = keep * s22[i] + ialpha * r22[i];
+    }
+}
+
+// all 18 nodal contributions -(sigma, grad phi_n)_K of one element
+__device__ __forceinline__ void node_contrib_all(const double (&s11)[8], const double (&s12)[8], const double (&s22)[8],
+    double hx, double hy, double (&cx)[9], double (&cy)[9])
+{
+    double gx11[9], gy12[9], gx12[9], gy22[9];
+    sf_gxi(s11, gx11);
+    sf_geta(s12, gy12);
+    sf_gxi(s12, gx12);
+    sf_geta(s22, gy22);
+#pragma unroll
+    for (int n = 0; n < 9; ++n) {
+        cx[n] = -(hy * gx11[n] + hx * gy12[n]);
+        cy[n] = -(hy * gx12[n] + hx * gy22[n]);
+    }
+}
+
+// -(sigma, grad phi_a)_K for local node A of an element with stress coefficients s11/s12/s22
+template <int A>
+__device__ __forceinline__ void node_contrib(const double (&s11)[8], const double (&s12)[8], const double (&s22)[8],
+    double hx, double hy, double& cx, double& cy)
+{
+    double gx11 = 0., gy12 = 0., gx12 = 0., gy22 = 0.;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        FMA_TAB(gx11, MASS[i] * DX[i][A], s11[i]);
+        FMA_TAB(gy12, MASS[i] * DY[i][A], s12[i]);
+        FMA_TAB(gx12, MASS[i] * DX[i][A], s12[i]);
+        FMA_TAB(gy22, MASS[i] * DY[i][A], s22[i]);
+    }
+    cx = -(hy * gx11 + hx * gy12);
+    cy = -(hy * gx12 + hx * gy22);
+}
+
+struct NodeIn {
+    const double *u_old, *v_old, *u0, *v0, *tax, *tay, *uo, *vo, *cgh, *cga;
+};
+
+// momentum update of one interior node from values already in registers
+__device__ __forceinline__ void node_update_vals(const nsdg_mevp_params& P, double dt, double uu, double vv, double u0,
+    double v0, double tax, double tay, double uoc, double voc, double cgh, double cga, double divx, double divy,
+    double ilumped, double& un, double& vn)
+{
+    const double du = uoc - uu, dv = voc - vv;
+    const double absocn = sqrt(du * du + dv * dv);
+    const double h = fmax(cgh, P.h_min);
+    const double a_ = fmin(fmax(cga, 0.), 1.);
+    const double mdt = P.rho_ice * h / dt;
+    const double cdrag = a_ * (P.c_ocean * P.rho_ocean) * absocn;
+    const double denom = 1. / (mdt * (1. + P.beta) + cdrag);
+    const double cor = P.rho_ice * h * P.fc;
+    un = denom * (mdt * (P.beta * uu + u0) + a_ * tax + cdrag * uoc + cor * (vv - voc) + divx * ilumped);
+    vn = denom * (mdt * (P.beta * vv + v0) + a_ * tay + cdrag * voc - cor * (uu - uoc) + divy * ilumped);
+}
+
+__device__ __forceinline__ void node_update(const nsdg_mevp_params& P, double dt, const NodeIn& in, long n, double divx,
+    double divy, double ilumped, double& un, double& vn)
+{
+    node_update_vals(P, dt, in.u_old[n], in.v_old[n], in.u0[n], in.v0[n], in.tax[n], in.tay[n], in.uo[n], in.vo[n], in.cgh[n],
+        in.cga[n], divx, divy, ilumped, un, vn);
+}
+
+} // namespace nsdg_mevp_detail

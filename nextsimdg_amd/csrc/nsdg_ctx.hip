@@ -76,7 +76,8 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     nsdg_mevp_default_params(&c->mevp);
     c->nx = c->ny = 0;
     c->hx = c->hy = 0.;
-    c->mevp_variant = 0;
+    c->mevp_variant = 1;
+    c->strip_rows = 8;
     c->d_ptrs = nullptr;
     *out = c;
     return NSDG_OK;
@@ -124,6 +125,14 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy)
     ctx->ny = ny;
     ctx->hx = hx;
     ctx->hy = hy;
+    return NSDG_OK;
+}
+
+int nsdg_mevp_strip_rows_set(nsdg_ctx* ctx, int32_t rows)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(rows >= 1 && rows <= 4096, "rows per strip must be in 1..4096");
+    ctx->strip_rows = rows;
     return NSDG_OK;
 }
 

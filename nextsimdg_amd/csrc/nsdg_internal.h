@@ -15,6 +15,7 @@ struct nsdg_ctx {
     int nx, ny; // local element array
     double hx, hy;
     int mevp_variant;
+    int strip_rows; // rows per strip of the fused marching kernel
     // device scratch for small host->device tables (field pointer lists of the transport stage)
     double** d_ptrs;
 };

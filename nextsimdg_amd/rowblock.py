@@ -118,6 +118,7 @@ class DynamicsCore:
         nodal = (2 * ny + 1, 2 * nx + 1)
         self.H, self.A = z(6, ny, nx), z(6, ny, nx)
         self.s = [z(8, ny, nx) for _ in range(3)]
+        self.sb = [z(8, ny, nx) for _ in range(3)]
         self.pg = z(9, ny, nx)
         self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
         self.u0, self.v0 = z(*nodal), z(*nodal)
@@ -153,11 +154,12 @@ class DynamicsCore:
         self.u0.copy_(self.u)
         self.v0.copy_(self.v)
         for _ in range(self.nsub):
-            ops.mevp_iterate(b.k0, b.j0, b.j1, self.dt, self.s, (self.u, self.v), (self.ub, self.vb),
+            ops.mevp_iterate(b.k0, b.j0, b.j1, self.dt, self.s, self.sb, (self.u, self.v), (self.ub, self.vb),
                              (self.u0, self.v0), (self.tax, self.tay), (self.uo, self.vo), self.cgh, self.cga, self.pg)
             self.halo.nodal((self.ub, self.vb))
             self.u, self.ub = self.ub, self.u
             self.v, self.vb = self.vb, self.v
+            self.s, self.sb = self.sb, self.s
 
     def transport(self):
         ops, b = self.ops, self.blk

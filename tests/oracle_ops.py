@@ -1,0 +1,50 @@
+"""CPU stand-in for nextsimdg_amd.abi.Context used ONLY by the multi-rank CPU tests: the same method
+names, implemented with the oracle on CPU torch tensors.  It lets world_size-2 `gloo` tests exercise
+the row-block decomposition and halo exchange (nextsimdg_amd/rowblock.py) without a GPU.  It lives
+under tests/ because it calls the oracle; the product never imports it."""
+import numpy as np
+
+import oracle_lib as O
+
+
+def _np(t):
+    return t.numpy()
+
+
+class OracleOps:
+    def __init__(self, **mevp):
+        self.p = O.mevp_params(**mevp)
+
+    def set_grid(self, nx, ny, hx, hy):
+        self.nx, self.ny, self.hx, self.hy = nx, ny, hx, hy
+
+    def dg_to_cg(self, f_dg, f_cg):
+        _np(f_cg)[:] = O.dg_to_cg(self.nx, self.ny, _np(f_dg))
+
+    def ice_strength(self, H, A, pg, j0=0, j1=None):
+        j1 = self.ny if j1 is None else j1
+        _np(pg)[:, j0:j1] = O.ice_strength(self.nx, self.ny, self.p, _np(H), _np(A), j0, j1)[:, j0:j1]
+
+    def wind_stress(self, ua, va, tax, tay):
+        a, b = O.wind_stress(self.p, _np(ua), _np(va))
+        _np(tax)[:] = a
+        _np(tay)[:] = b
+
+    def mevp_iterate(self, k0, j0, j1, dt, s_in, s_out, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, pg):
+        for a, b in zip(s_in, s_out):
+            _np(b)[:] = _np(a)
+        so = [_np(x) for x in s_out]
+        O.mevp_stress(self.nx, self.ny, k0, j1, self.hx, self.hy, self.p, _np(uv_old[0]), _np(uv_old[1]), _np(pg), *so)
+        O.mevp_velocity(self.nx, self.ny, j0, j1, self.hx, self.hy, dt, self.p, so, [_np(x) for x in uv_old],
+                        [_np(x) for x in uv_new], [_np(x) for x in u0v0], [_np(x) for x in tau],
+                        [_np(x) for x in ocean], _np(cgh), _np(cga))
+
+    def prepare_advection(self, order, u, v, vx, vy, unx, uny):
+        res = O.prepare_advection(self.nx, self.ny, order, _np(u), _np(v))
+        for dst, src in zip((vx, vy, unx, uny), res):
+            _np(dst)[:] = src
+
+    def transport_stage(self, order, j0, j1, dt, a, b, phi0, phis, out, adv):
+        advn = tuple(_np(x) for x in adv)
+        for p0, ps, o in zip(phi0, phis, out):
+            O.transport_stage(self.nx, self.ny, j0, j1, self.hx, self.hy, order, dt, a, b, _np(p0), _np(ps), _np(o), advn)

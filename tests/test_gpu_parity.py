@@ -244,7 +244,9 @@ def test_mevp_single_iteration_matches_oracle(ctx, variant):
     du, dv = dev(u), dev(v)
     dun, dvn = torch.full_like(du, 3.0), torch.full_like(dv, 3.0)
     args_d = [(dev(u0), dev(v0)), (dev(tax), dev(tay)), (dev(b.uo), dev(b.vo)), dev(cgh), dev(cga)]
-    ctx.mevp_iterate(0, 0, ny, 120.0, ds, (du, dv), (dun, dvn), *args_d, dev(pg))
+    dso = [torch.zeros_like(x) for x in ds]
+    ctx.mevp_iterate(0, 0, ny, 120.0, ds, dso, (du, dv), (dun, dvn), *args_d, dev(pg))
+    ds = dso
     # oracle
     O.mevp_stress(nx, ny, 0, ny, b.bt.hx, b.bt.hy, b.po, u, v, pg, *s)
     un, vn = np.full_like(u, 3.0), np.full_like(v, 3.0)
@@ -254,7 +256,7 @@ def test_mevp_single_iteration_matches_oracle(ctx, variant):
         assert_close(host(d), o, 1e-12, 1e-12 * np.max(np.abs(o)), name)
     assert_close(host(dun), un, 1e-11, 1e-13 * np.max(np.abs(un)), "u_new")
     assert_close(host(dvn), vn, 1e-11, 1e-13 * np.max(np.abs(vn)), "v_new")
-    ctx.set_mevp_variant(0)
+    ctx.set_mevp_variant(1)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -270,7 +272,7 @@ def test_mevp_subcycle_matches_oracle(ctx, variant):
     u0, v0 = u.copy(), v.copy()
     s = [np.zeros((8, ny, nx)) for _ in range(3)]
     du, dv, ds = dev(u), dev(v), [dev(x) for x in s]
-    scratch = torch.zeros(2 * u.size, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(2 * u.size + 3 * s[0].size, dtype=torch.float64, device="cuda")
     nsub = 25  # odd: exercises the copy-back of the ping-pong buffers
     ctx.mevp_subcycle(120.0, nsub, ds, du, dv, dev(u0), dev(v0), dev(tax), dev(tay), dev(b.uo), dev(b.vo), dev(cgh),
                       dev(cga), dev(pg), scratch)
@@ -283,7 +285,7 @@ def test_mevp_subcycle_matches_oracle(ctx, variant):
     # Dirichlet rows/columns are exactly zero
     g = host(du)
     assert np.all(g[0] == 0) and np.all(g[-1] == 0) and np.all(g[:, 0] == 0) and np.all(g[:, -1] == 0)
-    ctx.set_mevp_variant(0)
+    ctx.set_mevp_variant(1)
 
 
 def test_mevp_row_block_equals_full_domain_bitwise(ctx):
@@ -298,23 +300,52 @@ def test_mevp_row_block_equals_full_domain_bitwise(ctx):
         pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
         cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
         tax, tay = O.wind_stress(b.po, b.ua, b.va)
-        full = [dev(x) for x in s]
+        full = [torch.zeros_like(dev(x)) for x in s]
         un, vn = torch.zeros_like(dev(u)), torch.zeros_like(dev(v))
         nodal = [(dev(0.5 * u), dev(0.5 * v)), (dev(tax), dev(tay)), (dev(b.uo), dev(b.vo)), dev(cgh), dev(cga)]
-        ctx.mevp_iterate(0, 0, ny, 120.0, full, (dev(u), dev(v)), (un, vn), *nodal, dev(pg))
+        ctx.mevp_iterate(0, 0, ny, 120.0, [dev(x) for x in s], full, (dev(u), dev(v)), (un, vn), *nodal, dev(pg))
         # upper rank: owns element rows [12, 24); local array = rows [11, 24) (ghost row below)
         r0 = 12
         lo = r0 - 1
         sl_e = lambda a: np.ascontiguousarray(a[:, lo:])
         sl_n = lambda a: np.ascontiguousarray(a[2 * lo:])
         ctx.set_grid(nx, ny - lo, b.bt.hx, b.bt.hy)
-        part = [dev(sl_e(x)) for x in s]
+        part = [torch.zeros_like(dev(sl_e(x))) for x in s]
         pun, pvn = torch.zeros_like(dev(sl_n(u))), torch.zeros_like(dev(sl_n(v)))
         pnodal = [(dev(sl_n(0.5 * u)), dev(sl_n(0.5 * v))), (dev(sl_n(tax)), dev(sl_n(tay))),
                   (dev(sl_n(b.uo)), dev(sl_n(b.vo))), dev(sl_n(cgh)), dev(sl_n(cga))]
-        ctx.mevp_iterate(0, 1, ny - lo, 120.0, part, (dev(sl_n(u)), dev(sl_n(v))), (pun, pvn), *pnodal, dev(sl_e(pg)))
+        ctx.mevp_iterate(0, 1, ny - lo, 120.0, [dev(sl_e(x)) for x in s], part, (dev(sl_n(u)), dev(sl_n(v))), (pun, pvn), *pnodal,
+                         dev(sl_e(pg)))
         for f, p in zip(full, part):
             assert torch.equal(f[:, lo:], p)
         assert torch.equal(un[2 * r0:], pun[2:])
         assert torch.equal(vn[2 * r0:], pvn[2:])
-    ctx.set_mevp_variant(0)
+    ctx.set_mevp_variant(1)
+
+
+def test_mevp_fused_strip_size_does_not_change_results(ctx):
+    """the fused marching kernel recomputes strip-boundary rows/columns redundantly; whatever the strip
+    height, results are bit-identical, and they agree with the two-kernel variant to round-off"""
+    b = Box(ctx, 130, 45)
+    nx, ny = b.nx, b.ny
+    rng = np.random.default_rng(29)
+    u, v, s = mevp_state(b, rng)
+    pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
+    cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+    tax, tay = O.wind_stress(b.po, b.ua, b.va)
+    nodal = [(dev(0.5 * u), dev(0.5 * v)), (dev(tax), dev(tay)), (dev(b.uo), dev(b.vo)), dev(cgh), dev(cga)]
+    results = []
+    for variant, rows in ((0, 16), (1, 1), (1, 7), (1, 16), (1, 64)):
+        ctx.set_mevp_variant(variant)
+        ctx.set_mevp_strip_rows(rows)
+        so = [torch.zeros_like(dev(x)) for x in s]
+        un, vn = torch.full_like(dev(u), 9.0), torch.full_like(dev(v), 9.0)
+        ctx.mevp_iterate(0, 0, ny, 120.0, [dev(x) for x in s], so, (dev(u), dev(v)), (un, vn), *nodal, dev(pg))
+        results.append(so + [un, vn])
+    for r in results[2:]:
+        for a, c in zip(results[1], r):
+            assert torch.equal(a, c)
+    for a, c in zip(results[0], results[1]):
+        assert_close(host(c), host(a), 1e-12, 1e-13 * float(a.abs().max()), "fused vs two-kernel")
+    ctx.set_mevp_variant(1)
+    ctx.set_mevp_strip_rows(8)

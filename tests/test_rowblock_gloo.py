@@ -1,0 +1,94 @@
+"""Multi-rank path on CPU: world_size 2 and 3 over `gloo`.  The row-block driver and halo exchange of
+nextsimdg_amd/rowblock.py are the product code under test; the numerical kernels are replaced by the
+oracle (tests/oracle_ops.py) because no GPU exists here.  The decomposed run must reproduce the
+single-domain run bit for bit (gather formulation + redundant ghost-row stress update)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from nextsimdg_amd import rowblock, synthetic  # noqa: E402
+
+NX, NY, NSUB, NSTEPS = 20, 23, 5, 2
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_core(rank, world):
+    from oracle_ops import OracleOps
+
+    bt = synthetic.BoxTest(NX, NY)
+    rng = np.random.default_rng(41)
+    H, A = bt.dg_fields()
+    A[0] -= 0.3 * rng.random((NY, NX))
+    H[1:3] += 0.02 * rng.standard_normal((2, NY, NX))
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    blk = rowblock.RowBlock(NX, NY, rank, world)
+    core = rowblock.DynamicsCore(OracleOps(alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"))
+    core.load_global(H, A, uo, vo, 3.0 * ua, 3.0 * va)
+    for _ in range(NSTEPS):
+        core.step()
+    return core
+
+
+def worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        core = run_core(rank, world)
+        out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
+        out["s11"] = core.owned(core.s[0]).clone()
+        torch.save(out, os.path.join(outdir, "rank%d.pt" % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rowblock_index_bookkeeping():
+    for world in (1, 2, 3, 8):
+        rows = []
+        for r in range(world):
+            b = rowblock.RowBlock(16, 37, r, world)
+            assert b.ny == (b.r1 - b.r0) + b.gb + b.gt
+            assert (b.j0, b.j1) == (b.gb, b.ny - b.gt)
+            assert (b.below is None) == (r == 0) and (b.above is None) == (r == world - 1)
+            rows.append((b.r0, b.r1))
+        assert rows[0][0] == 0 and rows[-1][1] == 37
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+    with pytest.raises(ValueError):
+        rowblock.RowBlock(4, 2, 0, 3)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_block_run_equals_single_domain_bitwise(world, tmp_path):
+    ref = run_core(0, 1)
+    assert float(ref.u.abs().max()) > 1e-5
+    port = free_port()
+    mp.spawn(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
+        got = torch.cat([p[key] for p in parts], dim=1)
+        assert torch.equal(got, full), key
+    for key, full in (("u", ref.u), ("v", ref.v)):
+        got = torch.cat([p[key] for p in parts], dim=0)
+        assert got.shape == full.shape
+        assert torch.equal(got, full), key
