@@ -1,0 +1,59 @@
+// RectGrid.hpp -- size-configurable rectangular structure ("rectgrid") and the reference-compatible
+// fixed 10x10 "devgrid" (core/src/modules/DevGrid.cpp:16-48, DevGrid.hpp:24-73).
+//
+// Restart files: the reference writes NetCDF-4 (core/src/DevGridIO.cpp:65-210); neither netCDF nor
+// HDF5 development files exist in this image, so dump()/init() use a documented raw sidecar with
+// the same logical content: a text header
+//     NSDG-RESTART 1 / structure.type=<name> / data.x=<nx> / data.y=<ny> / data.nLayers=<n>
+// followed by the float64 variables hice, cice, hsnow, sst, sss (x, y) and tice (x, y, nLayers) in
+// x-major order, little endian.
+#pragma once
+#include "Configured.hpp"
+#include "IStructure.hpp"
+
+namespace Nextsim {
+
+class RectGrid : public IStructure, public Configured<RectGrid> {
+public:
+    RectGrid();
+    void configure() override; //!< rectgrid.nx / rectgrid.ny / rectgrid.nLayers
+    void init(const std::string& filePath) override;
+    void dump(const std::string& filePath) const override;
+    std::string structureType() const override { return "rectgrid"; }
+    int nIceLayers() const override { return m_store.nLayers; }
+    int nx() const override { return m_nx; }
+    int ny() const override { return m_ny; }
+    FieldStore& fields() override { return m_store; }
+    const FieldStore& fields() const override { return m_store; }
+    void resize(int nx, int ny, int nLayers);
+
+    int resetCursor() override;
+    bool validCursor() const override { return m_cursor < m_store.n; }
+    ElementData& cursorData() override { return m_current; }
+    void incrCursor() override;
+
+    //! Reads the structure type recorded in a restart file ("" if unreadable).
+    static std::string typeInFile(const std::string& filePath);
+
+protected:
+    int m_nx, m_ny;
+    FieldStore m_store;
+    std::size_t m_cursor = 0;
+    ElementData m_current;
+};
+
+class DevGrid : public RectGrid {
+public:
+    DevGrid() { resize(10, 10, 1); } // core/src/modules/DevGrid.cpp:20, DevGrid.hpp:49
+    void configure() override { } // the reference's grid is a compile-time 10x10
+    std::string structureType() const override { return "devgrid"; }
+};
+
+class StructureFactory {
+public:
+    //! std::invalid_argument for an unknown name (core/src/StructureFactory.cpp:20-44)
+    static std::shared_ptr<IStructure> generate(const std::string& structureName);
+    static std::shared_ptr<IStructure> generateFromFile(const std::string& filePath);
+};
+
+} // namespace Nextsim

@@ -1,0 +1,200 @@
+#include "RectGrid.hpp"
+
+#include <cstdint>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+#include "ModuleLoader.hpp"
+
+namespace Nextsim {
+
+void FieldStore::resize(std::size_t nElements, int nIceLayers)
+{
+    n = nElements;
+    nLayers = nIceLayers;
+    for (auto* v : { &hice, &cice, &hsnow, &sst, &sss, &tair, &tdew, &slp, &mixrat, &qsw, &qlw, &mld, &snowfall, &wind, &newice })
+        v->assign(n, 0.);
+    tice.assign(n * (std::size_t)nLayers, 0.);
+}
+
+ElementData& ElementData::operator=(const PrognosticGenerator& g)
+{
+    iceThickness() = g.m_hice;
+    iceConcentration() = g.m_cice;
+    snowThickness() = g.m_hsnow;
+    seaSurfaceTemperature() = g.m_sst;
+    seaSurfaceSalinity() = g.m_sss;
+    for (int l = 0; l < s->nLayers; ++l) // missing layers repeat the last given one (PrognosticData.cpp:82-94)
+        iceTemperature(l) = g.m_tice.empty() ? 0. : g.m_tice[std::min<std::size_t>(l, g.m_tice.size() - 1)];
+    return *this;
+}
+
+void DummyExternalData::setAll(IStructure& is)
+{
+    for (is.cursor = 0; is.cursor; ++is.cursor) {
+        is.cursor->airTemperature() = -1;
+        is.cursor->dewPoint2m() = -4;
+        is.cursor->airPressure() = 1e5;
+        is.cursor->mixingRatio() = -1.;
+        is.cursor->incomingShortwave() = 0;
+        is.cursor->incomingLongwave() = 311;
+        is.cursor->mixedLayerDepth() = 10;
+        is.cursor->snowfall() = 0;
+    }
+}
+
+RectGrid::RectGrid()
+    : m_nx(0)
+    , m_ny(0)
+    , m_current(&m_store, 0)
+{
+    resize(10, 10, 1);
+}
+
+void RectGrid::resize(int nx, int ny, int nLayers)
+{
+    if (nx <= 0 || ny <= 0 || nLayers <= 0)
+        throw std::invalid_argument("RectGrid: nx, ny and nLayers must be positive");
+    m_nx = nx;
+    m_ny = ny;
+    m_store.resize((std::size_t)nx * ny, nLayers);
+    resetCursor();
+}
+
+template <> const std::map<int, std::string> Configured<RectGrid>::keyMap = { { 0, "rectgrid.nx" }, { 1, "rectgrid.ny" }, { 2, "rectgrid.nLayers" } };
+
+void RectGrid::configure()
+{
+    const int nx = getConfiguration(keyMap.at(0), m_nx);
+    const int ny = getConfiguration(keyMap.at(1), m_ny);
+    const int nl = getConfiguration(keyMap.at(2), m_store.nLayers);
+    if (nx != m_nx || ny != m_ny || nl != m_store.nLayers)
+        resize(nx, ny, nl);
+}
+
+int RectGrid::resetCursor()
+{
+    m_cursor = 0;
+    m_current = ElementData(&m_store, 0);
+    return 0;
+}
+
+void RectGrid::incrCursor()
+{
+    ++m_cursor;
+    m_current = ElementData(&m_store, m_cursor);
+}
+
+namespace {
+const char* MAGIC = "NSDG-RESTART 1";
+bool readHeader(std::istream& f, std::string& type, int& nx, int& ny, int& nl)
+{
+    std::string line;
+    if (!std::getline(f, line) || line != MAGIC)
+        return false;
+    type.clear();
+    nx = ny = nl = 0;
+    while (std::getline(f, line) && line != "END-HEADER") {
+        const auto eq = line.find('=');
+        if (eq == std::string::npos)
+            continue;
+        const std::string k = line.substr(0, eq), v = line.substr(eq + 1);
+        if (k == "structure.type")
+            type = v;
+        else if (k == "data.x")
+            nx = std::stoi(v);
+        else if (k == "data.y")
+            ny = std::stoi(v);
+        else if (k == "data.nLayers")
+            nl = std::stoi(v);
+    }
+    return nx > 0 && ny > 0 && nl > 0;
+}
+} // namespace
+
+std::string RectGrid::typeInFile(const std::string& filePath)
+{
+    std::ifstream f(filePath, std::ios::binary);
+    std::string type;
+    int a, b, c;
+    return (f && readHeader(f, type, a, b, c)) ? type : std::string();
+}
+
+void RectGrid::dump(const std::string& filePath) const
+{
+    std::ofstream f(filePath, std::ios::binary);
+    if (!f)
+        throw std::runtime_error("cannot write restart file " + filePath);
+    f << MAGIC << "\n"
+      << metadataNodeName() << "." << typeNodeName() << "=" << structureType() << "\n"
+      << dataNodeName() << ".x=" << m_nx << "\n"
+      << dataNodeName() << ".y=" << m_ny << "\n"
+      << dataNodeName() << ".nLayers=" << m_store.nLayers << "\n"
+      << "variables=hice,cice,hsnow,sst,sss,tice\nEND-HEADER\n";
+    for (const auto* v : { &m_store.hice, &m_store.cice, &m_store.hsnow, &m_store.sst, &m_store.sss })
+        f.write(reinterpret_cast<const char*>(v->data()), (std::streamsize)(v->size() * sizeof(double)));
+    // tice is (x, y, nLayers) in the file, layer-major planes in memory
+    std::vector<double> t(m_store.tice.size());
+    for (std::size_t e = 0; e < m_store.n; ++e)
+        for (int l = 0; l < m_store.nLayers; ++l)
+            t[e * m_store.nLayers + l] = m_store.tice[(std::size_t)l * m_store.n + e];
+    f.write(reinterpret_cast<const char*>(t.data()), (std::streamsize)(t.size() * sizeof(double)));
+}
+
+void RectGrid::init(const std::string& filePath)
+{
+    tryConfigure(*this);
+    if (filePath.empty()) { // constants, defaults = run/dev_res.py:10-20 of the reference
+        typedef Configured<RectGrid> C;
+        const double hice = C::getConfiguration("init.hice", 0.1), cice = C::getConfiguration("init.cice", 0.5);
+        const double hsnow = C::getConfiguration("init.hsnow", 0.0), sst = C::getConfiguration("init.sst", -1.0);
+        const double sss = C::getConfiguration("init.sss", 32.0), tice = C::getConfiguration("init.tice", -1.0);
+        for (cursor = 0; cursor; ++cursor)
+            *cursor = PrognosticGenerator().hice(hice).cice(cice).hsnow(hsnow).sst(sst).sss(sss).tice({ tice });
+        return;
+    }
+    std::ifstream f(filePath, std::ios::binary);
+    std::string type;
+    int nx, ny, nl;
+    if (!f || !readHeader(f, type, nx, ny, nl))
+        throw std::runtime_error("cannot read restart file " + filePath);
+    if (structureType() == "devgrid" && (nx != 10 || ny != 10))
+        throw std::runtime_error("devgrid restart files must be 10x10");
+    resize(nx, ny, nl);
+    for (auto* v : { &m_store.hice, &m_store.cice, &m_store.hsnow, &m_store.sst, &m_store.sss })
+        f.read(reinterpret_cast<char*>(v->data()), (std::streamsize)(v->size() * sizeof(double)));
+    std::vector<double> t(m_store.tice.size());
+    f.read(reinterpret_cast<char*>(t.data()), (std::streamsize)(t.size() * sizeof(double)));
+    if (!f)
+        throw std::runtime_error("restart file " + filePath + " is truncated");
+    for (std::size_t e = 0; e < m_store.n; ++e)
+        for (int l = 0; l < nl; ++l)
+            m_store.tice[(std::size_t)l * m_store.n + e] = t[e * nl + l];
+}
+
+// registration order = default order: devgrid first, as in core/src/modules/modules.json:9-14
+NSDG_REGISTER_MODULE(IStructure, DevGrid, "Nextsim::IStructure", "Nextsim::DevGrid");
+NSDG_REGISTER_MODULE(IStructure, RectGrid, "Nextsim::IStructure", "Nextsim::RectGrid");
+
+std::shared_ptr<IStructure> StructureFactory::generate(const std::string& structureName)
+{
+    ModuleLoader& loader = ModuleLoader::getLoader();
+    for (const std::string& impl : loader.listImplementations("Nextsim::IStructure")) {
+        loader.setImplementation("Nextsim::IStructure", impl);
+        std::shared_ptr<IStructure> s(loader.getInstance<IStructure>().release());
+        if (s->structureTypeCheck(structureName))
+            return s;
+    }
+    throw std::invalid_argument("StructureFactory::generate: no structure type named " + structureName);
+}
+
+std::shared_ptr<IStructure> StructureFactory::generateFromFile(const std::string& filePath)
+{
+    const std::string type = RectGrid::typeInFile(filePath);
+    if (type.empty())
+        throw std::invalid_argument("StructureFactory::generateFromFile: no structure type in " + filePath);
+    return generate(type);
+}
+
+} // namespace Nextsim

@@ -1,0 +1,37 @@
+// main.cpp -- `nextsim_amd`: same start-up sequence as the reference's main (core/src/main.cpp:14-37):
+// command line -> config files -> module defaults -> [Modules] overrides -> Model::configure -> run.
+#include <cstdio>
+#include <iostream>
+
+#include "CommandLineParser.hpp"
+#include "ConfiguredModule.hpp"
+#include "Configurator.hpp"
+#include "Model.hpp"
+#include "ModuleLoader.hpp"
+
+int main(int argc, char* argv[])
+{
+    using namespace Nextsim;
+    Configurator::setCommandLine(argc, argv);
+    CommandLineParser cmdLine(argc, argv);
+    if (cmdLine.helpRequested()) {
+        std::cerr << CommandLineParser::helpText() << std::endl;
+        return 0;
+    }
+    Configurator::addFiles(cmdLine.getConfigFileNames());
+    try {
+        ModuleLoader::getLoader().setAllDefaults();
+        ConfiguredModule::parseConfigurator();
+        Model model;
+        model.configure();
+        model.run();
+        // one line per run with the state of element 0 (all elements are identical in run/dev1.cfg)
+        const FieldStore& f = model.structure().fields();
+        std::printf("elements=%zu launches=%ld hice=%.17g cice=%.17g hsnow=%.17g tice0=%.17g sst=%.17g\n", f.n, model.step().launches(),
+            f.hice[0], f.cice[0], f.hsnow[0], f.tice[0], f.sst[0]);
+    } catch (const std::exception& e) {
+        std::cerr << "nextsim_amd: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

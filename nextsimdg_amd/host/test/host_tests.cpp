@@ -1,0 +1,410 @@
+// host_tests.cpp -- tests of the C++ host layer.  The cases restate, against this repo's own
+// implementation, the behaviour the reference's Catch2 tests pin (file:line given per case); the GPU
+// cases (run with --gpu) drive HipStep / Model through the C ABI and compare with the reference's
+// known answers.  Tiny self-contained harness: CHECK() records failures, exit code = #failures.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <sstream>
+#include <typeinfo>
+
+#include "CommandLineParser.hpp"
+#include "ConfiguredModule.hpp"
+#include "Configurator.hpp"
+#include "Model.hpp"
+#include "ModuleLoader.hpp"
+#include "PhysicsModules.hpp"
+
+using namespace Nextsim;
+
+static int failures = 0, checks = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        ++checks;                                                                \
+        if (!(cond)) {                                                           \
+            ++failures;                                                          \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);          \
+        }                                                                        \
+    } while (0)
+#define CHECK_THROWS_AS(expr, Ex)                                                \
+    do {                                                                         \
+        ++checks;                                                                \
+        bool ok_ = false;                                                        \
+        try {                                                                    \
+            expr;                                                                \
+        } catch (const Ex&) {                                                    \
+            ok_ = true;                                                          \
+        } catch (...) {                                                          \
+        }                                                                        \
+        if (!ok_) {                                                              \
+            ++failures;                                                          \
+            std::printf("FAIL %s:%d: %s did not throw %s\n", __FILE__, __LINE__, #expr, #Ex); \
+        }                                                                        \
+    } while (0)
+static bool approx(double got, double want, double eps) { return std::fabs(got - want) <= eps * std::fabs(want) + 1e-300; }
+
+// fake backend of the reference's loader tests (core/test/moduleTestClasses.hpp:12-28)
+class ITest {
+public:
+    virtual ~ITest() = default;
+    virtual int operator()() = 0;
+};
+class Impl1 : public ITest {
+public:
+    int operator()() override { return 1; }
+};
+class Impl2 : public ITest {
+public:
+    int operator()() override { return 2; }
+};
+NSDG_REGISTER_MODULE(ITest, Impl1, "ITest", "Impl1");
+NSDG_REGISTER_MODULE(ITest, Impl2, "ITest", "Impl2");
+
+struct ArgV { // fake argv (core/test/ArgV.cpp:12-41)
+    std::vector<std::string> s;
+    std::vector<char*> p;
+    ArgV(std::initializer_list<const char*> a)
+    {
+        for (auto x : a)
+            s.emplace_back(x);
+        for (auto& x : s)
+            p.push_back(&x[0]);
+        p.push_back(nullptr);
+    }
+    int argc() { return (int)s.size(); }
+    char** operator()() { return p.data(); }
+};
+static void addConfig(const std::string& text) { Configurator::addStream(std::unique_ptr<std::istream>(new std::stringstream(text))); }
+
+static void test_module_loader()
+{ // core/test/ModuleLoader_test.cpp:14-26
+    ModuleLoader& ldr = ModuleLoader::getLoader();
+    CHECK(ldr.listModules().count("ITest") == 1);
+    CHECK(ldr.listImplementations("ITest").size() == 2);
+    ldr.setImplementation("ITest", "Impl1");
+    Impl1 i1;
+    CHECK(typeid(i1) == typeid(*(ldr.getInstance<ITest>())));
+    CHECK(&ldr.getImplementation<ITest>() == &ldr.getImplementation<ITest>()); // one shared static instance
+    CHECK(ldr.getInstance<ITest>().get() != ldr.getInstance<ITest>().get()); // fresh objects
+    ldr.setImplementation("ITest", "Impl2");
+    CHECK(ldr.getImplementation<ITest>()() == 2);
+    CHECK_THROWS_AS(ldr.setImplementation("ITest", "Impl3"), std::invalid_argument); // ModuleLoader.cpp:16-21
+    CHECK_THROWS_AS(ldr.listImplementations("NoSuchModule"), std::out_of_range); // ModuleLoader.hpp:51
+    ldr.setAllDefaults(); // default = first listed (ModuleLoader.cpp:51-54)
+    CHECK(ldr.getImplementation<ITest>()() == 1);
+    // the real registry: names and order of the reference's modules.json files
+    const auto& alb = ldr.listImplementations("Nextsim::IIceAlbedo");
+    CHECK(alb.size() == 3 && alb.front() == "Nextsim::SMUIceAlbedo" && alb.back() == "Nextsim::CCSMIceAlbedo");
+    CHECK(ldr.listImplementations("Nextsim::IFreezingPoint").front() == "Nextsim::LinearFreezing");
+    for (const char* m : { "Nextsim::IStructure", "Nextsim::IIceOceanHeatFlux", "Nextsim::IConcentrationModel", "Nextsim::IThermodynamics", "Nextsim::IPhysics1d" })
+        CHECK(ldr.listModules().count(m) == 1);
+    ModuleLoader::VariablesMap vm = { { "Nextsim::IFreezingPoint", "Nextsim::UnescoFreezing" } };
+    ldr.init(vm);
+    CHECK(std::fabs(ldr.getImplementation<IFreezingPoint>()(32.) - (-1.751)) < 5e-3);
+    ldr.setAllDefaults();
+    CHECK(ldr.getImplementation<IFreezingPoint>()(32.) == -0.055 * 32.);
+}
+
+static void test_configured_module()
+{ // core/test/ConfiguredModule_test.cpp:22-88
+    Configurator::clear();
+    ArgV argvee({ "cmtest", "--Modules.ITest=Impl1" });
+    Configurator::setCommandLine(argvee.argc(), argvee());
+    ConfiguredModule::parseConfigurator();
+    CHECK(ModuleLoader::getLoader().getImplementation<ITest>()() == 1);
+
+    Configurator::clear();
+    addConfig("[Modules]\nITest = Impl2\n");
+    ConfiguredModule::parseConfigurator();
+    CHECK(ModuleLoader::getLoader().getImplementation<ITest>()() == 2);
+
+    Configurator::clear();
+    ModuleLoader::getLoader().setImplementation("ITest", "Impl2");
+    addConfig("[Modules]\nITestNotReally = NotImpl2\n"); // unknown module: ignored, selection unchanged
+    ConfiguredModule::parseConfigurator();
+    CHECK(ModuleLoader::getLoader().getImplementation<ITest>()() == 2);
+
+    Configurator::clear();
+    addConfig("[Modules]\nITest = Graham\n");
+    CHECK_THROWS_AS(ConfiguredModule::parseConfigurator(), std::domain_error);
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+}
+
+class Config1 : public Configured<Config1> { // core/test/Configurator_test.cpp:23-117 style fixtures
+public:
+    int value = 0;
+    std::string name;
+    void configure() override
+    {
+        value = getConfiguration<int>("config.value", -1);
+        name = getConfiguration<std::string>("config.name", "");
+    }
+};
+class Config2 : public Configured<Config2> {
+public:
+    int value = 0;
+    double weight = 0;
+    void configure() override
+    {
+        value = getConfiguration<int>("config.value", -2);
+        weight = getConfiguration<double>("data.weight", 1.5);
+    }
+};
+class NotConfigured {
+public:
+    int x = 7;
+};
+
+static void test_configurator()
+{ // core/test/Configurator_test.cpp:119-230
+    Configurator::clear();
+    Config1 c1;
+    c1.configure();
+    CHECK(c1.value == -1 && c1.name.empty()); // defaults when nothing is configured
+    addConfig("[config]\nvalue = 42\nname = Zaphod\n\n# comment\n[data]\nweight = 2.5\n");
+    tryConfigure(c1); // by reference
+    CHECK(c1.value == 42 && c1.name == "Zaphod");
+    Config2 c2;
+    tryConfigure(&c2); // by pointer; two classes share config.value
+    CHECK(c2.value == 42 && c2.weight == 2.5);
+    NotConfigured nc;
+    tryConfigure(nc); // silently ignored
+    tryConfigure(&nc);
+    CHECK(nc.x == 7);
+    // two streams: the first one that defines a key wins (Configurator.hpp:23-26)
+    addConfig("[config]\nvalue = 43\n[extra]\nthing = 9\n");
+    c1.configure();
+    CHECK(c1.value == 42);
+    CHECK(Configured<Config1>::getConfiguration<int>("extra.thing", 0) == 9);
+    // the command line overrides every stream
+    ArgV a({ "prog", "--config.value=7", "--unrelated", "--data.weight", "0.125" });
+    Configurator::setCommandLine(a.argc(), a());
+    c2.configure();
+    CHECK(c2.value == 7 && c2.weight == 0.125);
+    Configurator::clear();
+    c2.configure();
+    CHECK(c2.value == -2 && c2.weight == 1.5);
+    CHECK(Configured<Config1>::getConfiguration<bool>("a.flag", true) == true);
+    addConfig("[a]\nflag = false\n");
+    CHECK(Configured<Config1>::getConfiguration<bool>("a.flag", true) == false);
+    Configurator::clear();
+}
+
+static void test_command_line_parser()
+{ // core/test/CommandLineParser_test.cpp:19-40
+    ArgV argv1({ "nextsimdg", "--config-file", "config.cfg" });
+    CommandLineParser clp1(argv1.argc(), argv1());
+    CHECK(clp1.getConfigFileNames().size() == 1 && clp1.getConfigFileNames()[0] == "config.cfg");
+    ArgV argv2({ "nextsimdg", "--config-file", "config.cfg", "--config-files", "test.cfg", "more.cfg", "final.cfg" });
+    CommandLineParser clp2(argv2.argc(), argv2());
+    const auto cfgs = clp2.getConfigFileNames();
+    CHECK(cfgs.size() == 4 && cfgs[0] == "config.cfg" && cfgs[1] == "test.cfg" && cfgs.back() == "final.cfg");
+    ArgV argv3({ "nextsimdg", "-h" });
+    CHECK(CommandLineParser(argv3.argc(), argv3()).helpRequested());
+}
+
+class Counter : public Iterator::Iterant { // core/test/Iterator_test.cpp:17-48
+public:
+    int starts = 0, iterates = 0, stops = 0, lastDt = 0;
+    void init() override { }
+    void start(const Iterator::TimePoint&) override { ++starts; }
+    void iterate(const Iterator::Duration& dt) override
+    {
+        ++iterates;
+        lastDt = dt;
+    }
+    void stop(const Iterator::TimePoint&) override { ++stops; }
+};
+
+static void test_iterator()
+{ // core/test/Iterator_test.cpp:50-65
+    Counter c;
+    Iterator it(&c);
+    it.setStartStopStep(0, 5, 1);
+    it.run();
+    CHECK(c.iterates == 5 && c.starts == 1 && c.stops == 1);
+    Counter d;
+    it.setIterant(&d);
+    it.parseAndSet("10", "999", "30", "7"); // run_length takes precedence over stop
+    it.run();
+    CHECK(d.iterates == 5 && d.lastDt == 7); // t = 10, 17, 24, 31, 38 < 40
+    it.parseAndSet("0", "1", "", "1"); // run/dev1.cfg: one iterate(1)
+    Counter e;
+    it.setIterant(&e);
+    it.run();
+    CHECK(e.iterates == 1);
+}
+
+static void test_physics_config()
+{ // physics/test/NextsimPhysics_test.cpp:21-45 + [Modules] selection as at :178-189
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    addConfig("[nextsim_thermo]\nmin_conc = 2e-12\nmin_thick = 0.02\nI_0 = 0.18\n");
+    NextsimPhysics nsphys;
+    nsphys.configure();
+    CHECK(NextsimPhysics::minimumIceConcentration() == 2e-12);
+    CHECK(NextsimPhysics::minimumIceThickness() == 0.02);
+    CHECK(NextsimPhysics::i0() == 0.18);
+    nsdg_column_params p;
+    nsphys.describe(p);
+    CHECK(p.min_conc == 2e-12 && p.min_thick == 0.02 && p.i0 == 0.18);
+    CHECK(p.albedo_kind == NSDG_ALBEDO_SMU && p.freezing_kind == NSDG_FREEZING_LINEAR && p.ks == 0.3096 && p.flooding == 1);
+    Configurator::clear();
+    addConfig("[Modules]\nNextsim::IFreezingPoint = Nextsim::UnescoFreezing\nNextsim::IIceAlbedo = Nextsim::CCSMIceAlbedo\n\n"
+              "[CCSMIceAlbedo]\niceAlbedo = 0.63\nsnowAlbedo = 0.88\n[thermoice0]\nflooding = false\n[Hibler]\nh0 = 0.3\n");
+    ConfiguredModule::parseConfigurator();
+    nsphys.configure();
+    nsphys.describe(p);
+    CHECK(p.albedo_kind == NSDG_ALBEDO_CCSM && p.freezing_kind == NSDG_FREEZING_UNESCO);
+    CHECK(p.ccsm_ice_albedo == 0.63 && p.ccsm_snow_albedo == 0.88 && p.flooding == 0 && p.h0 == 0.3 && p.phi_m == 0.5);
+    CHECK(p.min_conc == 1e-12 && p.i0 == 0.17); // back to the defaults
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    nsphys.configure();
+}
+
+static void test_structure()
+{ // core/test/DevGrid_test.cpp:24-103, StructureFactory_test.cpp:19-47, ElementData_test.cpp:57-63
+    Configurator::clear();
+    DevGrid grid;
+    CHECK(grid.nx() == 10 && grid.ny() == 10 && grid.size() == 100 && grid.nIceLayers() == 1);
+    CHECK(grid.structureTypeCheck("DevGrid") && grid.structureTypeCheck("devgrid") && !grid.structureTypeCheck("rectgrid"));
+    const int nx = 10;
+    int count = 0;
+    for (grid.cursor = 0; grid.cursor; ++grid.cursor) {
+        const int slow = count / nx, fast = count % nx; // cursor order = linear index slow*nx + fast
+        const double fractional = slow * 0.01 + fast * 0.0001;
+        *grid.cursor = PrognosticGenerator().hice(1 + fractional).cice(2 + fractional).sst(3 + fractional).sss(4 + fractional).hsnow(5 + fractional).tice({ -(1. + fractional) });
+        ++count;
+    }
+    CHECK(count == 100);
+    const std::string path = "/tmp/nsdg_host_test_restart.nsdg";
+    grid.dump(path);
+    auto again = StructureFactory::generateFromFile(path);
+    CHECK(again->structureType() == "devgrid");
+    again->init(path);
+    int targetIndex = 7 * nx + 3; // linear index i*nx + j (core/src/DevGridIO.cpp:107-109)
+    again->cursor = 0;
+    for (int k = 0; k < targetIndex; ++k)
+        ++again->cursor;
+    CHECK(again->cursor->iceThickness() == 1.0703);
+    CHECK(again->cursor->iceConcentration() == 2.0703 && again->cursor->iceTemperature(0) == -1.0703);
+    CHECK(again->fields().hice[targetIndex] == 1.0703); // SoA plane and cursor agree
+    CHECK(StructureFactory::generate("devgrid")->structureType() == "devgrid");
+    CHECK_THROWS_AS(StructureFactory::generate("notagrid"), std::invalid_argument);
+    // size-configurable grid
+    addConfig("[rectgrid]\nnx = 7\nny = 5\nnLayers = 3\n");
+    auto rect = StructureFactory::generate("rectgrid");
+    rect->init("");
+    CHECK(rect->nx() == 7 && rect->ny() == 5 && rect->nIceLayers() == 3 && rect->size() == 35);
+    rect->cursor = 0;
+    ElementData& d = *rect->cursor;
+    d = PrognosticGenerator().hice(0.1).cice(0.5).sst(-1).sss(32).hsnow(0.01).tice({ -1., -2., -3. });
+    CHECK(d.iceThickness() == 0.1 && d.iceConcentration() == 0.5 && d.snowThickness() == 0.01);
+    CHECK(d.seaSurfaceTemperature() == -1 && d.seaSurfaceSalinity() == 32 && d.iceTemperature(0) == -1. && d.iceTemperature(2) == -3.);
+    CHECK(d.iceTrueThickness() == 0.2 && d.snowTrueThickness() == 0.02);
+    DummyExternalData::setAll(*rect);
+    CHECK(rect->fields().tair[34] == -1 && rect->fields().qlw[0] == 311 && rect->fields().mixrat[3] == -1.);
+    Configurator::clear();
+    std::remove(path.c_str());
+}
+
+// ---------------------------------------------------------------------------------- GPU cases
+static void test_hipstep_melting()
+{ // core/test/ElementData_test.cpp:19-87 / physics/test/NextsimPhysics_test.cpp:176-243 through the plugin path
+    Configurator::clear();
+    addConfig("[Modules]\nNextsim::IFreezingPoint = Nextsim::UnescoFreezing\nNextsim::IIceAlbedo = Nextsim::CCSMIceAlbedo\n"
+              "Nextsim::IPhysics1d = Nextsim::NextsimPhysics\n\n[CCSMIceAlbedo]\niceAlbedo = 0.63\nsnowAlbedo = 0.88\n"
+              "[rectgrid]\nnx = 3\nny = 4\nnLayers = 3\n");
+    ModuleLoader::getLoader().setAllDefaults();
+    ConfiguredModule::parseConfigurator();
+    auto grid = StructureFactory::generate("rectgrid");
+    grid->init("");
+    for (grid->cursor = 0; grid->cursor; ++grid->cursor) {
+        ElementData& data = *grid->cursor;
+        data = PrognosticGenerator().hice(0.1).cice(0.5).sst(-1).sss(32).hsnow(0.01).tice({ -1., -1., -1. });
+        data.airTemperature() = 3;
+        data.dewPoint2m() = 2;
+        data.airPressure() = 100000;
+        data.mixedLayerDepth() = 10.;
+        data.incomingLongwave() = 330;
+        data.incomingShortwave() = 50;
+        data.snowfall() = 0;
+        data.windSpeed() = 5;
+    }
+    HipStep step;
+    step.setInitialData(*grid);
+    step.init();
+    step.start(0);
+    step.iterate(600);
+    step.stop(600);
+    CHECK(step.launches() == 1);
+    const FieldStore& f = grid->fields();
+    for (std::size_t e = 0; e < f.n; e += 5) {
+        // expected updated true thickness/concentration of the reference test, as cell means
+        CHECK(approx(f.cice[e], 0.368269, 1e-4));
+        CHECK(approx(f.hice[e] / f.cice[e], 0.12846, 1e-4));
+        CHECK(approx(f.hsnow[e] / f.cice[e], 0.01957732, 1e-4));
+        CHECK(f.tice[e] == 0.0);
+        CHECK(approx(f.cice[e], 0.36826938031129286, 1e-12)); // SURVEY.md Appendix C probe
+        CHECK(f.tice[f.n + e] == 0.0 && f.tice[2 * f.n + e] == 0.0); // layers > 0 are zeroed on write-back (A.7 quirk 5)
+        CHECK(f.sst[e] == -1 && f.sss[e] == 32); // never updated
+    }
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+}
+
+static void test_model_dev1()
+{ // BASELINE config 1: run/dev1.cfg (start 0, stop 1, time_step 1) on the 10x10 devgrid, Dummy forcing
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    addConfig("[model]\ninit_file = dev1.res.nc\nstart = 0\nstop = 1\ntime_step = 1\nfinal_file = /tmp/nsdg_dev1_restart.nsdg\n");
+    ConfiguredModule::parseConfigurator();
+    {
+        Model model;
+        model.configure();
+        model.run();
+        const FieldStore& f = model.structure().fields();
+        CHECK(f.n == 100 && model.step().launches() == 1);
+        for (std::size_t e = 0; e < f.n; ++e) {
+            CHECK(approx(f.hice[e], 0.04668325240678619, 1e-12));
+            CHECK(approx(f.cice[e], 0.36670813101696548, 1e-12));
+            CHECK(f.hsnow[e] == 0.0);
+            CHECK(approx(f.tice[e], -1.444501803353837, 1e-12));
+            CHECK(f.sst[e] == -1.0);
+        }
+    } // ~Model writes the restart file
+    CHECK(RectGrid::typeInFile("/tmp/nsdg_dev1_restart.nsdg") == "devgrid");
+    auto again = StructureFactory::generateFromFile("/tmp/nsdg_dev1_restart.nsdg");
+    again->init("/tmp/nsdg_dev1_restart.nsdg");
+    CHECK(approx(again->fields().cice[99], 0.36670813101696548, 1e-12));
+    std::remove("/tmp/nsdg_dev1_restart.nsdg");
+    Configurator::clear();
+}
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "--gpu") == 0;
+    try {
+        if (!gpu) {
+            test_module_loader();
+            test_configured_module();
+            test_configurator();
+            test_command_line_parser();
+            test_iterator();
+            test_physics_config();
+            test_structure();
+        } else {
+            test_hipstep_melting();
+            test_model_dev1();
+        }
+    } catch (const std::exception& e) {
+        std::printf("FAIL: unexpected exception: %s\n", e.what());
+        ++failures;
+    }
+    std::printf("%s: %d checks, %d failures\n", gpu ? "host GPU tests" : "host CPU tests", checks, failures);
+    return failures ? 1 : 0;
+}

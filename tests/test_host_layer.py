@@ -1,0 +1,75 @@
+"""C++ host layer (nextsimdg_amd/host): plugin registry, configuration, structure, HipStep, Model.
+The C++ test program restates the behaviour pinned by the reference's own Catch2 tests
+(core/test/*_test.cpp, physics/test/NextsimPhysics_test.cpp); pytest only builds and runs it."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "nextsimdg_amd", "host")
+
+
+@pytest.fixture(scope="module")
+def host_build():
+    from nextsimdg_amd import build
+
+    build.build_lib(verbose=False)
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return os.path.join(HOST, "build")
+
+
+def run(cmd, cwd=None):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=cwd, timeout=300)
+    return p.returncode, p.stdout.decode()
+
+
+def test_host_cpu_cases(host_build):
+    rc, out = run([os.path.join(host_build, "host_tests")])
+    assert rc == 0, out
+    assert re.search(r"host CPU tests: \d+ checks, 0 failures", out), out
+
+
+def test_help_lists_the_reference_options(host_build):
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--help"])
+    assert rc == 0
+    for opt in ("--help", "--config-file", "--config-files"):  # core/src/CommandLineParser.cpp:30-37
+        assert opt in out
+
+
+def test_executable_fails_loudly_without_gpu(host_build):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg")], cwd="/tmp")
+    assert rc != 0 and "no HIP device" in out
+
+
+@pytest.mark.gpu
+def test_host_gpu_cases(host_build, gpu):
+    rc, out = run([os.path.join(host_build, "host_tests"), "--gpu"])
+    assert rc == 0, out
+    assert re.search(r"host GPU tests: \d+ checks, 0 failures", out), out
+
+
+@pytest.mark.gpu
+def test_dev1_cfg_end_to_end(host_build, gpu, tmp_path):
+    """BASELINE config 1: ./nextsim --config-file dev1.cfg (run/dev1.sh:5 of the reference) -> one
+    iterate(1) on 100 elements; expected state = SURVEY.md Appendix C row 'dev1'."""
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"),
+                   "--model.final_file=%s" % os.path.join(str(tmp_path), "restart.nsdg")], cwd=str(tmp_path))
+    assert rc == 0, out
+    m = re.search(r"elements=(\d+) launches=(\d+) hice=(\S+) cice=(\S+) hsnow=(\S+) tice0=(\S+) sst=(\S+)", out)
+    assert m, out
+    assert int(m.group(1)) == 100 and int(m.group(2)) == 1
+    got = [float(m.group(i)) for i in range(3, 8)]
+    want = [0.04668325240678619, 0.36670813101696548, 0.0, -1.444501803353837, -1.0]
+    for g, w in zip(got, want):
+        assert abs(g - w) <= 1e-12 * abs(w), (got, want)
+    assert os.path.exists(os.path.join(str(tmp_path), "restart.nsdg"))
+    # command-line override of a config value (first-wins precedence): 3 steps instead of 1
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"),
+                   "--model.stop=3", "--model.final_file=%s" % os.path.join(str(tmp_path), "r2.nsdg")], cwd=str(tmp_path))
+    assert rc == 0 and "launches=3" in out, out
