@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--nsub", type=int, default=120)
     ap.add_argument("--variant", type=int, default=None, help="mEVP kernel variant (default: library default)")
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
+    ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -129,6 +130,8 @@ def main():
         ctx.set_mevp_variant(args.variant)
     if args.strip_rows is not None:
         ctx.set_mevp_strip_rows(args.strip_rows)
+    if args.occupancy is not None:
+        ctx.set_mevp_occupancy(args.occupancy)
     ctx.set_mevp_params(ctx.mevp_default_params())
     blk = rowblock.RowBlock(nx, ny, rank, world)
     core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, device)

@@ -156,11 +156,18 @@ int nsdg_wind_stress(nsdg_ctx* ctx, int64_t nnodes, const double* ua, const doub
 int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, const double* v, const double* pg,
     double* s11, double* s12, double* s22);
 
+/* Per-step coefficients of the momentum update at every CG2 node in an internal packed layout
+ * (6 doubles per node, csrc/mevp_common.h), valid for the whole sub-cycle of one time step because
+ * u0, v0, the wind stress, the ocean current and the nodal H, A do not change inside it.  The context
+ * remembers dt and the mEVP parameters of the packing for the following iterate/velocity calls.
+ * `packed` must hold 8*(2nx+1)*(2ny+1) doubles (6 used) and be 16-byte aligned. */
+int nsdg_mevp_pack_nodal(nsdg_ctx* ctx, double dt, const double* u0, const double* v0, const double* tax,
+    const double* tay, const double* uo, const double* vo, const double* cgh, const double* cga, double* packed);
+
 /* mEVP velocity update of the nodes owned (bottom-left) by element rows [j0, j1) */
-int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const double* s11, const double* s12,
+int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11, const double* s12,
     const double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
-    const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
-    const double* vo, const double* cgh, const double* cga);
+    const double* packed);
 
 /* one complete sub-iteration: stress on element rows [k0, j1) (S_out <- relax(S_in, u_old)), then the
  * velocity of the nodes owned by rows [j0, j1) from S_out.  Out-of-place in both the stress and the
@@ -168,20 +175,21 @@ int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const d
  * strips of the fused kernel) with bit-identical results.  k0 == j0 - 1 (one redundant ghost row below)
  * or k0 == j0 == 0 (rows start at the physical boundary).  Used by multi-rank drivers that exchange
  * velocity halos between sub-iterations. */
-int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, const double* s11_in,
-    const double* s12_in, const double* s22_in, double* s11_out, double* s12_out, double* s22_out,
-    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
-    const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh,
-    const double* cga, const double* pg);
+int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
+    const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old,
+    const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
 
-/* nsub sub-iterations over the whole local array; result in s11/s12/s22 and u, v.
- * scratch: 2*(2nx+1)*(2ny+1) + 24*nx*ny doubles (ping-pong copies of the velocity and the stress). */
+/* nsub sub-iterations over the whole local array (packs the nodal coefficients, then iterates);
+ * result in s11/s12/s22 and u, v.  scratch: 10*(2nx+1)*(2ny+1) + 24*nx*ny doubles, 16-byte aligned
+ * (packed coefficients + ping-pong copies of the velocity and the stress). */
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u,
     double* v, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
     const double* vo, const double* cgh, const double* cga, const double* pg, double* scratch);
 
 /* rows per strip of the fused marching kernel (performance knob; results do not depend on it) */
 int nsdg_mevp_strip_rows_set(nsdg_ctx* ctx, int32_t rows);
+/* register budget of the fused kernel: 1 or 2 resident waves per SIMD (performance knob) */
+int nsdg_mevp_occupancy_set(nsdg_ctx* ctx, int32_t waves_per_simd);
 
 #ifdef __cplusplus
 }

@@ -60,9 +60,11 @@ SYMBOLS = {
     "nsdg_ice_strength": (C.c_int, [VP, I32, I32, VP, VP, VP]),
     "nsdg_wind_stress": (C.c_int, [VP, I64, VP, VP, VP, VP]),
     "nsdg_mevp_stress": (C.c_int, [VP, I32, I32] + [VP] * 6),
-    "nsdg_mevp_velocity": (C.c_int, [VP, I32, I32, D] + [VP] * 15),
-    "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32, D] + [VP] * 19),
+    "nsdg_mevp_pack_nodal": (C.c_int, [VP, D] + [VP] * 9),
+    "nsdg_mevp_velocity": (C.c_int, [VP, I32, I32] + [VP] * 8),
+    "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
+    "nsdg_mevp_occupancy_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
 }
 
@@ -197,6 +199,9 @@ class Context:
     def set_mevp_strip_rows(self, rows):
         self._call(self.lib.nsdg_mevp_strip_rows_set(self.h, rows))
 
+    def set_mevp_occupancy(self, waves_per_simd):
+        self._call(self.lib.nsdg_mevp_occupancy_set(self.h, waves_per_simd))
+
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):
         _check_f64(u, v, vx, vy, unx, uny)
         self._call(self.lib.nsdg_prepare_advection(self.h, order, *[_ptr(t) for t in (u, v, vx, vy, unx, uny)]))
@@ -231,22 +236,27 @@ class Context:
         _check_f64(u, v, pg, s11, s12, s22)
         self._call(self.lib.nsdg_mevp_stress(self.h, k0, k1, *[_ptr(t) for t in (u, v, pg, s11, s12, s22)]))
 
-    def mevp_velocity(self, j0, j1, dt, s, uv_old, uv_new, u0v0, tau, ocean, cgh, cga):
-        ts = [s[0], s[1], s[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], u0v0[0], u0v0[1], tau[0], tau[1],
-              ocean[0], ocean[1], cgh, cga]
+    def mevp_pack_nodal(self, dt, u0v0, tau, ocean, cgh, cga, packed):
+        ts = [u0v0[0], u0v0[1], tau[0], tau[1], ocean[0], ocean[1], cgh, cga, packed]
         _check_f64(*ts)
-        self._call(self.lib.nsdg_mevp_velocity(self.h, j0, j1, float(dt), *[_ptr(t) for t in ts]))
+        if packed.numel() < 8 * cgh.numel():
+            raise NsdgError("packed nodal buffer too small: need %d doubles" % (8 * cgh.numel()))
+        self._call(self.lib.nsdg_mevp_pack_nodal(self.h, float(dt), *[_ptr(t) for t in ts]))
 
-    def mevp_iterate(self, k0, j0, j1, dt, s_in, s_out, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, pg):
-        ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], u0v0[0], u0v0[1], tau[0], tau[1],
-              ocean[0], ocean[1], cgh, cga, pg]
+    def mevp_velocity(self, j0, j1, s, uv_old, uv_new, packed):
+        ts = [s[0], s[1], s[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed]
         _check_f64(*ts)
-        self._call(self.lib.nsdg_mevp_iterate(self.h, k0, j0, j1, float(dt), *[_ptr(t) for t in ts]))
+        self._call(self.lib.nsdg_mevp_velocity(self.h, j0, j1, *[_ptr(t) for t in ts]))
+
+    def mevp_iterate(self, k0, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
+        _check_f64(*ts)
+        self._call(self.lib.nsdg_mevp_iterate(self.h, k0, j0, j1, *[_ptr(t) for t in ts]))
 
     def mevp_subcycle(self, dt, nsub, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch):
         ts = [s[0], s[1], s[2], u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch]
         _check_f64(*ts)
-        need = 2 * u.numel() + 3 * s[0].numel()
+        need = 10 * u.numel() + 3 * s[0].numel()
         if scratch.numel() < need:
             raise NsdgError("mEVP scratch too small: need %d doubles" % need)
         self._call(self.lib.nsdg_mevp_subcycle(self.h, float(dt), int(nsub), *[_ptr(t) for t in ts]))

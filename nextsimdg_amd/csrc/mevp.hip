@@ -67,9 +67,10 @@ __device__ __forceinline__ void load_stress(const double* __restrict__ S11, cons
     }
 }
 
-__global__ __launch_bounds__(256) void mevp_velocity_kernel(nsdg_mevp_params P, int nx, int ny, int j0, int j1, double hx,
-    double hy, double dt, const double* __restrict__ S11, const double* __restrict__ S12, const double* __restrict__ S22,
-    NodeIn in, double* __restrict__ u_new, double* __restrict__ v_new)
+__global__ __launch_bounds__(256) void mevp_velocity_kernel(NodalConsts K, int nx, int ny, int j0, int j1, double hx, double hy,
+    const double* __restrict__ S11, const double* __restrict__ S12, const double* __restrict__ S22,
+    const double* __restrict__ u_old, const double* __restrict__ v_old, const double* __restrict__ packed,
+    double* __restrict__ u_new, double* __restrict__ v_new)
 {
     const int ix = blockIdx.x * 64 + threadIdx.x;
     const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(nsdg_mevp_params P, 
     const long N = (long)nx * ny;
     const long e = (long)iy * nx + ix;
     const int nn = 2 * nx + 1;
-    const double area = hx * hy;
+    const double iarea = 1. / (hx * hy);
     double s11[8], s12[8], s22[8];
     double cx, cy;
     // node sums, accumulated in the order below-left, below, left, own (same as the oracle)
@@ -113,27 +114,28 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(nsdg_mevp_params P, 
     node_contrib<4>(s11, s12, s22, hx, hy, ccx, ccy);
 
     const long nV = (long)(2 * iy) * nn + 2 * ix; // vertex; EX = nV+1; EY = nV+nn; C = nV+nn+1
-    double un, vn;
-    // vertex node (4 elements, lumped = 4/36 area)
-    if (hasL && hasB) {
-        node_update(P, dt, in, nV, vx_, vy_, 1. / (area * (4. * LUMP[0])), un, vn);
+    double un, vn, c[6];
+    // inverse lumped masses: 4, 2, 2, 1 adjacent elements times LUMP = 1/36, 1/9, 1/9, 4/9 of the cell area
+    if (hasL && hasB) { // vertex
+        load_nodal(packed, nV, c);
+        node_update_packed(K, c, u_old[nV], v_old[nV], vx_, vy_, 9. * iarea, un, vn);
     } else
         un = vn = 0.;
     u_new[nV] = un, v_new[nV] = vn;
-    // bottom edge-mid node (2 elements)
-    if (hasB) {
-        node_update(P, dt, in, nV + 1, exx, exy, 1. / (area * (2. * LUMP[1])), un, vn);
+    if (hasB) { // bottom edge-mid
+        load_nodal(packed, nV + 1, c);
+        node_update_packed(K, c, u_old[nV + 1], v_old[nV + 1], exx, exy, 4.5 * iarea, un, vn);
     } else
         un = vn = 0.;
     u_new[nV + 1] = un, v_new[nV + 1] = vn;
-    // left edge-mid node (2 elements)
-    if (hasL) {
-        node_update(P, dt, in, nV + nn, eyx, eyy, 1. / (area * (2. * LUMP[3])), un, vn);
+    if (hasL) { // left edge-mid
+        load_nodal(packed, nV + nn, c);
+        node_update_packed(K, c, u_old[nV + nn], v_old[nV + nn], eyx, eyy, 4.5 * iarea, un, vn);
     } else
         un = vn = 0.;
     u_new[nV + nn] = un, v_new[nV + nn] = vn;
-    // centre node (1 element)
-    node_update(P, dt, in, nV + nn + 1, ccx, ccy, 1. / (area * LUMP[4]), un, vn);
+    load_nodal(packed, nV + nn + 1, c); // centre
+    node_update_packed(K, c, u_old[nV + nn + 1], v_old[nV + nn + 1], ccx, ccy, 2.25 * iarea, un, vn);
     u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
     // right column / top row of the local lattice are boundary nodes (v = 0)
     if (ix == nx - 1) {
@@ -146,6 +148,26 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(nsdg_mevp_params P, 
         if (ix == nx - 1)
             u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
     }
+}
+
+// per-step momentum coefficients, 6 doubles per node (layout: mevp_common.h)
+__global__ __launch_bounds__(256) void mevp_pack_nodal_kernel(nsdg_mevp_params P, long nnodes, double dt,
+    const double* __restrict__ u0, const double* __restrict__ v0, const double* __restrict__ tax,
+    const double* __restrict__ tay, const double* __restrict__ uo, const double* __restrict__ vo,
+    const double* __restrict__ cgh, const double* __restrict__ cga, double* __restrict__ packed)
+{
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes)
+        return;
+    const double h = fmax(cgh[n], P.h_min);
+    const double a = fmin(fmax(cga[n], 0.), 1.);
+    const double mdt = P.rho_ice * h / dt;
+    const double cor = P.rho_ice * h * P.fc;
+    const double uoc = uo[n], voc = vo[n];
+    double2* out = reinterpret_cast<double2*>(packed + n * NODAL_STRIDE);
+    out[0] = make_double2(h, a * (P.c_ocean * P.rho_ocean));
+    out[1] = make_double2(mdt * u0[n] + a * tax[n] - cor * voc, mdt * v0[n] + a * tay[n] + cor * uoc);
+    out[2] = make_double2(uoc, voc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,10 +257,15 @@ __global__ __launch_bounds__(256) void wind_stress_kernel(long n, double f_atm, 
 using namespace nsdg_mevp_detail;
 
 // defined in mevp_fused.hip
-int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, double dt, const double* s11i, const double* s12i,
-    const double* s22i, double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0, const double* v0,
-    const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh, const double* cga,
-    const double* pg);
+int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, const double* s11i, const double* s12i, const double* s22i,
+    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
+    const double* packed, const double* pg);
+
+static NodalConsts nodal_consts(const nsdg_ctx* ctx)
+{
+    const nsdg_mevp_params& P = ctx->mevp;
+    return NodalConsts { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
+}
 
 extern "C" {
 
@@ -305,52 +332,67 @@ int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, con
     return launch_stress(ctx, k0, k1, u, v, pg, s11, s12, s22, s11, s12, s22);
 }
 
-int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, double dt, const double* s11, const double* s12,
-    const double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0,
-    const double* v0, const double* tax, const double* tay, const double* uo, const double* vo, const double* cgh,
-    const double* cga)
+int nsdg_mevp_pack_nodal(nsdg_ctx* ctx, double dt, const double* u0, const double* v0, const double* tax, const double* tay,
+    const double* uo, const double* vo, const double* cgh, const double* cga, double* packed)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(u0 && v0 && tax && tay && uo && vo && cgh && cga && packed, "null field pointer");
+    NSDG_CHECK_ARG(dt > 0, "dt must be positive");
+    NSDG_CHECK_ARG(((uintptr_t)packed & 15) == 0, "packed must be 16-byte aligned");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const long nnodes = (long)(2 * ctx->nx + 1) * (2 * ctx->ny + 1);
+    hipLaunchKernelGGL(mevp_pack_nodal_kernel, dim3(nsdg_div_up(nnodes, 256)), dim3(256), 0, ctx->stream, ctx->mevp, nnodes, dt, u0,
+        v0, tax, tay, uo, vo, cgh, cga, packed);
+    NSDG_CHECK_LAUNCH();
+    ctx->pack_dt = dt; // the launch constants K1, K2 of the velocity update belong to this packing
+    return NSDG_OK;
+}
+
+int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11, const double* s12, const double* s22,
+    const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed)
 {
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
-    NSDG_CHECK_ARG(s11 && s12 && s22 && u_old && v_old && u_new && v_new && u0 && v0 && tax && tay && uo && vo && cgh && cga,
-        "null field pointer");
+    NSDG_CHECK_ARG(s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed, "null field pointer");
     NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
-    NSDG_CHECK_ARG(dt > 0, "dt must be positive");
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    const NodeIn in = { u_old, v_old, u0, v0, tax, tay, uo, vo, cgh, cga };
     const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4));
-    hipLaunchKernelGGL(mevp_velocity_kernel, grid, block, 0, ctx->stream, ctx->mevp, ctx->nx, ctx->ny, j0, j1, ctx->hx, ctx->hy,
-        dt, s11, s12, s22, in, u_new, v_new);
+    if (!(ctx->pack_dt > 0)) {
+        nsdg_set_error("nsdg_mevp_velocity: nsdg_mevp_pack_nodal was not called on this context");
+        return NSDG_ERR_STATE;
+    }
+    hipLaunchKernelGGL(mevp_velocity_kernel, grid, block, 0, ctx->stream, nodal_consts(ctx), ctx->nx, ctx->ny, j0, j1, ctx->hx, ctx->hy, s11, s12, s22,
+        u_old, v_old, packed, u_new, v_new);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }
 
-int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, double dt, const double* s11i, const double* s12i,
+int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const double* s11i, const double* s12i,
     const double* s22i, double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new,
-    double* v_new, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
-    const double* vo, const double* cgh, const double* cga, const double* pg)
+    double* v_new, const double* packed, const double* pg)
 {
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(0 <= k0 && k0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "need 0 <= k0 <= j0 <= j1 <= ny");
     NSDG_CHECK_ARG(k0 == j0 - 1 || (k0 == 0 && j0 == 0), "need k0 == j0 - 1 (one ghost row below) or k0 == j0 == 0");
-    NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && u0 && v0 && tax && tay && uo
-            && vo && cgh && cga && pg,
+    NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed && pg,
         "null field pointer");
     NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
     NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
-    NSDG_CHECK_ARG(dt > 0, "dt must be positive");
     if (k0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!(ctx->pack_dt > 0)) {
+        nsdg_set_error("nsdg_mevp_iterate: nsdg_mevp_pack_nodal was not called on this context");
+        return NSDG_ERR_STATE;
+    }
     if (ctx->mevp_variant == 1)
-        return nsdg_launch_mevp_fused(ctx, k0, j0, j1, dt, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, u0, v0,
-            tax, tay, uo, vo, cgh, cga, pg);
+        return nsdg_launch_mevp_fused(ctx, k0, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     int rc = launch_stress(ctx, k0, j1, u_old, v_old, pg, s11i, s12i, s22i, s11, s12, s22);
     if (rc)
         return rc;
-    return nsdg_mevp_velocity(ctx, j0, j1, dt, s11, s12, s22, u_old, v_old, u_new, v_new, u0, v0, tax, tay, uo, vo, cgh, cga);
+    return nsdg_mevp_velocity(ctx, j0, j1, s11, s12, s22, u_old, v_old, u_new, v_new, packed);
 }
 
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u, double* v,
@@ -361,14 +403,19 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
     NSDG_CHECK_ARG(nsub >= 0, "negative sub-iteration count");
     NSDG_CHECK_ARG(u && v && s11 && s12 && s22 && scratch, "null field pointer");
     NSDG_CHECK_ARG(u0 != u && v0 != v, "u0/v0 (velocity at step start) must not alias the iterate u/v");
+    NSDG_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
     const long nnodes = (long)(2 * ctx->nx + 1) * (2 * ctx->ny + 1);
     const long M = 8L * ctx->nx * ctx->ny;
-    double *ua = u, *va = v, *ub = scratch, *vb = scratch + nnodes;
+    // scratch: [packed nodal 6*nnodes (8*nnodes reserved)][u, v ping-pong 2*nnodes][stress ping-pong 3*M]
+    double* packed = scratch;
+    double *ua = u, *va = v, *ub = scratch + 8 * nnodes, *vb = ub + nnodes;
     double *sa[3] = { s11, s12, s22 };
-    double *sb[3] = { scratch + 2 * nnodes, scratch + 2 * nnodes + M, scratch + 2 * nnodes + 2 * M };
+    double *sb[3] = { vb + nnodes, vb + nnodes + M, vb + nnodes + 2 * M };
+    int rc = nsdg_mevp_pack_nodal(ctx, dt, u0, v0, tax, tay, uo, vo, cgh, cga, packed);
+    if (rc)
+        return rc;
     for (int it = 0; it < nsub; ++it) {
-        int rc = nsdg_mevp_iterate(ctx, 0, 0, ctx->ny, dt, sa[0], sa[1], sa[2], sb[0], sb[1], sb[2], ua, va, ub, vb, u0, v0, tax, tay,
-            uo, vo, cgh, cga, pg);
+        rc = nsdg_mevp_iterate(ctx, 0, 0, ctx->ny, sa[0], sa[1], sa[2], sb[0], sb[1], sb[2], ua, va, ub, vb, packed, pg);
         if (rc)
             return rc;
         double* t = ua; ua = ub; ub = t;

@@ -251,32 +251,42 @@ __device__ __forceinline__ void node_contrib(const double (&s11)[8], const doubl
     cy = -(hy * gx12 + hx * gy22);
 }
 
-struct NodeIn {
-    const double *u_old, *v_old, *u0, *v0, *tax, *tay, *uo, *vo, *cgh, *cga;
+// Per-step coefficients of the momentum update, packed once per time step by
+// mevp_pack_nodal_kernel as 6 consecutive doubles per CG2 node (read with three 16-byte loads).
+// With h' = max(cgH,h_min), m = rho_ice*h', a = clamp(cgA,0,1), cor = m*f_c:
+//   [0] h'                                      [3] c3 = (m/dt)*v0 + a*tau_y + cor*u_ocean
+//   [1] cd = a * C_o * rho_o                    [4] u_ocean
+//   [2] c2 = (m/dt)*u0 + a*tau_x - cor*v_ocean  [5] v_ocean
+// and three launch constants K1 = rho_ice*beta/dt, K2 = rho_ice*(1+beta)/dt, K3 = rho_ice*f_c, so that
+// the update of DESIGN.md section 3.2 reads
+//   drag = cd*|v_o - v|;  u' = (K1 h' u + c2 + drag*u_o + K3 h' v + div_x/M) / (K2 h' + drag)
+//                         v' = (K1 h' v + c3 + drag*v_o - K3 h' u + div_y/M) / (K2 h' + drag)
+constexpr int NODAL_STRIDE = 6;
+
+struct NodalConsts {
+    double k1, k2, k3;
 };
 
-// momentum update of one interior node from values already in registers
-__device__ __forceinline__ void node_update_vals(const nsdg_mevp_params& P, double dt, double uu, double vv, double u0,
-    double v0, double tax, double tay, double uoc, double voc, double cgh, double cga, double divx, double divy,
-    double ilumped, double& un, double& vn)
-{
-    const double du = uoc - uu, dv = voc - vv;
-    const double absocn = sqrt(du * du + dv * dv);
-    const double h = fmax(cgh, P.h_min);
-    const double a_ = fmin(fmax(cga, 0.), 1.);
-    const double mdt = P.rho_ice * h / dt;
-    const double cdrag = a_ * (P.c_ocean * P.rho_ocean) * absocn;
-    const double denom = 1. / (mdt * (1. + P.beta) + cdrag);
-    const double cor = P.rho_ice * h * P.fc;
-    un = denom * (mdt * (P.beta * uu + u0) + a_ * tax + cdrag * uoc + cor * (vv - voc) + divx * ilumped);
-    vn = denom * (mdt * (P.beta * vv + v0) + a_ * tay + cdrag * voc - cor * (uu - uoc) + divy * ilumped);
-}
-
-__device__ __forceinline__ void node_update(const nsdg_mevp_params& P, double dt, const NodeIn& in, long n, double divx,
+__device__ __forceinline__ void node_update_packed(const NodalConsts& K, const double (&c)[6], double uu, double vv, double divx,
     double divy, double ilumped, double& un, double& vn)
 {
-    node_update_vals(P, dt, in.u_old[n], in.v_old[n], in.u0[n], in.v0[n], in.tax[n], in.tay[n], in.uo[n], in.vo[n], in.cgh[n],
-        in.cga[n], divx, divy, ilumped, un, vn);
+    const double du = c[4] - uu, dv = c[5] - vv;
+    const double drag = c[1] * sqrt(du * du + dv * dv);
+    const double denom = 1. / (K.k2 * c[0] + drag);
+    const double c1 = K.k1 * c[0], cor = K.k3 * c[0];
+    un = denom * (c1 * uu + c[2] + drag * c[4] + cor * vv + divx * ilumped);
+    vn = denom * (c1 * vv + c[3] + drag * c[5] - cor * uu + divy * ilumped);
+}
+
+__device__ __forceinline__ void load_nodal(const double* __restrict__ packed, long n, double (&c)[6])
+{
+    const double2* p = reinterpret_cast<const double2*>(packed + n * NODAL_STRIDE);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double2 t = p[k];
+        c[2 * k] = t.x;
+        c[2 * k + 1] = t.y;
+    }
 }
 
 } // namespace nsdg_mevp_detail

@@ -12,7 +12,7 @@
 //          previous iteration of the march (and shifted by one lane for the below-left element),
 //      and applies the momentum update to those 4 nodes.
 // Nothing but the final stress and velocity ever goes to memory: per element-sub-iteration the kernel
-// moves 8 (u,v) + 9 (P) + 24 (S in) + 32 (nodal coefficients) loads and 24 + 8 stores = 840 B of
+// moves 8 (u,v) + 9 (P) + 24 (S in) + 24 (nodal coefficients) loads and 24 + 8 stores = 776 B of
 // unique data, below the 896 B algorithmic figure of SURVEY.md section 8(d) (which counts H, A instead of the
 // pre-evaluated P), against 1152 B for the two-kernel variant.
 //
@@ -37,9 +37,10 @@ __device__ __forceinline__ double shift_up(double x)
     return __shfl_up(x, 1);
 }
 
-__global__ __launch_bounds__(256) void mevp_fused_kernel(nsdg_mevp_params P, int nx, int ny, int k0, int j0, int j1, int R,
-    int ncw, double hx, double hy, double dt, double ialpha, double dmin2, StressPtrs S, NodeIn in,
-    const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, int nx, int ny, int k0, int j0, int j1, int R, int ncw, double hx,
+    double hy, double ialpha, double dmin2, StressPtrs S, const double* __restrict__ u_old, const double* __restrict__ v_old,
+    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
 {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -48,15 +49,14 @@ __global__ __launch_bounds__(256) void mevp_fused_kernel(nsdg_mevp_params P, int
     if (y0 >= j1)
         return; // wave-uniform
     const int y1 = min(y0 + R, j1);
-    const int ix = cw * 63 - 1 + lane;
-    const bool valid = ix >= 0 && ix < nx; // lanes beyond the array compute on zeros and store nothing
+    const int ixr = cw * 63 - 1 + lane;
+    const bool valid = ixr >= 0 && ixr < nx; // lanes outside the array load a clamped column and store nothing
     const bool own = valid && lane > 0;
+    const int ix = min(max(ixr, 0), nx - 1);
     const bool hasL = ix > 0;
     const long N = (long)nx * ny;
     const int nn = 2 * nx + 1;
-    const double ihx = 1. / hx, ihy = 1. / hy, area = hx * hy;
-    const double il_v = 1. / (area * (4. * LUMP[0])), il_ex = 1. / (area * (2. * LUMP[1]));
-    const double il_ey = 1. / (area * (2. * LUMP[3])), il_c = 1. / (area * LUMP[4]);
+    const double ihx = 1. / hx, ihy = 1. / hy, iarea = ihx * ihy;
 
     // contributions of the row below to its top-row nodes: b6 (top-left), b7 (top-mid) of my column and
     // bl8 = top-right of the column to my left
@@ -64,42 +64,24 @@ __global__ __launch_bounds__(256) void mevp_fused_kernel(nsdg_mevp_params P, int
 
     for (int iy = (y0 > k0 ? y0 - 1 : y0); iy < y1; ++iy) {
         const bool prologue = iy < y0; // recomputed row owned by the strip below: nothing is stored
-        const long e = (long)iy * nx + (valid ? ix : 0);
-        const long nV = (long)(2 * iy) * nn + 2 * (valid ? ix : 0);
+        const long e = (long)iy * nx + ix;
+        const long nV = (long)(2 * iy) * nn + 2 * ix;
         double ul[9], vl[9], Pq[9], s11[8], s12[8], s22[8];
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
             const long n = nV + (a / 3) * nn + a % 3;
-            ul[a] = valid ? in.u_old[n] : 0.;
-            vl[a] = valid ? in.v_old[n] : 0.;
+            ul[a] = u_old[n];
+            vl[a] = v_old[n];
         }
 #pragma unroll
         for (int q = 0; q < 9; ++q)
-            Pq[q] = valid ? pg[q * N + e] : 0.;
+            Pq[q] = pg[q * N + e];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            s11[i] = valid ? S.i11[i * N + e] : 0.;
-            s12[i] = valid ? S.i12[i * N + e] : 0.;
-            s22[i] = valid ? S.i22[i * N + e] : 0.;
+            s11[i] = S.i11[i * N + e];
+            s12[i] = S.i12[i * N + e];
+            s22[i] = S.i22[i * N + e];
         }
-        const bool do_nodes = !prologue && iy >= j0;
-        // nodal coefficients of the 4 owned nodes (V, EX, EY, C), issued with the other loads
-        double nu0[4], nv0[4], ntx[4], nty[4], nuo[4], nvo[4], nh[4], na[4];
-        if (do_nodes) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long n = nV + (k >> 1) * nn + (k & 1);
-                nu0[k] = own ? in.u0[n] : 0.;
-                nv0[k] = own ? in.v0[n] : 0.;
-                ntx[k] = own ? in.tax[n] : 0.;
-                nty[k] = own ? in.tay[n] : 0.;
-                nuo[k] = own ? in.uo[n] : 0.;
-                nvo[k] = own ? in.vo[n] : 0.;
-                nh[k] = own ? in.cgh[n] : 1.;
-                na[k] = own ? in.cga[n] : 0.;
-            }
-        }
-
         stress_update(ul, vl, Pq, ihx, ihy, ialpha, dmin2, s11, s12, s22);
         if (!prologue && own) {
 #pragma unroll
@@ -115,36 +97,36 @@ __global__ __launch_bounds__(256) void mevp_fused_kernel(nsdg_mevp_params P, int
         const double l2x = shift_up(cx[2]), l2y = shift_up(cy[2]);
         const double l5x = shift_up(cx[5]), l5y = shift_up(cy[5]);
 
-        if (do_nodes) {
+        if (!prologue && iy >= j0) { // wave-uniform
             const bool hasB = iy > 0;
-            double un, vn;
+            double un, vn, c[6];
             // vertex: below-left + below + left + own (the oracle's summation order)
-            if (hasL && hasB)
-                node_update_vals(P, dt, ul[0], vl[0], nu0[0], nv0[0], ntx[0], nty[0], nuo[0], nvo[0], nh[0], na[0],
-                    ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], il_v, un, vn);
-            else
+            if (hasL && hasB) {
+                load_nodal(packed, nV, c);
+                node_update_packed(K, c, ul[0], vl[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea, un, vn);
+            } else
                 un = vn = 0.;
             if (own)
                 u_new[nV] = un, v_new[nV] = vn;
             // bottom edge-mid: below + own
-            if (hasB)
-                node_update_vals(P, dt, ul[1], vl[1], nu0[1], nv0[1], ntx[1], nty[1], nuo[1], nvo[1], nh[1], na[1], b7x + cx[1],
-                    b7y + cy[1], il_ex, un, vn);
-            else
+            if (hasB) {
+                load_nodal(packed, nV + 1, c);
+                node_update_packed(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, un, vn);
+            } else
                 un = vn = 0.;
             if (own)
                 u_new[nV + 1] = un, v_new[nV + 1] = vn;
             // left edge-mid: left + own
-            if (hasL)
-                node_update_vals(P, dt, ul[3], vl[3], nu0[2], nv0[2], ntx[2], nty[2], nuo[2], nvo[2], nh[2], na[2], l5x + cx[3],
-                    l5y + cy[3], il_ey, un, vn);
-            else
+            if (hasL) {
+                load_nodal(packed, nV + nn, c);
+                node_update_packed(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, un, vn);
+            } else
                 un = vn = 0.;
             if (own)
                 u_new[nV + nn] = un, v_new[nV + nn] = vn;
             // centre: own
-            node_update_vals(P, dt, ul[4], vl[4], nu0[3], nv0[3], ntx[3], nty[3], nuo[3], nvo[3], nh[3], na[3], cx[4], cy[4], il_c,
-                un, vn);
+            load_nodal(packed, nV + nn + 1, c);
+            node_update_packed(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, un, vn);
             if (own) {
                 u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
                 // right column / top row of the local lattice are boundary nodes (v = 0)
@@ -170,20 +152,26 @@ __global__ __launch_bounds__(256) void mevp_fused_kernel(nsdg_mevp_params P, int
 
 using namespace nsdg_mevp_detail;
 
-int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, double dt, const double* s11i, const double* s12i,
-    const double* s22i, double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new,
-    double* v_new, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
-    const double* vo, const double* cgh, const double* cga, const double* pg)
+int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, const double* s11i, const double* s12i, const double* s22i,
+    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
+    const double* packed, const double* pg)
 {
     const int R = ctx->strip_rows;
     const int ncw = nsdg_div_up(ctx->nx, 63); // 63 owned columns per wave
     const int nstrips = nsdg_div_up(j1 - k0, R);
     const long nwaves = (long)ncw * nstrips;
     const StressPtrs S = { s11i, s12i, s22i, s11, s12, s22 };
-    const NodeIn in = { u_old, v_old, u0, v0, tax, tay, uo, vo, cgh, cga };
-    hipLaunchKernelGGL(mevp_fused_kernel, dim3(nsdg_div_up(nwaves, 4)), dim3(256), 0, ctx->stream, ctx->mevp, ctx->nx, ctx->ny, k0,
-        j0, j1, R, ncw, ctx->hx, ctx->hy, dt, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, in, pg, u_new,
-        v_new);
+    const nsdg_mevp_params& P = ctx->mevp;
+    const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
+    // two register budgets of the same kernel: 1 wave/SIMD (no spills) or 2 waves/SIMD (a few scratch spills)
+    if (ctx->fused_min_waves >= 2)
+        hipLaunchKernelGGL(mevp_fused_kernel<2>, dim3(nsdg_div_up(nwaves, 4)), dim3(256), 0, ctx->stream, K, ctx->nx, ctx->ny, k0, j0, j1,
+            R, ncw, ctx->hx, ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg,
+            u_new, v_new);
+    else
+        hipLaunchKernelGGL(mevp_fused_kernel<1>, dim3(nsdg_div_up(nwaves, 4)), dim3(256), 0, ctx->stream, K, ctx->nx, ctx->ny, k0, j0, j1,
+            R, ncw, ctx->hx, ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg,
+            u_new, v_new);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }

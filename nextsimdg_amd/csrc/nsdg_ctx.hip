@@ -77,7 +77,9 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     c->nx = c->ny = 0;
     c->hx = c->hy = 0.;
     c->mevp_variant = 1;
-    c->strip_rows = 8;
+    c->strip_rows = 6;
+    c->fused_min_waves = 1;
+    c->pack_dt = 0.;
     c->d_ptrs = nullptr;
     *out = c;
     return NSDG_OK;
@@ -133,6 +135,14 @@ int nsdg_mevp_strip_rows_set(nsdg_ctx* ctx, int32_t rows)
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
     NSDG_CHECK_ARG(rows >= 1 && rows <= 4096, "rows per strip must be in 1..4096");
     ctx->strip_rows = rows;
+    return NSDG_OK;
+}
+
+int nsdg_mevp_occupancy_set(nsdg_ctx* ctx, int32_t waves_per_simd)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(waves_per_simd == 1 || waves_per_simd == 2, "waves per SIMD must be 1 or 2");
+    ctx->fused_min_waves = waves_per_simd;
     return NSDG_OK;
 }
 

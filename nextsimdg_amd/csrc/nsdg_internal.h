@@ -16,6 +16,8 @@ struct nsdg_ctx {
     double hx, hy;
     int mevp_variant;
     int strip_rows; // rows per strip of the fused marching kernel
+    double pack_dt; // time step the packed nodal coefficients were built for (0 = never packed)
+    int fused_min_waves; // register budget of the fused kernel: 1 or 2 waves per SIMD
     // device scratch for small host->device tables (field pointer lists of the transport stage)
     double** d_ptrs;
 };

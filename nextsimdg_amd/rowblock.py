@@ -54,6 +54,7 @@ class RowBlock:
 class HaloExchanger:
     def __init__(self, blk, group=None):
         self.blk, self.group = blk, group
+        self._nodal_ops = {}
 
     def _run(self, ops):
         if not ops:
@@ -61,11 +62,8 @@ class HaloExchanger:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
-    def nodal(self, fields):
-        """refresh the ghost node rows of CG2 arrays [2ny+1, 2nx+1] (after a velocity update)"""
+    def _build_nodal_ops(self, fields):
         b = self.blk
-        if b.world == 1:
-            return
         ops = []
         for f in fields:
             if b.above is not None:
@@ -75,7 +73,27 @@ class HaloExchanger:
             if b.below is not None:
                 ops.append(dist.P2POp(dist.isend, f[2 * b.j0:2 * b.j0 + 1], b.below, self.group))
                 ops.append(dist.P2POp(dist.irecv, f[0:2], b.below, self.group))
-        self._run(ops)
+        return ops
+
+    def nodal_start(self, fields):
+        """post the ghost-node-row exchange of CG2 arrays [2ny+1, 2nx+1]; returns the requests.
+        The P2P op lists are cached per set of arrays (the sub-cycle ping-pongs between two sets)."""
+        if self.blk.world == 1:
+            return []
+        key = tuple(f.data_ptr() for f in fields)
+        ops = self._nodal_ops.get(key)
+        if ops is None:
+            ops = self._nodal_ops[key] = self._build_nodal_ops(fields)
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    @staticmethod
+    def finish(reqs):
+        for req in reqs:
+            req.wait()
+
+    def nodal(self, fields):
+        """refresh the ghost node rows of CG2 arrays (after a velocity update), blocking form"""
+        self.finish(self.nodal_start(fields))
 
     def element(self, fields):
         """refresh the ghost element rows of DG arrays [nc, ny, nx] (after a transport stage)"""
@@ -110,8 +128,9 @@ class DynamicsCore:
 
     ORDER = 2
 
-    def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None):
+    def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None, overlap=True):
         self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
+        self.overlap = overlap
         self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
         nx, ny = blk.nx, blk.ny
         z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
@@ -124,6 +143,7 @@ class DynamicsCore:
         self.u0, self.v0 = z(*nodal), z(*nodal)
         self.ua, self.va, self.tax, self.tay = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
         self.uo, self.vo, self.cgh, self.cga = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
+        self.packed = z(nodal[0] * nodal[1] * 8)  # per-step momentum coefficients, 8 per node
         self.adv = (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
         self.t1 = [z(6, ny, nx), z(6, ny, nx)]
         self.t2 = [z(6, ny, nx), z(6, ny, nx)]
@@ -153,10 +173,28 @@ class DynamicsCore:
         ops.wind_stress(self.ua, self.va, self.tax, self.tay)
         self.u0.copy_(self.u)
         self.v0.copy_(self.v)
+        ops.mevp_pack_nodal(self.dt, (self.u0, self.v0), (self.tax, self.tay), (self.uo, self.vo), self.cgh, self.cga,
+                            self.packed)
+        split = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 4
         for _ in range(self.nsub):
-            ops.mevp_iterate(b.k0, b.j0, b.j1, self.dt, self.s, self.sb, (self.u, self.v), (self.ub, self.vb),
-                             (self.u0, self.v0), (self.tax, self.tay), (self.uo, self.vo), self.cgh, self.cga, self.pg)
-            self.halo.nodal((self.ub, self.vb))
+            uv, uvn = (self.u, self.v), (self.ub, self.vb)
+            if not split:
+                ops.mevp_iterate(b.k0, b.j0, b.j1, self.s, self.sb, uv, uvn, self.packed, self.pg)
+                self.halo.nodal(uvn)
+            else:
+                # boundary rows first, so that their node rows travel while the interior is computed:
+                # the exchange is posted after the boundary launches and before the interior launch, the
+                # communication stream therefore waits only for the former
+                lo, hi = b.j0, b.j1
+                if b.above is not None:  # top owned element row -> the two node rows sent upwards
+                    ops.mevp_iterate(b.j1 - 2, b.j1 - 1, b.j1, self.s, self.sb, uv, uvn, self.packed, self.pg)
+                    hi = b.j1 - 1
+                if b.below is not None:  # bottom owned element row (+ redundant ghost-row stress) -> node row sent downwards
+                    ops.mevp_iterate(b.j0 - 1, b.j0, b.j0 + 1, self.s, self.sb, uv, uvn, self.packed, self.pg)
+                    lo = b.j0 + 1
+                reqs = self.halo.nodal_start(uvn)
+                ops.mevp_iterate(lo - 1 if lo > 0 else 0, lo, hi, self.s, self.sb, uv, uvn, self.packed, self.pg)
+                self.halo.finish(reqs)
             self.u, self.ub = self.ub, self.u
             self.v, self.vb = self.vb, self.v
             self.s, self.sb = self.sb, self.s

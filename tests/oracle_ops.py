@@ -30,14 +30,18 @@ class OracleOps:
         _np(tax)[:] = a
         _np(tay)[:] = b
 
-    def mevp_iterate(self, k0, j0, j1, dt, s_in, s_out, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, pg):
-        for a, b in zip(s_in, s_out):
-            _np(b)[:] = _np(a)
+    def mevp_pack_nodal(self, dt, u0v0, tau, ocean, cgh, cga, packed):
+        # the oracle has no packed layout: remember the per-step fields the coefficients are made from
+        self.nodal = (dt, [_np(x) for x in u0v0], [_np(x) for x in tau], [_np(x) for x in ocean], _np(cgh), _np(cga))
+
+    def mevp_iterate(self, k0, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        dt, u0v0, tau, ocean, cgh, cga = self.nodal
+        for a, b in zip(s_in, s_out):  # the oracle's stress update is in place: seed the output rows
+            _np(b)[:, k0:j1] = _np(a)[:, k0:j1]
         so = [_np(x) for x in s_out]
         O.mevp_stress(self.nx, self.ny, k0, j1, self.hx, self.hy, self.p, _np(uv_old[0]), _np(uv_old[1]), _np(pg), *so)
         O.mevp_velocity(self.nx, self.ny, j0, j1, self.hx, self.hy, dt, self.p, so, [_np(x) for x in uv_old],
-                        [_np(x) for x in uv_new], [_np(x) for x in u0v0], [_np(x) for x in tau],
-                        [_np(x) for x in ocean], _np(cgh), _np(cga))
+                        [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga)
 
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):
         res = O.prepare_advection(self.nx, self.ny, order, _np(u), _np(v))

@@ -217,6 +217,12 @@ def test_mevp_helpers_match_oracle(ctx):
     assert_close(host(tay_d), tay_o, 1e-13, 1e-16, "tay")
 
 
+def pack(ctx, dt, u0, v0, tax, tay, uo, vo, cgh, cga):
+    packed = torch.zeros(8 * u0.size, dtype=torch.float64, device="cuda")
+    ctx.mevp_pack_nodal(dt, (dev(u0), dev(v0)), (dev(tax), dev(tay)), (dev(uo), dev(vo)), dev(cgh), dev(cga), packed)
+    return packed
+
+
 def mevp_state(b, rng):
     nx, ny = b.nx, b.ny
     shape = (2 * ny + 1, 2 * nx + 1)
@@ -243,9 +249,9 @@ def test_mevp_single_iteration_matches_oracle(ctx, variant):
     ds = [dev(x) for x in s]
     du, dv = dev(u), dev(v)
     dun, dvn = torch.full_like(du, 3.0), torch.full_like(dv, 3.0)
-    args_d = [(dev(u0), dev(v0)), (dev(tax), dev(tay)), (dev(b.uo), dev(b.vo)), dev(cgh), dev(cga)]
+    packed = pack(ctx, 120.0, u0, v0, tax, tay, b.uo, b.vo, cgh, cga)
     dso = [torch.zeros_like(x) for x in ds]
-    ctx.mevp_iterate(0, 0, ny, 120.0, ds, dso, (du, dv), (dun, dvn), *args_d, dev(pg))
+    ctx.mevp_iterate(0, 0, ny, ds, dso, (du, dv), (dun, dvn), packed, dev(pg))
     ds = dso
     # oracle
     O.mevp_stress(nx, ny, 0, ny, b.bt.hx, b.bt.hy, b.po, u, v, pg, *s)
@@ -272,7 +278,7 @@ def test_mevp_subcycle_matches_oracle(ctx, variant):
     u0, v0 = u.copy(), v.copy()
     s = [np.zeros((8, ny, nx)) for _ in range(3)]
     du, dv, ds = dev(u), dev(v), [dev(x) for x in s]
-    scratch = torch.zeros(2 * u.size + 3 * s[0].size, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(10 * u.size + 3 * s[0].size, dtype=torch.float64, device="cuda")
     nsub = 25  # odd: exercises the copy-back of the ping-pong buffers
     ctx.mevp_subcycle(120.0, nsub, ds, du, dv, dev(u0), dev(v0), dev(tax), dev(tay), dev(b.uo), dev(b.vo), dev(cgh),
                       dev(cga), dev(pg), scratch)
@@ -302,8 +308,8 @@ def test_mevp_row_block_equals_full_domain_bitwise(ctx):
         tax, tay = O.wind_stress(b.po, b.ua, b.va)
         full = [torch.zeros_like(dev(x)) for x in s]
         un, vn = torch.zeros_like(dev(u)), torch.zeros_like(dev(v))
-        nodal = [(dev(0.5 * u), dev(0.5 * v)), (dev(tax), dev(tay)), (dev(b.uo), dev(b.vo)), dev(cgh), dev(cga)]
-        ctx.mevp_iterate(0, 0, ny, 120.0, [dev(x) for x in s], full, (dev(u), dev(v)), (un, vn), *nodal, dev(pg))
+        packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
+        ctx.mevp_iterate(0, 0, ny, [dev(x) for x in s], full, (dev(u), dev(v)), (un, vn), packed, dev(pg))
         # upper rank: owns element rows [12, 24); local array = rows [11, 24) (ghost row below)
         r0 = 12
         lo = r0 - 1
@@ -312,9 +318,8 @@ def test_mevp_row_block_equals_full_domain_bitwise(ctx):
         ctx.set_grid(nx, ny - lo, b.bt.hx, b.bt.hy)
         part = [torch.zeros_like(dev(sl_e(x))) for x in s]
         pun, pvn = torch.zeros_like(dev(sl_n(u))), torch.zeros_like(dev(sl_n(v)))
-        pnodal = [(dev(sl_n(0.5 * u)), dev(sl_n(0.5 * v))), (dev(sl_n(tax)), dev(sl_n(tay))),
-                  (dev(sl_n(b.uo)), dev(sl_n(b.vo))), dev(sl_n(cgh)), dev(sl_n(cga))]
-        ctx.mevp_iterate(0, 1, ny - lo, 120.0, [dev(sl_e(x)) for x in s], part, (dev(sl_n(u)), dev(sl_n(v))), (pun, pvn), *pnodal,
+        ppacked = pack(ctx, 120.0, *[sl_n(x) for x in (0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)])
+        ctx.mevp_iterate(0, 1, ny - lo, [dev(sl_e(x)) for x in s], part, (dev(sl_n(u)), dev(sl_n(v))), (pun, pvn), ppacked,
                          dev(sl_e(pg)))
         for f, p in zip(full, part):
             assert torch.equal(f[:, lo:], p)
@@ -333,14 +338,14 @@ def test_mevp_fused_strip_size_does_not_change_results(ctx):
     pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
     cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
     tax, tay = O.wind_stress(b.po, b.ua, b.va)
-    nodal = [(dev(0.5 * u), dev(0.5 * v)), (dev(tax), dev(tay)), (dev(b.uo), dev(b.vo)), dev(cgh), dev(cga)]
+    packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
     results = []
     for variant, rows in ((0, 16), (1, 1), (1, 7), (1, 16), (1, 64)):
         ctx.set_mevp_variant(variant)
         ctx.set_mevp_strip_rows(rows)
         so = [torch.zeros_like(dev(x)) for x in s]
         un, vn = torch.full_like(dev(u), 9.0), torch.full_like(dev(v), 9.0)
-        ctx.mevp_iterate(0, 0, ny, 120.0, [dev(x) for x in s], so, (dev(u), dev(v)), (un, vn), *nodal, dev(pg))
+        ctx.mevp_iterate(0, 0, ny, [dev(x) for x in s], so, (dev(u), dev(v)), (un, vn), packed, dev(pg))
         results.append(so + [un, vn])
     for r in results[2:]:
         for a, c in zip(results[1], r):
@@ -348,4 +353,26 @@ def test_mevp_fused_strip_size_does_not_change_results(ctx):
     for a, c in zip(results[0], results[1]):
         assert_close(host(c), host(a), 1e-12, 1e-13 * float(a.abs().max()), "fused vs two-kernel")
     ctx.set_mevp_variant(1)
-    ctx.set_mevp_strip_rows(8)
+    ctx.set_mevp_strip_rows(4)
+
+
+def test_mevp_split_sub_iteration_equals_single_launch_bitwise(ctx):
+    """the multi-rank driver computes the boundary rows first (so that their node rows can travel while the
+    interior is computed): three launches over row ranges must reproduce the single launch bit for bit"""
+    b = Box(ctx, 70, 24)
+    nx, ny = b.nx, b.ny
+    rng = np.random.default_rng(31)
+    u, v, s = mevp_state(b, rng)
+    pg = dev(O.ice_strength(nx, ny, b.po, b.H, b.A))
+    cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+    tax, tay = O.wind_stress(b.po, b.ua, b.va)
+    packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
+    s_in = [dev(x) for x in s]
+    one = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+    ctx.mevp_iterate(0, 0, ny, s_in, one[:3], (dev(u), dev(v)), (one[3], one[4]), packed, pg)
+    three = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+    ctx.mevp_iterate(ny - 2, ny - 1, ny, s_in, three[:3], (dev(u), dev(v)), (three[3], three[4]), packed, pg)
+    ctx.mevp_iterate(0, 0, 1, s_in, three[:3], (dev(u), dev(v)), (three[3], three[4]), packed, pg)
+    ctx.mevp_iterate(0, 1, ny - 1, s_in, three[:3], (dev(u), dev(v)), (three[3], three[4]), packed, pg)
+    for a, c in zip(one, three):
+        assert torch.equal(a, c)

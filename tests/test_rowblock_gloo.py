@@ -20,7 +20,7 @@ for p in (ROOT, HERE):
 
 from nextsimdg_amd import rowblock, synthetic  # noqa: E402
 
-NX, NY, NSUB, NSTEPS = 20, 23, 5, 2
+NX, NY, NSUB, NSTEPS = 20, 29, 5, 2
 
 
 def free_port():
@@ -31,7 +31,7 @@ def free_port():
     return p
 
 
-def run_core(rank, world):
+def run_core(rank, world, overlap=True):
     from oracle_ops import OracleOps
 
     bt = synthetic.BoxTest(NX, NY)
@@ -42,19 +42,20 @@ def run_core(rank, world):
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
     blk = rowblock.RowBlock(NX, NY, rank, world)
-    core = rowblock.DynamicsCore(OracleOps(alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"))
+    core = rowblock.DynamicsCore(OracleOps(alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"),
+                                 overlap=overlap)
     core.load_global(H, A, uo, vo, 3.0 * ua, 3.0 * va)
     for _ in range(NSTEPS):
         core.step()
     return core
 
 
-def worker(rank, world, port, outdir):
+def worker(rank, world, port, outdir, overlap=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        core = run_core(rank, world)
+        core = run_core(rank, world, overlap)
         out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
         out["s11"] = core.owned(core.s[0]).clone()
         torch.save(out, os.path.join(outdir, "rank%d.pt" % rank))
@@ -78,12 +79,14 @@ def test_rowblock_index_bookkeeping():
         rowblock.RowBlock(4, 2, 0, 3)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_block_run_equals_single_domain_bitwise(world, tmp_path):
+@pytest.mark.parametrize("world,overlap", [(2, True), (3, True), (3, False)])
+def test_row_block_run_equals_single_domain_bitwise(world, overlap, tmp_path):
+    """overlap=True: boundary rows are computed and sent first, the interior follows (3 launches per
+    sub-iteration); overlap=False: one launch then a blocking exchange.  Both must equal the 1-rank run."""
     ref = run_core(0, 1)
     assert float(ref.u.abs().max()) > 1e-5
     port = free_port()
-    mp.spawn(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
     for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
         got = torch.cat([p[key] for p in parts], dim=1)
