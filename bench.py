@@ -86,8 +86,66 @@ def cpu_baseline(nsub_full, budget_s=12.0):
     return res
 
 
+def measured_traffic(nx, ny):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/): bench.py
+    cannot run rocprofv3 on itself, so the figure is the one measured with the same command under the
+    profiler (FETCH_SIZE doubled as the gfx950 correction requires, WRITE_SIZE as is)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
+        if d.get("nx") == nx and d.get("ny") == ny:
+            return d["kernels"]["mevp_fused_kernel"]["total_bytes"]
+    except Exception:
+        pass
+    return None
+
+
+def column_bench(args, device):
+    """Secondary workload: the reference's column-physics step (the only per-element path the snapshot
+    contains) on nx*ny seeded elements; 160 B / element-step algorithmic traffic."""
+    n = args.nx * args.ny
+    ctx = abi.Context(device)
+    state, forcing, newice = synthetic.column_fields(n)
+    put = lambda a: torch.from_numpy(a).to(device)
+    ds, df, dn = {k: put(v) for k, v in state.items()}, {k: put(v) for k, v in forcing.items()}, put(newice)
+    for _ in range(max(args.warmup, 1)):
+        ctx.column_step(600.0, ds, df, dn)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(ctx.stream)
+    for _ in range(args.steps):
+        ctx.column_step(600.0, ds, df, dn)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    m = 1 << 20
+    st, fo, ni = synthetic.column_fields(m)
+    O.column_step(O.column_params(), 600.0, st, fo, ni)
+    c0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - c0 < 10.0:
+        O.column_step(O.column_params(), 600.0, st, fo, ni)
+        reps += 1
+    cpu = reps * m / (time.perf_counter() - c0)
+    achieved = n * 160 / (ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "element-steps/sec (column physics)", "value": n * args.steps / elapsed, "unit": "element-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "column-physics step (DevStep::iterate equivalent) on %d seeded elements, dt=600 s, default modules" % n},
+        "roofline": {"bound": "hbm", "kernel": "column_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": n * 160, "avg_launch_ms": ms},
+        "cpu_baseline": {"value": cpu, "unit": "element-steps/s", "cores": 1, "kind": "port",
+                         "sample": "oracle/column_oracle.c, %d steps of 2^20 seeded elements, single thread" % reps}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["dynamics", "column"], default="dynamics")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -121,6 +179,11 @@ def main():
         build.build_lib(verbose=False)
     if world > 1:
         dist.barrier()
+
+    if args.workload == "column":
+        if world != 1:
+            raise SystemExit("the column workload is a single-GPU measurement")
+        return column_bench(args, device)
 
     nx, ny, nsub = args.nx, args.ny, args.nsub
     L = 512e3
@@ -186,7 +249,7 @@ def main():
                        "decomposition": "%d row block(s), ghost-row send/recv" % world,
                        "mevp_variant": args.variant if args.variant is not None else "default"},
             "roofline": {"bound": "hbm", "kernel": "mEVP sub-iteration", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(nx, ny) if world == 1 else None,
                          "algorithmic_bytes_per_launch": own_elems * BYTES_PER_ELEM_SUBITER,
                          "avg_launch_ms": sub_ms},
             "mevp_element_subiters_per_s": own_elems / (sub_ms * 1e-3),
