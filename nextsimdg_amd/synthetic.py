@@ -35,6 +35,17 @@ class BoxTest:
         self.nx, self.ny, self.L = nx, ny, L
         self.hx, self.hy = L / nx, L / ny
 
+    def stable_alpha(self, dt, pstar=27.5e3, delta_min=2e-9, rho_ice=900.0, h_ice=0.3, safety=1.2, floor=1500.0):
+        """alpha = beta for which the mEVP pseudo-time iteration is linearly stable on this mesh:
+        alpha*beta >= pi^2 * zeta_max * dt / (m * h^2), zeta_max = P*H/(2 Delta_min), m = rho_i H.
+        (Measured on the MI355X, round 1: with alpha = beta = 1500 round-off differences between two
+        kernel variants grow x150 per sub-iteration at h = 250 m; the bound -- 1.2e4 there -- is sharp:
+        12000 is stable, 6000 is not.  The flop and byte counts do not depend on alpha.)"""
+        h = min(self.hx, self.hy)
+        zeta_max = pstar * h_ice / (2.0 * delta_min)
+        bound = np.sqrt(np.pi ** 2 * zeta_max * dt / (rho_ice * h_ice * h * h))
+        return float(max(floor, safety * bound))
+
     def H0(self, x, y):
         return 0.3 + 0.005 * (np.sin(6e-5 * x) + np.sin(3e-5 * y))
 
