@@ -32,6 +32,7 @@ def needs_build():
 
 
 def build_lib(force=False, verbose=True, extra_flags=()):
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("NSDG_EXTRA_FLAGS", "").split())
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)

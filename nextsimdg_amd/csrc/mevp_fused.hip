@@ -24,6 +24,16 @@
 // wave is independent and runs to completion.
 #include "mevp_common.h"
 
+// streamed-once data (stress in/out, Gauss-point strength): non-temporal policy keeps the velocity rows,
+// which ARE re-read by the next row of the march, in cache
+#ifdef NSDG_FUSED_NT
+#define NSDG_LD(p) __builtin_nontemporal_load(p)
+#define NSDG_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define NSDG_LD(p) (*(p))
+#define NSDG_ST(v, p) (*(p) = (v))
+#endif
+
 namespace nsdg_mevp_detail {
 
 struct StressPtrs {
@@ -75,20 +85,20 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
         }
 #pragma unroll
         for (int q = 0; q < 9; ++q)
-            Pq[q] = pg[q * N + e];
+            Pq[q] = NSDG_LD(&pg[q * N + e]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            s11[i] = S.i11[i * N + e];
-            s12[i] = S.i12[i * N + e];
-            s22[i] = S.i22[i * N + e];
+            s11[i] = NSDG_LD(&S.i11[i * N + e]);
+            s12[i] = NSDG_LD(&S.i12[i * N + e]);
+            s22[i] = NSDG_LD(&S.i22[i * N + e]);
         }
         stress_update(ul, vl, Pq, ihx, ihy, ialpha, dmin2, s11, s12, s22);
         if (!prologue && own) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                S.o11[i * N + e] = s11[i];
-                S.o12[i * N + e] = s12[i];
-                S.o22[i * N + e] = s22[i];
+                NSDG_ST(s11[i], &S.o11[i * N + e]);
+                NSDG_ST(s12[i], &S.o12[i * N + e]);
+                NSDG_ST(s22[i], &S.o22[i * N + e]);
             }
         }
         double cx[9], cy[9];

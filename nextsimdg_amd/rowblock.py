@@ -226,3 +226,42 @@ class DynamicsCore:
             return f[:, b.j0:b.j1]
         top = 2 * b.j1 + (1 if b.above is None else 0)
         return f[2 * b.j0:top]
+
+
+class CoupledCore(DynamicsCore):
+    """BASELINE config 5: dynamics + column thermodynamics.  Each model step first advances the column
+    physics of every owned element (the reference's DevStep::iterate, core/src/DevStep.cpp:14-23) and then
+    the dynamics.  The coupling is zero-copy: the cell means of the DG fields ARE the column model's
+    prognostic variables -- plane 0 of H is `hice`, plane 0 of A is `cice` -- so the column kernel reads
+    and writes those planes in place; higher DG coefficients are left as they are (a thermodynamic
+    source changes the mean, not the sub-cell shape).  The column step needs no exchange (elements are
+    independent); it runs on the ghost rows too, redundantly, so that they stay consistent without a
+    message."""
+
+    COLUMN_STATE = ("hsnow", "tice0")
+    COLUMN_FORCING = ("sst", "sss", "tair", "tdew", "slp", "qsw", "qlw", "mld", "snowfall", "wind")
+
+    def __init__(self, ops, blk, hx, hy, dt, nsub, device, **kw):
+        super().__init__(ops, blk, hx, hy, dt, nsub, device, **kw)
+        z = lambda: torch.zeros(blk.ny, blk.nx, dtype=torch.float64, device=device)
+        self.col = {k: z() for k in self.COLUMN_STATE + self.COLUMN_FORCING}
+        self.newice = z()
+
+    def load_column(self, fields):
+        """fields: dict name -> global [ny, nx] numpy array for hsnow, tice0 and the 10 forcing fields"""
+        import numpy as np
+
+        es = self.blk.elem_slice()
+        for k, dst in self.col.items():
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(fields[k][es])).to(dst.device))
+
+    def thermodynamics(self):
+        state = {"hice": self.H[0], "cice": self.A[0], "hsnow": self.col["hsnow"], "tice0": self.col["tice0"]}
+        forcing = {k: self.col[k] for k in self.COLUMN_FORCING}
+        self.ops.column_step(self.dt, state, forcing, self.newice)
+
+    def step(self):
+        self._set_grid()
+        self.thermodynamics()
+        self.momentum()
+        self.transport()

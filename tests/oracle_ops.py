@@ -14,6 +14,13 @@ def _np(t):
 class OracleOps:
     def __init__(self, **mevp):
         self.p = O.mevp_params(**mevp)
+        self.cp = O.column_params()
+
+    def column_step(self, dt, state, forcing, newice, diag=None):
+        # plane views ([ny, nx] slices of the DG arrays) are contiguous: flatten without copying
+        st = {k: _np(v).reshape(-1) for k, v in state.items()}
+        fo = {k: _np(v).reshape(-1) for k, v in forcing.items()}
+        O.column_step(self.cp, dt, st, fo, _np(newice).reshape(-1))
 
     def set_grid(self, nx, ny, hx, hy):
         self.nx, self.ny, self.hx, self.hy = nx, ny, hx, hy

@@ -31,7 +31,14 @@ def free_port():
     return p
 
 
-def run_core(rank, world, overlap=True):
+def column_fields_2d(seed=5):
+    state, forcing, _ = synthetic.column_fields(NX * NY, seed)
+    f = {k: v.reshape(NY, NX) for k, v in {**state, **forcing}.items()}
+    f["wind"] = 0.2 * f["wind"]
+    return f
+
+
+def run_core(rank, world, overlap=True, coupled=False):
     from oracle_ops import OracleOps
 
     bt = synthetic.BoxTest(NX, NY)
@@ -42,22 +49,27 @@ def run_core(rank, world, overlap=True):
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
     blk = rowblock.RowBlock(NX, NY, rank, world)
-    core = rowblock.DynamicsCore(OracleOps(alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"),
-                                 overlap=overlap)
+    cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
+    core = cls(OracleOps(alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"), overlap=overlap)
     core.load_global(H, A, uo, vo, 3.0 * ua, 3.0 * va)
+    if coupled:
+        core.load_column(column_fields_2d())
     for _ in range(NSTEPS):
         core.step()
     return core
 
 
-def worker(rank, world, port, outdir, overlap=True):
+def worker(rank, world, port, outdir, overlap=True, coupled=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        core = run_core(rank, world, overlap)
+        core = run_core(rank, world, overlap, coupled)
         out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
         out["s11"] = core.owned(core.s[0]).clone()
+        if coupled:
+            b = core.blk
+            out["tice0"] = core.col["tice0"][b.j0:b.j1].clone()
         torch.save(out, os.path.join(outdir, "rank%d.pt" % rank))
         dist.barrier()
     finally:
@@ -95,3 +107,16 @@ def test_row_block_run_equals_single_domain_bitwise(world, overlap, tmp_path):
         got = torch.cat([p[key] for p in parts], dim=0)
         assert got.shape == full.shape
         assert torch.equal(got, full), key
+
+
+def test_coupled_thermodynamics_dynamics_row_blocks(tmp_path):
+    """BASELINE config 5 in miniature: column physics + dynamics per step, 2 ranks == 1 rank bitwise"""
+    ref = run_core(0, 1, coupled=True)
+    assert float((ref.A[0] - 1.0).abs().max()) > 1e-3  # the thermodynamics changed the concentration
+    port = free_port()
+    mp.spawn(worker, args=(2, port, str(tmp_path), True, True), nprocs=2, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2)]
+    for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
+        assert torch.equal(torch.cat([p[key] for p in parts], dim=1), full), key
+    assert torch.equal(torch.cat([p["u"] for p in parts], dim=0), ref.u)
+    assert torch.equal(torch.cat([p["tice0"] for p in parts], dim=0), ref.col["tice0"])
