@@ -32,7 +32,7 @@ public:
     //! Copies the prognostic fields (and newice) back into the structure's host planes.
     void syncToHost();
     //! Number of kernel launches issued so far (one per iterate()).
-    long launches() const { return m_launches; }
+    long launches() const override { return m_launches; }
 
 private:
     void upload();

@@ -16,6 +16,8 @@ public:
     void setInitFile(const std::string& filePath) { initialRestartFilePath = filePath; }
     virtual void writeRestartFile(const std::string& filePath) = 0;
     virtual void setInitialData(IStructure& dataStructure) = 0;
+    //! Number of model steps executed on the device so far (new; for reports and tests).
+    virtual long launches() const { return 0; }
 
 protected:
     std::string initialRestartFilePath;

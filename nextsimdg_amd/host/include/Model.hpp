@@ -19,13 +19,15 @@ public:
     void run();
     void writeRestartFile();
     IStructure& structure() { return *dataStructure; }
-    HipStep& step() { return modelStep; }
+    IModelStep& step() { return *modelStep; }
 
     enum { RESTARTFILE_KEY, STARTTIME_KEY, STOPTIME_KEY, RUNLENGTH_KEY, TIMESTEP_KEY, STRUCTURE_KEY, FINALFILE_KEY };
 
 private:
     Iterator iterator;
-    HipStep modelStep; // "Change the model step calculation here" (core/src/include/Model.hpp:47)
+    // "Change the model step calculation here" (core/src/include/Model.hpp:47): here the step is itself a
+    // plugin, [Modules] Nextsim::IModelStep = Nextsim::HipStep (default) | Nextsim::DynamicsStep
+    std::unique_ptr<IModelStep> modelStep;
     std::shared_ptr<IStructure> dataStructure;
     std::string initialFileName, finalFileName;
 };

@@ -118,3 +118,8 @@ void HipStep::writeRestartFile(const std::string& filePath)
 }
 
 } // namespace Nextsim
+
+namespace Nextsim {
+// the model step is a plugin too; HipStep first = default
+NSDG_REGISTER_MODULE(IModelStep, HipStep, "Nextsim::IModelStep", "Nextsim::HipStep");
+}

@@ -18,8 +18,9 @@ const std::map<int, std::string> Configured<Model>::keyMap = {
 };
 
 Model::Model()
+    : modelStep(ModuleLoader::getLoader().getInstance<IModelStep>())
 {
-    iterator.setIterant(&modelStep);
+    iterator.setIterant(modelStep.get());
     finalFileName = "restart.nsdg";
 }
 
@@ -43,7 +44,7 @@ void Model::configure()
 
     initialFileName = getConfiguration(keyMap.at(RESTARTFILE_KEY), std::string(""));
     finalFileName = getConfiguration(keyMap.at(FINALFILE_KEY), finalFileName);
-    modelStep.setInitFile(initialFileName);
+    modelStep->setInitFile(initialFileName);
     const std::string type = RectGrid::typeInFile(initialFileName);
     if (!type.empty()) {
         dataStructure = StructureFactory::generateFromFile(initialFileName);
@@ -52,8 +53,8 @@ void Model::configure()
         dataStructure = StructureFactory::generate(getConfiguration(keyMap.at(STRUCTURE_KEY), std::string("devgrid")));
         dataStructure->init("");
     }
-    modelStep.setInitialData(*dataStructure);
-    modelStep.init();
+    modelStep->setInitialData(*dataStructure);
+    modelStep->init();
     DummyExternalData::setAll(*dataStructure); // core/src/Model.cpp:76
 }
 
@@ -61,7 +62,7 @@ void Model::run() { iterator.run(); }
 
 void Model::writeRestartFile()
 {
-    modelStep.writeRestartFile(finalFileName);
+    modelStep->writeRestartFile(finalFileName);
     std::cout << "Restart file written to " << finalFileName << std::endl;
 }
 

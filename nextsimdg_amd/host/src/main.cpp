@@ -6,6 +6,7 @@
 #include "CommandLineParser.hpp"
 #include "ConfiguredModule.hpp"
 #include "Configurator.hpp"
+#include "DynamicsStep.hpp"
 #include "Model.hpp"
 #include "ModuleLoader.hpp"
 
@@ -29,6 +30,8 @@ int main(int argc, char* argv[])
         const FieldStore& f = model.structure().fields();
         std::printf("elements=%zu launches=%ld hice=%.17g cice=%.17g hsnow=%.17g tice0=%.17g sst=%.17g\n", f.n, model.step().launches(),
             f.hice[0], f.cice[0], f.hsnow[0], f.tice[0], f.sst[0]);
+        if (auto* dyn = dynamic_cast<DynamicsStep*>(&model.step()))
+            std::printf("dynamics umax=%.17g sumH=%.17g sumA=%.17g\n", dyn->maxSpeed(), dyn->sumH(), dyn->sumA());
     } catch (const std::exception& e) {
         std::cerr << "nextsim_amd: " << e.what() << std::endl;
         return 1;

@@ -13,6 +13,7 @@
 #include "CommandLineParser.hpp"
 #include "ConfiguredModule.hpp"
 #include "Configurator.hpp"
+#include "DynamicsStep.hpp"
 #include "Model.hpp"
 #include "ModuleLoader.hpp"
 #include "PhysicsModules.hpp"
@@ -368,7 +369,7 @@ static void test_model_dev1()
         model.configure();
         model.run();
         const FieldStore& f = model.structure().fields();
-        CHECK(f.n == 100 && model.step().launches() == 1);
+        CHECK(f.n == 100 && model.step().launches() == 1 && dynamic_cast<HipStep*>(&model.step()) != nullptr);
         for (std::size_t e = 0; e < f.n; ++e) {
             CHECK(approx(f.hice[e], 0.04668325240678619, 1e-12));
             CHECK(approx(f.cice[e], 0.36670813101696548, 1e-12));
@@ -383,6 +384,37 @@ static void test_model_dev1()
     CHECK(approx(again->fields().cice[99], 0.36670813101696548, 1e-12));
     std::remove("/tmp/nsdg_dev1_restart.nsdg");
     Configurator::clear();
+}
+
+static void test_dynamics_step()
+{ // the dynamics core as an IModelStep plugin: [Modules] Nextsim::IModelStep = Nextsim::DynamicsStep
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    addConfig("[Modules]\nNextsim::IModelStep = Nextsim::DynamicsStep\n[model]\nstructure = rectgrid\nstart = 0\nstop = 240\ntime_step = 120\n"
+              "final_file = /tmp/nsdg_dyn_restart.nsdg\n[rectgrid]\nnx = 40\nny = 56\n[init]\nhice = 0.3\ncice = 0.9\n[dynamics]\nnsub = 10\n");
+    ConfiguredModule::parseConfigurator();
+    {
+        Model model;
+        model.configure();
+        CHECK(dynamic_cast<DynamicsStep*>(&model.step()) != nullptr);
+        model.run();
+        DynamicsStep& dyn = dynamic_cast<DynamicsStep&>(model.step());
+        const FieldStore& f = model.structure().fields();
+        CHECK(dyn.launches() == 2 && f.n == 40 * 56);
+        CHECK(dyn.maxSpeed() > 1e-6 && dyn.maxSpeed() < 1.0);
+        CHECK(approx(dyn.sumH(), 0.3 * f.n, 1e-12)); // closed box: mass is conserved to round-off
+        CHECK(approx(dyn.sumA(), 0.9 * f.n, 1e-12));
+        double lo = 1e9, hi = -1e9;
+        for (double h : f.hice) {
+            lo = std::min(lo, h);
+            hi = std::max(hi, h);
+        }
+        CHECK(lo > 0.29 && hi < 0.31 && hi > lo); // advected, not blown up
+    }
+    CHECK(RectGrid::typeInFile("/tmp/nsdg_dyn_restart.nsdg") == "rectgrid");
+    std::remove("/tmp/nsdg_dyn_restart.nsdg");
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
 }
 
 int main(int argc, char** argv)
@@ -400,6 +432,7 @@ int main(int argc, char** argv)
         } else {
             test_hipstep_melting();
             test_model_dev1();
+            test_dynamics_step();
         }
     } catch (const std::exception& e) {
         std::printf("FAIL: unexpected exception: %s\n", e.what());
