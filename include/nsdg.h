@@ -27,7 +27,11 @@
  *  - edge-normal velocities at the ng = order+1 edge Gauss points:
  *        un_x[g*(nx+1)*ny + iy*(nx+1) + ex]   (vertical edges, normal = +x)
  *        un_y[g*nx*(ny+1) + ey*nx + ix]       (horizontal edges, normal = +y)
- *  - ice strength at the 3x3 Gauss points:  pg[q*nx*ny + e], q = 3*qy + qx.
+ *  - arrays private to the mEVP sub-cycle -- the stress coefficients s11/s12/s22 (nc = 8) and the ice
+ *    strength at the 3x3 Gauss points pg (nc = 9, q = 3*qy + qx) -- use a TILED layout: tiles of 64
+ *    consecutive elements of a row with all coefficients of the tile together,
+ *        a[((iy*ntx + ix/64)*nc + c)*64 + ix%64],  ntx = ceil(nx/64),  nsdg_tiled_len(nx, ny, nc) doubles.
+ *    Element rows stay contiguous, so row ranges / ghost rows work as for the plane layout.
  *  - Row ranges [j0, j1) are ELEMENT rows of the local array; the edges of the local array are the
  *    physical boundary (zero inflow for transport, v = 0 for momentum).  A rank of a row-block
  *    decomposition passes arrays that include its ghost rows and the range of rows it owns.
@@ -121,6 +125,9 @@ typedef struct {
 void nsdg_mevp_default_params(nsdg_mevp_params* p);
 int nsdg_mevp_params_set(nsdg_ctx* ctx, const nsdg_mevp_params* p);
 
+/* number of doubles of a tiled array (see "Data layout") */
+int64_t nsdg_tiled_len(int32_t nx, int32_t ny, int32_t nc);
+
 /* shape and cell size of the local element array all following calls refer to */
 int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
 
@@ -186,7 +193,8 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
     double* v, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
     const double* vo, const double* cgh, const double* cga, const double* pg, double* scratch);
 
-/* rows per strip of the fused marching kernel (performance knob; results do not depend on it) */
+/* rows per strip of the fused marching kernel (performance knob; results do not depend on it);
+ * 0 (default) = chosen per launch from the row count and the number of resident wave slots */
 int nsdg_mevp_strip_rows_set(nsdg_ctx* ctx, int32_t rows);
 /* register budget of the fused kernel: 1 or 2 resident waves per SIMD (performance knob) */
 int nsdg_mevp_occupancy_set(nsdg_ctx* ctx, int32_t waves_per_simd);

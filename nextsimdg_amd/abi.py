@@ -51,6 +51,7 @@ SYMBOLS = {
     "nsdg_column_step": (C.c_int, [VP, I64, D] + [VP] * 16),
     "nsdg_mevp_default_params": (None, [C.POINTER(MevpParams)]),
     "nsdg_mevp_params_set": (C.c_int, [VP, C.POINTER(MevpParams)]),
+    "nsdg_tiled_len": (C.c_int64, [I32, I32, I32]),
     "nsdg_grid_set": (C.c_int, [VP, I32, I32, D, D]),
     "nsdg_mevp_variant_set": (C.c_int, [VP, I32]),
     "nsdg_prepare_advection": (C.c_int, [VP, I32] + [VP] * 6),
@@ -91,6 +92,26 @@ def load_library(path=LIB_PATH):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+TILE = 64
+
+
+def tile(a):
+    """[nc, ny, nx] coefficient planes -> the tiled layout [ny, ceil(nx/64), nc, 64] of include/nsdg.h
+    (stress coefficients and Gauss-point ice strength); padding elements are zero"""
+    import torch
+
+    nc, ny, nx = a.shape
+    ntx = (nx + TILE - 1) // TILE
+    b = torch.nn.functional.pad(a, (0, ntx * TILE - nx))
+    return b.reshape(nc, ny, ntx, TILE).permute(1, 2, 0, 3).contiguous()
+
+
+def untile(t, nx):
+    """inverse of tile(): [ny, ntx, nc, 64] -> [nc, ny, nx]"""
+    ny, ntx, nc, _ = t.shape
+    return t.permute(2, 0, 1, 3).reshape(nc, ny, ntx * TILE)[:, :, :nx].contiguous()
 
 
 def _ptr(t):
@@ -151,6 +172,16 @@ class Context:
 
     def synchronize(self):
         self._call(self.lib.nsdg_ctx_synchronize(self.h))
+
+    # ---- arrays private to the mEVP sub-cycle (stress, ice strength) live in the tiled layout
+    def private_zeros(self, nc, ny, nx, device):
+        import torch
+
+        return torch.zeros(ny, (nx + TILE - 1) // TILE, nc, TILE, dtype=torch.float64, device=device)
+
+    @staticmethod
+    def private_rows(f, j0, j1):
+        return f[j0:j1]
 
     # ---- column physics
     def column_default_params(self, **kw):
@@ -222,6 +253,8 @@ class Context:
 
     def dg_to_cg(self, f_dg, f_cg):
         _check_f64(f_dg, f_cg)
+        if f_dg.dim() != 3:
+            raise NsdgError("dg_to_cg expects coefficient planes [nc, ny, nx]")
         self._call(self.lib.nsdg_dg_to_cg(self.h, f_dg.shape[0], _ptr(f_dg), _ptr(f_cg)))
 
     def ice_strength(self, H, A, pg, j0=0, j1=None):
@@ -256,7 +289,7 @@ class Context:
     def mevp_subcycle(self, dt, nsub, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch):
         ts = [s[0], s[1], s[2], u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch]
         _check_f64(*ts)
-        need = 10 * u.numel() + 3 * s[0].numel()
+        need = 10 * u.numel() + 3 * s[0].numel()  # s[k] are tiled arrays: numel() == nsdg_tiled_len(nx, ny, 8)
         if scratch.numel() < need:
             raise NsdgError("mEVP scratch too small: need %d doubles" % need)
         self._call(self.lib.nsdg_mevp_subcycle(self.h, float(dt), int(nsub), *[_ptr(t) for t in ts]))

@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void mevp_stress_kernel(int nx, int ny, int k0
     const int iy = k0 + blockIdx.y * 4 + threadIdx.y;
     if (ix >= nx || iy >= k1)
         return;
-    const long N = (long)nx * ny;
-    const long e = (long)iy * nx + ix;
+    const int ntx = tiles_per_row(nx);
+    const long ts = tile_off(ix, iy, ntx, 8), tp = tile_off(ix, iy, ntx, 9);
     const int nn = 2 * nx + 1;
     double ul[9], vl[9], P[9], s11[8], s12[8], s22[8];
 #pragma unroll
@@ -40,30 +40,30 @@ __global__ __launch_bounds__(256) void mevp_stress_kernel(int nx, int ny, int k0
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q)
-        P[q] = pg[q * N + e];
+        P[q] = pg[tp + q * 64];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s11[i] = S11i[i * N + e];
-        s12[i] = S12i[i * N + e];
-        s22[i] = S22i[i * N + e];
+        s11[i] = S11i[ts + i * 64];
+        s12[i] = S12i[ts + i * 64];
+        s22[i] = S22i[ts + i * 64];
     }
     stress_update(ul, vl, P, ihx, ihy, ialpha, dmin2, s11, s12, s22);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        S11[i * N + e] = s11[i];
-        S12[i * N + e] = s12[i];
-        S22[i * N + e] = s22[i];
+        S11[ts + i * 64] = s11[i];
+        S12[ts + i * 64] = s12[i];
+        S22[ts + i * 64] = s22[i];
     }
 }
 
 __device__ __forceinline__ void load_stress(const double* __restrict__ S11, const double* __restrict__ S12,
-    const double* __restrict__ S22, long N, long e, double (&s11)[8], double (&s12)[8], double (&s22)[8])
+    const double* __restrict__ S22, long ts, double (&s11)[8], double (&s12)[8], double (&s22)[8])
 {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s11[i] = S11[i * N + e];
-        s12[i] = S12[i * N + e];
-        s22[i] = S22[i * N + e];
+        s11[i] = S11[ts + i * 64];
+        s12[i] = S12[ts + i * 64];
+        s22[i] = S22[ts + i * 64];
     }
 }
 
@@ -76,8 +76,7 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(NodalConsts K, int n
     const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
     if (ix >= nx || iy >= j1)
         return;
-    const long N = (long)nx * ny;
-    const long e = (long)iy * nx + ix;
+    const int ntx = tiles_per_row(nx);
     const int nn = 2 * nx + 1;
     const double iarea = 1. / (hx * hy);
     double s11[8], s12[8], s22[8];
@@ -86,25 +85,25 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(NodalConsts K, int n
     double vx_ = 0., vy_ = 0., exx = 0., exy = 0., eyx = 0., eyy = 0., ccx, ccy;
     const bool hasL = ix > 0, hasB = iy > 0;
     if (hasL && hasB) {
-        load_stress(S11, S12, S22, N, e - nx - 1, s11, s12, s22);
+        load_stress(S11, S12, S22, tile_off(ix - 1, iy - 1, ntx, 8), s11, s12, s22);
         node_contrib<8>(s11, s12, s22, hx, hy, cx, cy);
         vx_ += cx, vy_ += cy;
     }
     if (hasB) {
-        load_stress(S11, S12, S22, N, e - nx, s11, s12, s22);
+        load_stress(S11, S12, S22, tile_off(ix, iy - 1, ntx, 8), s11, s12, s22);
         node_contrib<6>(s11, s12, s22, hx, hy, cx, cy);
         vx_ += cx, vy_ += cy;
         node_contrib<7>(s11, s12, s22, hx, hy, cx, cy);
         exx += cx, exy += cy;
     }
     if (hasL) {
-        load_stress(S11, S12, S22, N, e - 1, s11, s12, s22);
+        load_stress(S11, S12, S22, tile_off(ix - 1, iy, ntx, 8), s11, s12, s22);
         node_contrib<2>(s11, s12, s22, hx, hy, cx, cy);
         vx_ += cx, vy_ += cy;
         node_contrib<5>(s11, s12, s22, hx, hy, cx, cy);
         eyx += cx, eyy += cy;
     }
-    load_stress(S11, S12, S22, N, e, s11, s12, s22);
+    load_stress(S11, S12, S22, tile_off(ix, iy, ntx, 8), s11, s12, s22);
     node_contrib<0>(s11, s12, s22, hx, hy, cx, cy);
     vx_ += cx, vy_ += cy;
     node_contrib<1>(s11, s12, s22, hx, hy, cx, cy);
@@ -220,6 +219,7 @@ __global__ __launch_bounds__(256) void ice_strength_kernel(int nx, int ny, int j
         return;
     const long N = (long)nx * ny;
     const long e = (long)iy * nx + ix;
+    const long tp = tile_off(ix, iy, tiles_per_row(nx), 9);
     double hc[6], ac[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void ice_strength_kernel(int nx, int ny, int j
         }
         h = fmax(h, 0.);
         a = fmin(fmax(a, 0.), 1.);
-        pg[q * N + e] = pstar * h * exp(-compaction * (1. - a));
+        pg[tp + q * 64] = pstar * h * exp(-compaction * (1. - a));
     }
 }
 
@@ -268,6 +268,8 @@ static NodalConsts nodal_consts(const nsdg_ctx* ctx)
 }
 
 extern "C" {
+
+int64_t nsdg_tiled_len(int32_t nx, int32_t ny, int32_t nc) { return (int64_t)ny * tiles_per_row(nx) * nc * 64; }
 
 int nsdg_dg_to_cg(nsdg_ctx* ctx, int32_t ncoef, const double* f_dg, double* f_cg)
 {
@@ -405,7 +407,7 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
     NSDG_CHECK_ARG(u0 != u && v0 != v, "u0/v0 (velocity at step start) must not alias the iterate u/v");
     NSDG_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
     const long nnodes = (long)(2 * ctx->nx + 1) * (2 * ctx->ny + 1);
-    const long M = 8L * ctx->nx * ctx->ny;
+    const long M = nsdg_tiled_len(ctx->nx, ctx->ny, 8);
     // scratch: [packed nodal 6*nnodes (8*nnodes reserved)][u, v ping-pong 2*nnodes][stress ping-pong 3*M]
     double* packed = scratch;
     double *ua = u, *va = v, *ub = scratch + 8 * nnodes, *vb = ub + nnodes;

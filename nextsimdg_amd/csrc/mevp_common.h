@@ -9,6 +9,19 @@ namespace nsdg_mevp_detail {
 
 using namespace nsdg_tab;
 
+// Tiled layout of the element-wise arrays that only the mEVP kernels touch (stress coefficients,
+// Gauss-point ice strength): tiles of 64 consecutive elements of a row, all nc coefficients of a tile
+// stored together,
+//     a[((iy*ntx + ix/64)*nc + c)*64 + ix%64],   ntx = ceil(nx/64)   (rows padded to whole tiles).
+// A lane then reaches every coefficient of its element from ONE base address plus a compile-time
+// immediate (c*512 B <= 4 KB), instead of one 64-bit address per coefficient plane, and a wave streams
+// 4 KB of contiguous HBM per array and element row instead of 8 separate 512 B pieces 32 MB apart.
+__host__ __device__ __forceinline__ int tiles_per_row(int nx) { return (nx + 63) >> 6; }
+__device__ __forceinline__ long tile_off(int ix, int iy, int ntx, int nc)
+{
+    return ((long)iy * ntx + (ix >> 6)) * (nc * 64) + (ix & 63);
+}
+
 #define FMA_TAB(acc, tab, val)   \
     do {                         \
         const double t_ = (tab); \
@@ -176,9 +189,9 @@ __device__ __forceinline__ void sf_geta(const double (&c)[8], double (&G)[9])
     }
 }
 
-// stress of one element from its 9 nodal velocities: S <- (1-1/alpha) S + (1/alpha) Proj sigma(v)
-__device__ __forceinline__ void stress_update(const double (&ul)[9], const double (&vl)[9], const double (&P)[9],
-    double ihx, double ihy, double ialpha, double dmin2, double (&s11)[8], double (&s12)[8], double (&s22)[8])
+// (1/alpha) Proj sigma(v): the projected viscous-plastic stress of one element from its 9 nodal velocities
+__device__ __forceinline__ void stress_projected(const double (&ul)[9], const double (&vl)[9], const double (&P)[9], double ihx,
+    double ihy, double dmin2, double (&r11)[8], double (&r12)[8], double (&r22)[8])
 {
     double E11[8], E12[8], E22[8];
     {
@@ -205,10 +218,14 @@ __device__ __forceinline__ void stress_update(const double (&ul)[9], const doubl
         t22[q] = pd * (0.625 * e22[q] + 0.375 * e11[q]) - 0.5 * P[q];
         t12[q] = pd * 0.25 * e12[q];
     }
-    double r11[8], r12[8], r22[8];
     sf_project(t11, r11);
     sf_project(t12, r12);
     sf_project(t22, r22);
+}
+
+__device__ __forceinline__ void stress_relax(double ialpha, const double (&r11)[8], const double (&r12)[8], const double (&r22)[8],
+    double (&s11)[8], double (&s12)[8], double (&s22)[8])
+{
     const double keep = 1. - ialpha;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -216,6 +233,15 @@ __device__ __forceinline__ void stress_update(const double (&ul)[9], const doubl
         s12[i] = keep * s12[i] + ialpha * r12[i];
         s22[i] = keep * s22[i] + ialpha * r22[i];
     }
+}
+
+// stress of one element from its 9 nodal velocities: S <- (1-1/alpha) S + (1/alpha) Proj sigma(v)
+__device__ __forceinline__ void stress_update(const double (&ul)[9], const double (&vl)[9], const double (&P)[9],
+    double ihx, double ihy, double ialpha, double dmin2, double (&s11)[8], double (&s12)[8], double (&s22)[8])
+{
+    double r11[8], r12[8], r22[8];
+    stress_projected(ul, vl, P, ihx, ihy, dmin2, r11, r12, r22);
+    stress_relax(ialpha, r11, r12, r22, s11, s12, s22);
 }
 
 // all 18 nodal contributions -(sigma, grad phi_n)_K of one element

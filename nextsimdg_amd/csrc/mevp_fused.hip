@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
     const bool own = valid && lane > 0;
     const int ix = min(max(ixr, 0), nx - 1);
     const bool hasL = ix > 0;
-    const long N = (long)nx * ny;
+    const int ntx = tiles_per_row(nx);
     const int nn = 2 * nx + 1;
     const double ihx = 1. / hx, ihy = 1. / hy, iarea = ihx * ihy;
 
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
 
     for (int iy = (y0 > k0 ? y0 - 1 : y0); iy < y1; ++iy) {
         const bool prologue = iy < y0; // recomputed row owned by the strip below: nothing is stored
-        const long e = (long)iy * nx + ix;
+        const long ts = tile_off(ix, iy, ntx, 8), tp = tile_off(ix, iy, ntx, 9);
         const long nV = (long)(2 * iy) * nn + 2 * ix;
         double ul[9], vl[9], Pq[9], s11[8], s12[8], s22[8];
 #pragma unroll
@@ -85,24 +85,41 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
         }
 #pragma unroll
         for (int q = 0; q < 9; ++q)
-            Pq[q] = NSDG_LD(&pg[q * N + e]);
+            Pq[q] = NSDG_LD(&pg[tp + q * 64]);
+        if constexpr (MINW >= 2) {
+            // 2 waves/SIMD build: stage the loads so that the live set stays under 256 registers -- the old
+            // stress is fetched only after the projected stress is formed, the partner wave covers the latency
+            double r11[8], r12[8], r22[8];
+            stress_projected(ul, vl, Pq, ihx, ihy, dmin2, r11, r12, r22);
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            s11[i] = NSDG_LD(&S.i11[i * N + e]);
-            s12[i] = NSDG_LD(&S.i12[i * N + e]);
-            s22[i] = NSDG_LD(&S.i22[i * N + e]);
+            for (int i = 0; i < 8; ++i) {
+                s11[i] = NSDG_LD(&S.i11[ts + i * 64]);
+                s12[i] = NSDG_LD(&S.i12[ts + i * 64]);
+                s22[i] = NSDG_LD(&S.i22[ts + i * 64]);
+            }
+            stress_relax(ialpha, r11, r12, r22, s11, s12, s22);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s11[i] = NSDG_LD(&S.i11[ts + i * 64]);
+                s12[i] = NSDG_LD(&S.i12[ts + i * 64]);
+                s22[i] = NSDG_LD(&S.i22[ts + i * 64]);
+            }
+            stress_update(ul, vl, Pq, ihx, ihy, ialpha, dmin2, s11, s12, s22);
         }
-        stress_update(ul, vl, Pq, ihx, ihy, ialpha, dmin2, s11, s12, s22);
         if (!prologue && own) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                NSDG_ST(s11[i], &S.o11[i * N + e]);
-                NSDG_ST(s12[i], &S.o12[i * N + e]);
-                NSDG_ST(s22[i], &S.o22[i * N + e]);
+                NSDG_ST(s11[i], &S.o11[ts + i * 64]);
+                NSDG_ST(s12[i], &S.o12[ts + i * 64]);
+                NSDG_ST(s22[i], &S.o22[ts + i * 64]);
             }
         }
         double cx[9], cy[9];
         node_contrib_all(s11, s12, s22, hx, hy, cx, cy);
+        if constexpr (MINW >= 2)
+            asm volatile("" ::: "memory"); // keep the nodal-coefficient loads below this point
         // wavefront-level edge exchange: right-column contributions of the element to my left
         const double l2x = shift_up(cx[2]), l2y = shift_up(cy[2]);
         const double l5x = shift_up(cx[5]), l5y = shift_up(cy[5]);
@@ -166,8 +183,28 @@ int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, const double* 
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
     const double* packed, const double* pg)
 {
-    const int R = ctx->strip_rows;
     const int ncw = nsdg_div_up(ctx->nx, 63); // 63 owned columns per wave
+    int R = ctx->strip_rows;
+    if (R <= 0) {
+        // Automatic strip height.  Every wave marches R+1 rows (one redundant), and the launch runs in
+        // ceil(waves / resident wave slots) rounds, so the time is ~ rounds * (R+1) row-times: pick the R
+        // that minimises it (measured on 2048^2: R = 17 -> 2 full rounds, 8 % faster than R = 4 with its
+        // 8.25 rounds and 25 % redundant rows).  A single round is charged 1.5 row-times because one
+        // straggling wave then ends the launch alone.
+        const long slots = 2L * 4 * ctx->num_cus; // 2 waves per SIMD at ~204 VGPRs
+        const int rows = j1 - k0;
+        double best = 1e30;
+        R = 4;
+        for (int r = 2; r <= 64; ++r) {
+            const long waves = (long)nsdg_div_up(rows, r) * ncw;
+            const long rounds = (waves + slots - 1) / slots;
+            const double cost = rounds * (r + 1.0) + (rounds == 1 ? 1.5 : 0.0);
+            if (cost < best) {
+                best = cost;
+                R = r;
+            }
+        }
+    }
     const int nstrips = nsdg_div_up(j1 - k0, R);
     const long nwaves = (long)ncw * nstrips;
     const StressPtrs S = { s11i, s12i, s22i, s11, s12, s22 };

@@ -77,7 +77,11 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     c->nx = c->ny = 0;
     c->hx = c->hy = 0.;
     c->mevp_variant = 1;
-    c->strip_rows = 6;
+    c->strip_rows = 0;
+    {
+        hipDeviceProp_t prop;
+        c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
     c->fused_min_waves = 1;
     c->pack_dt = 0.;
     c->d_ptrs = nullptr;
@@ -133,7 +137,7 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy)
 int nsdg_mevp_strip_rows_set(nsdg_ctx* ctx, int32_t rows)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
-    NSDG_CHECK_ARG(rows >= 1 && rows <= 4096, "rows per strip must be in 1..4096");
+    NSDG_CHECK_ARG(rows >= 0 && rows <= 4096, "rows per strip must be in 0..4096 (0 = automatic)");
     ctx->strip_rows = rows;
     return NSDG_OK;
 }

@@ -15,7 +15,8 @@ struct nsdg_ctx {
     int nx, ny; // local element array
     double hx, hy;
     int mevp_variant;
-    int strip_rows; // rows per strip of the fused marching kernel
+    int strip_rows; // rows per strip of the fused marching kernel (0 = chosen per launch)
+    int num_cus;
     double pack_dt; // time step the packed nodal coefficients were built for (0 = never packed)
     int fused_min_waves; // register budget of the fused kernel: 1 or 2 waves per SIMD
     // device scratch for small host->device tables (field pointer lists of the transport stage)

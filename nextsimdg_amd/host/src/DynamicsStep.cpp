@@ -87,8 +87,10 @@ void DynamicsStep::start(const Iterator::TimePoint&)
     nyf = pStructure->nx();
     N = (long)nxf * nyf;
     NN = (long)(2 * nxf + 1) * (2 * nyf + 1);
-    const long sizes[NARR] = { 6 * N, 6 * N, 12 * N, 12 * N, 8 * N, 8 * N, 8 * N, 9 * N, 6 * N, 6 * N, 3L * (nxf + 1) * nyf, 3L * nxf * (nyf + 1), NN,
-        NN, NN, NN, NN, NN, NN, NN, NN, NN, NN, NN, 10 * NN + 24 * N, 13 * N };
+    // stress and ice strength are private to the sub-cycle and use the ABI's tiled layout
+    const long TS = nsdg_tiled_len(nxf, nyf, 8), TP = nsdg_tiled_len(nxf, nyf, 9);
+    const long sizes[NARR] = { 6 * N, 6 * N, 12 * N, 12 * N, TS, TS, TS, TP, 6 * N, 6 * N, 3L * (nxf + 1) * nyf, 3L * nxf * (nyf + 1), NN, NN,
+        NN, NN, NN, NN, NN, NN, NN, NN, NN, NN, 10 * NN + 3 * TS, 13 * N };
     long total = 0;
     for (long s : sizes)
         total += s + 2; // keep every sub-array 16-byte aligned

@@ -136,9 +136,10 @@ class DynamicsCore:
         z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
         nodal = (2 * ny + 1, 2 * nx + 1)
         self.H, self.A = z(6, ny, nx), z(6, ny, nx)
-        self.s = [z(8, ny, nx) for _ in range(3)]
-        self.sb = [z(8, ny, nx) for _ in range(3)]
-        self.pg = z(9, ny, nx)
+        # stress and ice strength are private to the sub-cycle: the ops object chooses their layout
+        self.s = [ops.private_zeros(8, ny, nx, device) for _ in range(3)]
+        self.sb = [ops.private_zeros(8, ny, nx, device) for _ in range(3)]
+        self.pg = ops.private_zeros(9, ny, nx, device)
         self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
         self.u0, self.v0 = z(*nodal), z(*nodal)
         self.ua, self.va, self.tax, self.tay = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
@@ -222,6 +223,8 @@ class DynamicsCore:
     def owned(self, f):
         """owned element rows of a DG array / owned node rows of a nodal array (for gathering)"""
         b = self.blk
+        if any(f is x for x in self.s + self.sb + [self.pg]):
+            return self.ops.private_rows(f, b.j0, b.j1)
         if f.dim() == 3:
             return f[:, b.j0:b.j1]
         top = 2 * b.j1 + (1 if b.above is None else 0)

@@ -22,6 +22,15 @@ class OracleOps:
         fo = {k: _np(v).reshape(-1) for k, v in forcing.items()}
         O.column_step(self.cp, dt, st, fo, _np(newice).reshape(-1))
 
+    def private_zeros(self, nc, ny, nx, device):
+        import torch
+
+        return torch.zeros(nc, ny, nx, dtype=torch.float64, device=device)  # the oracle keeps coefficient planes
+
+    @staticmethod
+    def private_rows(f, j0, j1):
+        return f[:, j0:j1]
+
     def set_grid(self, nx, ny, hx, hy):
         self.nx, self.ny, self.hx, self.hy = nx, ny, hx, hy
 

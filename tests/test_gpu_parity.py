@@ -35,6 +35,15 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
+def tdev(a):
+    """coefficient planes [nc, ny, nx] (oracle layout) -> tiled device array (stress, ice strength)"""
+    return abi.tile(dev(a))
+
+
+def thost(t, nx):
+    return abi.untile(t, nx).cpu().numpy()
+
+
 def host(t):
     return t.cpu().numpy()
 
@@ -203,9 +212,9 @@ def test_mevp_helpers_match_oracle(ctx):
     b = Box(ctx, 37, 29)
     nx, ny = b.nx, b.ny
     pg_o = O.ice_strength(nx, ny, b.po, b.H, b.A)
-    pg_d = torch.zeros(9, ny, nx, dtype=torch.float64, device="cuda")
+    pg_d = ctx.private_zeros(9, ny, nx, "cuda")
     ctx.ice_strength(dev(b.H), dev(b.A), pg_d)
-    assert_close(host(pg_d), pg_o, 1e-12, 1e-10, "ice strength")
+    assert_close(thost(pg_d, nx), pg_o, 1e-12, 1e-10, "ice strength")
     for f in (b.H, b.A):
         cg_d = torch.zeros(2 * ny + 1, 2 * nx + 1, dtype=torch.float64, device="cuda")
         ctx.dg_to_cg(dev(f), cg_d)
@@ -246,12 +255,12 @@ def test_mevp_single_iteration_matches_oracle(ctx, variant):
     cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
     tax, tay = O.wind_stress(b.po, b.ua, b.va)
     u0, v0 = 0.9 * u, 0.9 * v
-    ds = [dev(x) for x in s]
+    ds = [tdev(x) for x in s]
     du, dv = dev(u), dev(v)
     dun, dvn = torch.full_like(du, 3.0), torch.full_like(dv, 3.0)
     packed = pack(ctx, 120.0, u0, v0, tax, tay, b.uo, b.vo, cgh, cga)
     dso = [torch.zeros_like(x) for x in ds]
-    ctx.mevp_iterate(0, 0, ny, ds, dso, (du, dv), (dun, dvn), packed, dev(pg))
+    ctx.mevp_iterate(0, 0, ny, ds, dso, (du, dv), (dun, dvn), packed, tdev(pg))
     ds = dso
     # oracle
     O.mevp_stress(nx, ny, 0, ny, b.bt.hx, b.bt.hy, b.po, u, v, pg, *s)
@@ -259,7 +268,7 @@ def test_mevp_single_iteration_matches_oracle(ctx, variant):
     O.mevp_velocity(nx, ny, 0, ny, b.bt.hx, b.bt.hy, 120.0, b.po, s, (u, v), (un, vn), (u0, v0), (tax, tay),
                     (b.uo, b.vo), cgh, cga)
     for d, o, name in zip(ds, s, ("s11", "s12", "s22")):
-        assert_close(host(d), o, 1e-12, 1e-12 * np.max(np.abs(o)), name)
+        assert_close(thost(d, nx), o, 1e-12, 1e-12 * np.max(np.abs(o)), name)
     assert_close(host(dun), un, 1e-11, 1e-13 * np.max(np.abs(un)), "u_new")
     assert_close(host(dvn), vn, 1e-11, 1e-13 * np.max(np.abs(vn)), "v_new")
     ctx.set_mevp_variant(1)
@@ -277,17 +286,17 @@ def test_mevp_subcycle_matches_oracle(ctx, variant):
     u, v = np.zeros(shape), np.zeros(shape)
     u0, v0 = u.copy(), v.copy()
     s = [np.zeros((8, ny, nx)) for _ in range(3)]
-    du, dv, ds = dev(u), dev(v), [dev(x) for x in s]
-    scratch = torch.zeros(10 * u.size + 3 * s[0].size, dtype=torch.float64, device="cuda")
+    du, dv, ds = dev(u), dev(v), [tdev(x) for x in s]
+    scratch = torch.zeros(10 * u.size + 3 * ds[0].numel(), dtype=torch.float64, device="cuda")
     nsub = 25  # odd: exercises the copy-back of the ping-pong buffers
     ctx.mevp_subcycle(120.0, nsub, ds, du, dv, dev(u0), dev(v0), dev(tax), dev(tay), dev(b.uo), dev(b.vo), dev(cgh),
-                      dev(cga), dev(pg), scratch)
+                      dev(cga), tdev(pg), scratch)
     O.mevp_subcycle(nx, ny, b.bt.hx, b.bt.hy, 120.0, nsub, b.po, s, u, v, u0, v0, tax, tay, b.uo, b.vo, cgh, cga, pg)
     assert np.max(np.abs(u)) > 1e-4
     assert_close(host(du), u, 1e-9, 1e-11 * np.max(np.abs(u)), "u after subcycle")
     assert_close(host(dv), v, 1e-9, 1e-11 * np.max(np.abs(v)), "v after subcycle")
     for d, o in zip(ds, s):
-        assert_close(host(d), o, 1e-9, 1e-10 * np.max(np.abs(o)), "stress after subcycle")
+        assert_close(thost(d, nx), o, 1e-9, 1e-10 * np.max(np.abs(o)), "stress after subcycle")
     # Dirichlet rows/columns are exactly zero
     g = host(du)
     assert np.all(g[0] == 0) and np.all(g[-1] == 0) and np.all(g[:, 0] == 0) and np.all(g[:, -1] == 0)
@@ -306,23 +315,23 @@ def test_mevp_row_block_equals_full_domain_bitwise(ctx):
         pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
         cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
         tax, tay = O.wind_stress(b.po, b.ua, b.va)
-        full = [torch.zeros_like(dev(x)) for x in s]
+        full = [torch.zeros_like(tdev(x)) for x in s]
         un, vn = torch.zeros_like(dev(u)), torch.zeros_like(dev(v))
         packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
-        ctx.mevp_iterate(0, 0, ny, [dev(x) for x in s], full, (dev(u), dev(v)), (un, vn), packed, dev(pg))
+        ctx.mevp_iterate(0, 0, ny, [tdev(x) for x in s], full, (dev(u), dev(v)), (un, vn), packed, tdev(pg))
         # upper rank: owns element rows [12, 24); local array = rows [11, 24) (ghost row below)
         r0 = 12
         lo = r0 - 1
         sl_e = lambda a: np.ascontiguousarray(a[:, lo:])
         sl_n = lambda a: np.ascontiguousarray(a[2 * lo:])
         ctx.set_grid(nx, ny - lo, b.bt.hx, b.bt.hy)
-        part = [torch.zeros_like(dev(sl_e(x))) for x in s]
+        part = [torch.zeros_like(tdev(sl_e(x))) for x in s]
         pun, pvn = torch.zeros_like(dev(sl_n(u))), torch.zeros_like(dev(sl_n(v)))
         ppacked = pack(ctx, 120.0, *[sl_n(x) for x in (0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)])
-        ctx.mevp_iterate(0, 1, ny - lo, [dev(sl_e(x)) for x in s], part, (dev(sl_n(u)), dev(sl_n(v))), (pun, pvn), ppacked,
-                         dev(sl_e(pg)))
+        ctx.mevp_iterate(0, 1, ny - lo, [tdev(sl_e(x)) for x in s], part, (dev(sl_n(u)), dev(sl_n(v))), (pun, pvn), ppacked,
+                         tdev(sl_e(pg)))
         for f, p in zip(full, part):
-            assert torch.equal(f[:, lo:], p)
+            assert torch.equal(f[lo:], p)  # tiled arrays: element rows are the leading dimension
         assert torch.equal(un[2 * r0:], pun[2:])
         assert torch.equal(vn[2 * r0:], pvn[2:])
     ctx.set_mevp_variant(1)
@@ -340,12 +349,12 @@ def test_mevp_fused_strip_size_does_not_change_results(ctx):
     tax, tay = O.wind_stress(b.po, b.ua, b.va)
     packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
     results = []
-    for variant, rows in ((0, 16), (1, 1), (1, 7), (1, 16), (1, 64)):
+    for variant, rows in ((0, 16), (1, 1), (1, 7), (1, 16), (1, 64), (1, 0)):
         ctx.set_mevp_variant(variant)
         ctx.set_mevp_strip_rows(rows)
-        so = [torch.zeros_like(dev(x)) for x in s]
+        so = [torch.zeros_like(tdev(x)) for x in s]
         un, vn = torch.full_like(dev(u), 9.0), torch.full_like(dev(v), 9.0)
-        ctx.mevp_iterate(0, 0, ny, [dev(x) for x in s], so, (dev(u), dev(v)), (un, vn), packed, dev(pg))
+        ctx.mevp_iterate(0, 0, ny, [tdev(x) for x in s], so, (dev(u), dev(v)), (un, vn), packed, tdev(pg))
         results.append(so + [un, vn])
     for r in results[2:]:
         for a, c in zip(results[1], r):
@@ -353,7 +362,7 @@ def test_mevp_fused_strip_size_does_not_change_results(ctx):
     for a, c in zip(results[0], results[1]):
         assert_close(host(c), host(a), 1e-12, 1e-13 * float(a.abs().max()), "fused vs two-kernel")
     ctx.set_mevp_variant(1)
-    ctx.set_mevp_strip_rows(4)
+    ctx.set_mevp_strip_rows(0)
 
 
 def test_mevp_split_sub_iteration_equals_single_launch_bitwise(ctx):
@@ -363,11 +372,11 @@ def test_mevp_split_sub_iteration_equals_single_launch_bitwise(ctx):
     nx, ny = b.nx, b.ny
     rng = np.random.default_rng(31)
     u, v, s = mevp_state(b, rng)
-    pg = dev(O.ice_strength(nx, ny, b.po, b.H, b.A))
+    pg = tdev(O.ice_strength(nx, ny, b.po, b.H, b.A))
     cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
     tax, tay = O.wind_stress(b.po, b.ua, b.va)
     packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
-    s_in = [dev(x) for x in s]
+    s_in = [tdev(x) for x in s]
     one = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
     ctx.mevp_iterate(0, 0, ny, s_in, one[:3], (dev(u), dev(v)), (one[3], one[4]), packed, pg)
     three = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]

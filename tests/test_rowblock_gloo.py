@@ -100,7 +100,7 @@ def test_row_block_run_equals_single_domain_bitwise(world, overlap, tmp_path):
     port = free_port()
     mp.spawn(worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
-    for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
+    for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):  # oracle ops keep [nc, ny, nx] planes
         got = torch.cat([p[key] for p in parts], dim=1)
         assert torch.equal(got, full), key
     for key, full in (("u", ref.u), ("v", ref.v)):
