@@ -286,6 +286,24 @@ class Context:
         _check_f64(*ts)
         self._call(self.lib.nsdg_mevp_iterate(self.h, k0, j0, j1, *[_ptr(t) for t in ts]))
 
+    def bind_mevp_iterate(self, k0, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        """Pre-validated, pre-marshalled form of mevp_iterate for inner loops: returns a zero-argument
+        callable.  (Argument checking and ctypes marshalling cost ~20 us per call in Python -- comparable
+        to a sub-iteration of a 256-row block -- so the 120-iteration sub-cycle binds its calls once.)"""
+        ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
+        _check_f64(*ts)
+        fn, h = self.lib.nsdg_mevp_iterate, self.h
+        args = (h, I32(k0), I32(j0), I32(j1)) + tuple(_ptr(t) for t in ts)
+        keep = ts  # the tensors must outlive the binding
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                self._call(rc)
+            return keep is None
+
+        return call
+
     def mevp_subcycle(self, dt, nsub, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch):
         ts = [s[0], s[1], s[2], u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch]
         _check_f64(*ts)

@@ -6,7 +6,7 @@
 // growth, min-c/h cut-off) and PrognosticData::updateAndIntegrate.  Formulae are cited inline
 // (paths relative to /root/reference).
 //
-// Shape: one lane per element, SoA planes, 15 coalesced fp64 loads + 5 stores per element
+// Shape: two adjacent elements per lane (16-byte accesses), SoA planes, 15 coalesced loads + 5 stores per element
 // (160 B / element-step algorithmic traffic); all intermediates (the reference's
 // PhysicsData scratch and the NextsimPhysics members) live in registers.  The virtual plugin calls
 // of the reference (albedo / freezing point) become wave-uniform switches on the params struct,
@@ -81,23 +81,21 @@ __device__ __forceinline__ double ice_albedo(const nsdg_column_params& P, double
     return (hs > 0.) ? SNOW_ALBEDO : bare; // SMUIceAlbedo.cpp:19-26
 }
 
+struct ColumnIn {
+    double thick, conc, snow, tice, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice;
+};
+struct ColumnOut {
+    double hice, cice, hsnow, tice0, newice;
+};
+
+// The column physics of ONE element (everything DevStep::iterate does to it), on register values.
 template <bool DIAG>
-__global__ __launch_bounds__(256) void column_step_kernel(nsdg_column_params P, long n, double dt,
-    double* __restrict__ hice, double* __restrict__ cice, double* __restrict__ hsnow,
-    double* __restrict__ tice0, const double* __restrict__ sst_, const double* __restrict__ sss_,
-    const double* __restrict__ tair_, const double* __restrict__ tdew_, const double* __restrict__ slp_,
-    const double* __restrict__ qsw_, const double* __restrict__ qlw_, const double* __restrict__ mld_,
-    const double* __restrict__ snowfall_, const double* __restrict__ wind_, double* __restrict__ newice_,
-    double* __restrict__ diag)
+__device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P, double dt, const ColumnIn& in, double* d /* NSDG_NDIAG or unused */)
 {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n)
-        return;
-    // 15 coalesced loads, issued up front so they are all in flight together
-    const double thick = hice[e], conc = cice[e], snow = hsnow[e], tice = tice0[e];
-    const double sst = sst_[e], sss = sss_[e], tair = tair_[e], tdew = tdew_[e], slp = slp_[e];
-    const double qsw = qsw_[e], qlw = qlw_[e], mld = mld_[e], snowfall = snowfall_[e], wind = wind_[e];
-    double newice = newice_[e];
+    const double thick = in.thick, conc = in.conc, snow = in.snow, tice = in.tice;
+    const double sst = in.sst, sss = in.sss, tair = in.tair, tdew = in.tdew, slp = in.slp;
+    const double qsw = in.qsw, qlw = in.qlw, mld = in.mld, snowfall = in.snowfall, wind = in.wind;
+    double newice = in.newice;
 
     // PrognosticData.hpp:56,75,78; ExternalData.hpp:60
     const double h_true = (conc != 0) ? thick / conc : 0;
@@ -227,15 +225,7 @@ __global__ __launch_bounds__(256) void column_step_kernel(nsdg_column_params P, 
         hs = 0;
     }
 
-    // ---- PrognosticData::updateAndIntegrate (core/src/PrognosticData.cpp:63-71; PhysicsData.hpp:61,66)
-    hice[e] = hi * c_new;
-    cice[e] = c_new;
-    hsnow[e] = hs * c_new;
-    tice0[e] = Tnew;
-    newice_[e] = newice;
-
     if (DIAG) {
-        double d[NSDG_NDIAG];
         d[NSDG_D_RHO] = rho;
         d[NSDG_D_QA] = q_a;
         d[NSDG_D_QW] = q_w;
@@ -251,10 +241,63 @@ __global__ __launch_bounds__(256) void column_step_kernel(nsdg_column_params P, 
         d[NSDG_D_DQDT] = dQ_dT;
         d[NSDG_D_HIFROMS] = hifroms;
         d[NSDG_D_QOW] = Qow;
+    }
+    // ---- PrognosticData::updateAndIntegrate (core/src/PrognosticData.cpp:63-71; PhysicsData.hpp:61,66)
+    return ColumnOut { hi * c_new, c_new, hs * c_new, Tnew, newice };
+}
+
+// Scalar kernel (one element per lane): used when diagnostics are requested and for the odd tail element.
+template <bool DIAG>
+__global__ __launch_bounds__(256) void column_step_kernel(nsdg_column_params P, long first, long n, long nplane, double dt,
+    double* __restrict__ hice, double* __restrict__ cice, double* __restrict__ hsnow,
+    double* __restrict__ tice0, const double* __restrict__ sst_, const double* __restrict__ sss_,
+    const double* __restrict__ tair_, const double* __restrict__ tdew_, const double* __restrict__ slp_,
+    const double* __restrict__ qsw_, const double* __restrict__ qlw_, const double* __restrict__ mld_,
+    const double* __restrict__ snowfall_, const double* __restrict__ wind_, double* __restrict__ newice_,
+    double* __restrict__ diag)
+{
+    const long e = first + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n)
+        return;
+    const ColumnIn in = { hice[e], cice[e], hsnow[e], tice0[e], sst_[e], sss_[e], tair_[e], tdew_[e], slp_[e], qsw_[e], qlw_[e], mld_[e],
+        snowfall_[e], wind_[e], newice_[e] };
+    double d[NSDG_NDIAG];
+    const ColumnOut o = column_element<DIAG>(P, dt, in, d);
+    hice[e] = o.hice;
+    cice[e] = o.cice;
+    hsnow[e] = o.hsnow;
+    tice0[e] = o.tice0;
+    newice_[e] = o.newice;
+    if (DIAG) {
 #pragma unroll
         for (int k = 0; k < NSDG_NDIAG; ++k)
-            diag[(long)k * n + e] = d[k];
+            diag[(long)k * nplane + e] = d[k];
     }
+}
+
+// Production kernel: two adjacent elements per lane, every plane access a 16-byte load/store (the
+// widest coalesced access; 8-byte accesses reach a lower fraction of the HBM rate).
+__global__ __launch_bounds__(256) void column_step_kernel_x2(nsdg_column_params P, long npairs, double dt,
+    double2* __restrict__ hice, double2* __restrict__ cice, double2* __restrict__ hsnow, double2* __restrict__ tice0,
+    const double2* __restrict__ sst_, const double2* __restrict__ sss_, const double2* __restrict__ tair_,
+    const double2* __restrict__ tdew_, const double2* __restrict__ slp_, const double2* __restrict__ qsw_,
+    const double2* __restrict__ qlw_, const double2* __restrict__ mld_, const double2* __restrict__ snowfall_,
+    const double2* __restrict__ wind_, double2* __restrict__ newice_)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs)
+        return;
+    const double2 a0 = hice[i], a1 = cice[i], a2 = hsnow[i], a3 = tice0[i], a4 = sst_[i], a5 = sss_[i], a6 = tair_[i], a7 = tdew_[i],
+                  a8 = slp_[i], a9 = qsw_[i], a10 = qlw_[i], a11 = mld_[i], a12 = snowfall_[i], a13 = wind_[i], a14 = newice_[i];
+    const ColumnIn inx = { a0.x, a1.x, a2.x, a3.x, a4.x, a5.x, a6.x, a7.x, a8.x, a9.x, a10.x, a11.x, a12.x, a13.x, a14.x };
+    const ColumnIn iny = { a0.y, a1.y, a2.y, a3.y, a4.y, a5.y, a6.y, a7.y, a8.y, a9.y, a10.y, a11.y, a12.y, a13.y, a14.y };
+    const ColumnOut ox = column_element<false>(P, dt, inx, nullptr);
+    const ColumnOut oy = column_element<false>(P, dt, iny, nullptr);
+    hice[i] = make_double2(ox.hice, oy.hice);
+    cice[i] = make_double2(ox.cice, oy.cice);
+    hsnow[i] = make_double2(ox.hsnow, oy.hsnow);
+    tice0[i] = make_double2(ox.tice0, oy.tice0);
+    newice_[i] = make_double2(ox.newice, oy.newice);
 }
 
 } // namespace
@@ -273,13 +316,27 @@ extern "C" int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hic
         "null field pointer");
     NSDG_CHECK_ARG(n < (1LL << 31) * 256, "element count too large for one launch");
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    const dim3 block(256), grid(nsdg_div_up(n, 256));
-    if (diag)
-        hipLaunchKernelGGL(column_step_kernel<true>, grid, block, 0, ctx->stream, ctx->column, (long)n, dt, hice, cice,
-            hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice, diag);
-    else
-        hipLaunchKernelGGL(column_step_kernel<false>, grid, block, 0, ctx->stream, ctx->column, (long)n, dt, hice, cice,
-            hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice, diag);
+    const dim3 block(256);
+    if (diag) {
+        hipLaunchKernelGGL(column_step_kernel<true>, dim3(nsdg_div_up(n, 256)), block, 0, ctx->stream, ctx->column, 0L, (long)n, (long)n, dt,
+            hice, cice, hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice, diag);
+    } else {
+        // 16-byte path for the even part when every plane is 16-byte aligned, scalar kernel for the rest
+        const double* planes[15] = { hice, cice, hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice };
+        bool aligned = true;
+        for (const double* p : planes)
+            aligned = aligned && (((uintptr_t)p & 15) == 0);
+        const long npairs = aligned ? n / 2 : 0;
+        if (npairs > 0)
+            hipLaunchKernelGGL(column_step_kernel_x2, dim3(nsdg_div_up(npairs, 256)), block, 0, ctx->stream, ctx->column, npairs, dt,
+                (double2*)hice, (double2*)cice, (double2*)hsnow, (double2*)tice0, (const double2*)sst, (const double2*)sss,
+                (const double2*)tair, (const double2*)tdew, (const double2*)slp, (const double2*)qsw, (const double2*)qlw,
+                (const double2*)mld, (const double2*)snowfall, (const double2*)wind, (double2*)newice);
+        const long done = 2 * npairs;
+        if (done < n)
+            hipLaunchKernelGGL(column_step_kernel<false>, dim3(nsdg_div_up(n - done, 256)), block, 0, ctx->stream, ctx->column, done, (long)n,
+                (long)n, dt, hice, cice, hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice, diag);
+    }
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }

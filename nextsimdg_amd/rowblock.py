@@ -131,6 +131,7 @@ class DynamicsCore:
     def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None, overlap=True):
         self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
         self.overlap = overlap
+        self._calls = {}
         self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
         nx, ny = blk.nx, blk.ny
         z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
@@ -178,27 +179,50 @@ class DynamicsCore:
                             self.packed)
         split = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 4
         for _ in range(self.nsub):
-            uv, uvn = (self.u, self.v), (self.ub, self.vb)
+            uvn = (self.ub, self.vb)
+            calls = self._iterate_calls(split)
             if not split:
-                ops.mevp_iterate(b.k0, b.j0, b.j1, self.s, self.sb, uv, uvn, self.packed, self.pg)
+                calls[0]()
                 self.halo.nodal(uvn)
             else:
                 # boundary rows first, so that their node rows travel while the interior is computed:
                 # the exchange is posted after the boundary launches and before the interior launch, the
                 # communication stream therefore waits only for the former
-                lo, hi = b.j0, b.j1
-                if b.above is not None:  # top owned element row -> the two node rows sent upwards
-                    ops.mevp_iterate(b.j1 - 2, b.j1 - 1, b.j1, self.s, self.sb, uv, uvn, self.packed, self.pg)
-                    hi = b.j1 - 1
-                if b.below is not None:  # bottom owned element row (+ redundant ghost-row stress) -> node row sent downwards
-                    ops.mevp_iterate(b.j0 - 1, b.j0, b.j0 + 1, self.s, self.sb, uv, uvn, self.packed, self.pg)
-                    lo = b.j0 + 1
+                for c in calls[:-1]:
+                    c()
                 reqs = self.halo.nodal_start(uvn)
-                ops.mevp_iterate(lo - 1 if lo > 0 else 0, lo, hi, self.s, self.sb, uv, uvn, self.packed, self.pg)
+                calls[-1]()
                 self.halo.finish(reqs)
             self.u, self.ub = self.ub, self.u
             self.v, self.vb = self.vb, self.v
             self.s, self.sb = self.sb, self.s
+
+    def _iterate_calls(self, split):
+        """the launches of one sub-iteration for the current ping-pong parity, bound once and cached"""
+        key = (self.u.data_ptr(), self.s[0].data_ptr(), split)
+        calls = self._calls.get(key)
+        if calls is not None:
+            return calls
+        ops, b = self.ops, self.blk
+        uv, uvn = (self.u, self.v), (self.ub, self.vb)
+        bind = getattr(ops, "bind_mevp_iterate", None)
+        if bind is None:  # ops without a binding fast path (the CPU test stand-in)
+            bind = lambda *a: (lambda: ops.mevp_iterate(*a))
+        rng = []
+        if not split:
+            rng.append((b.k0, b.j0, b.j1))
+        else:
+            lo, hi = b.j0, b.j1
+            if b.above is not None:  # top owned element row -> the two node rows sent upwards
+                rng.append((b.j1 - 2, b.j1 - 1, b.j1))
+                hi = b.j1 - 1
+            if b.below is not None:  # bottom owned element row (+ redundant ghost-row stress) -> node row sent downwards
+                rng.append((b.j0 - 1, b.j0, b.j0 + 1))
+                lo = b.j0 + 1
+            rng.append((lo - 1 if lo > 0 else 0, lo, hi))  # interior, launched after the exchange is posted
+        calls = [bind(k0, j0, j1, self.s, self.sb, uv, uvn, self.packed, self.pg) for (k0, j0, j1) in rng]
+        self._calls[key] = calls
+        return calls
 
     def transport(self):
         ops, b = self.ops, self.blk
