@@ -64,6 +64,7 @@ SYMBOLS = {
     "nsdg_mevp_pack_nodal": (C.c_int, [VP, D] + [VP] * 9),
     "nsdg_mevp_velocity": (C.c_int, [VP, I32, I32] + [VP] * 8),
     "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32] + [VP] * 12),
+    "nsdg_mevp_iterate2": (C.c_int, [VP, I32, I32] + [VP] * 12),
     "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_occupancy_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
@@ -154,6 +155,7 @@ class Context:
         self._call(self.lib.nsdg_ctx_create(self.device.index or 0, VP(self.stream.cuda_stream), C.byref(h)))
         self.h = h
         self.nx = self.ny = 0
+        self.mevp_variant = 2  # the library default (two sub-iterations per pass)
 
     def _call(self, rc):
         if rc != 0:
@@ -226,6 +228,7 @@ class Context:
 
     def set_mevp_variant(self, variant):
         self._call(self.lib.nsdg_mevp_variant_set(self.h, variant))
+        self.mevp_variant = variant
 
     def set_mevp_strip_rows(self, rows):
         self._call(self.lib.nsdg_mevp_strip_rows_set(self.h, rows))
@@ -285,6 +288,25 @@ class Context:
         ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
         _check_f64(*ts)
         self._call(self.lib.nsdg_mevp_iterate(self.h, k0, j0, j1, *[_ptr(t) for t in ts]))
+
+    def mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        """two sub-iterations in one pass on the owned rows [j0, j1) (variant 2)"""
+        self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg)()
+
+    def bind_mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
+        _check_f64(*ts)
+        fn = self.lib.nsdg_mevp_iterate2
+        args = (self.h, I32(j0), I32(j1)) + tuple(_ptr(t) for t in ts)
+        keep = ts
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                self._call(rc)
+            return keep is None
+
+        return call
 
     def bind_mevp_iterate(self, k0, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         """Pre-validated, pre-marshalled form of mevp_iterate for inner loops: returns a zero-argument

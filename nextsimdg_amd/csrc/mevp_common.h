@@ -226,12 +226,14 @@ __device__ __forceinline__ void stress_projected(const double (&ul)[9], const do
 __device__ __forceinline__ void stress_relax(double ialpha, const double (&r11)[8], const double (&r12)[8], const double (&r22)[8],
     double (&s11)[8], double (&s12)[8], double (&s22)[8])
 {
+    // written with an explicit fma so that every kernel variant rounds the relaxation the same way
+    // (left to the compiler, the contraction differed between variants by one ulp)
     const double keep = 1. - ialpha;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s11[i] = keep * s11[i] + ialpha * r11[i];
-        s12[i] = keep * s12[i] + ialpha * r12[i];
-        s22[i] = keep * s22[i] + ialpha * r22[i];
+        s11[i] = __builtin_fma(ialpha, r11[i], keep * s11[i]);
+        s12[i] = __builtin_fma(ialpha, r12[i], keep * s12[i]);
+        s22[i] = __builtin_fma(ialpha, r22[i], keep * s22[i]);
     }
 }
 

@@ -1,0 +1,258 @@
+// mevp_fused2.hip -- variant 2 of the mEVP sub-cycle: TWO sub-iterations per kernel pass.
+//
+// The single-iteration fused kernel (mevp_fused.hip) is HBM-bound at ~87 % of the copy ceiling, so
+// the only way to go faster is to move fewer bytes.  Here the march is software-pipelined in pseudo
+// time: at march step t a lane performs
+//     A(t): sub-iteration p   on element row t      (stress S^p(t), velocity u^p at the row's owned nodes)
+//     B(t): sub-iteration p+1 on element row t - 1  (stress S^{p+1}(t-1), velocity u^{p+1})
+// B(t) needs u^p on the three node rows of element row t-1: two of them were produced by A(t-1) and are
+// still in registers, the third was produced by A(t) a moment ago.  S^p and u^p therefore never touch
+// memory: per TWO sub-iterations an element reads u,v (64 B), P (72), S (192) and the packed nodal
+// coefficients (192) once and writes S (192) and u,v (64) once -- 388 B per element-sub-iteration
+// instead of 776.
+//
+// Redundancy instead of synchronisation, one level deeper than in the single-iteration kernel: a wave
+// owns 61 of its 64 columns (lanes 0,1 recompute the two columns to its left, lane 63 the column to
+// its right) and a strip of R rows runs A on rows y0-2 .. y1 and B on rows y0-1 .. y1-1.  All
+// recomputed values are bit-identical to their owners', the stress and the velocity are written out of
+// place, and nothing is exchanged between waves.  The arithmetic is the same sequence of inlined
+// functions as in the other variants, so two passes of variant 1 and one pass of variant 2 agree to
+// the last bit.
+//
+// Row ranges: a launch updates the owned element rows [j0, j1) of the local array and reads two rows
+// below and one row above them (S, P, u: rows j0-2 .. j1, node rows 2(j0-2) .. 2*j1+2).  Where those rows
+// do not exist the edge of the local array is the physical boundary, so a rank of a row-block
+// decomposition keeps 2 ghost element rows below and 1 above and refreshes them (stress and velocity)
+// after every pass.
+#include "mevp_common.h"
+
+namespace nsdg_mevp_detail {
+
+struct StressPtrs2 {
+    const double *i11, *i12, *i22;
+    double *o11, *o12, *o22;
+};
+
+__device__ __forceinline__ double from_left(double x) { return __shfl_up(x, 1); }
+__device__ __forceinline__ double from_right(double x) { return __shfl_down(x, 1); }
+
+__global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int R, int ncw, double hx, double hy,
+    double ialpha, double dmin2, StressPtrs2 S, const double* __restrict__ u_old, const double* __restrict__ v_old,
+    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = wave / ncw, cw = wave - strip * ncw;
+    const int y0 = j0 + strip * R;
+    if (y0 >= j1)
+        return; // wave-uniform
+    const int y1 = min(y0 + R, j1);
+    const int ixr = cw * 61 - 2 + lane;
+    const bool valid = ixr >= 0 && ixr < nx;
+    const bool own = valid && lane >= 2 && lane <= 62;
+    const int ix = min(max(ixr, 0), nx - 1);
+    const bool hasL = ix > 0, lastcol = ix == nx - 1;
+    const int ntx = tiles_per_row(nx);
+    const int nn = 2 * nx + 1;
+    const double ihx = 1. / hx, ihy = 1. / hy, iarea = ihx * ihy;
+
+    // state carried from A(t-1) to B(t): everything of element row t-1 that sub-iteration p+1 needs
+    double sp11[8], sp12[8], sp22[8]; // S^p(t-1)
+    double Pk[9]; // ice strength at the Gauss points of row t-1
+    double ck[4][6]; // packed momentum coefficients of the 4 owned nodes (V, EX, EY, C) of row t-1
+    double upu[4], upv[4]; // u^p, v^p at those nodes
+    // contributions of the row below to its top nodes (6: top-left, 7: top-mid of my column, 8 of the left column)
+    double a6x = 0., a6y = 0., a7x = 0., a7y = 0., al8x = 0., al8y = 0.; // sub-iteration p   (row t-1)
+    double b6x = 0., b6y = 0., b7x = 0., b7y = 0., bl8x = 0., bl8y = 0.; // sub-iteration p+1 (row t-2)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        upu[k] = upv[k] = 0.;
+
+    const int tbeg = max(y0 - 2, 0), tend = min(y1, ny - 1); // A runs on rows tbeg .. tend
+    for (int t = tbeg; t <= tend + 1; ++t) {
+        // ------------------------------------------------------------------ A(t): sub-iteration p on row t
+        double s11[8], s12[8], s22[8], Pq[9], ct[4][6], unu[4], unv[4];
+        const bool doA = t <= tend; // the last march step only drains B
+        if (doA) {
+            const long ts = tile_off(ix, t, ntx, 8), tp = tile_off(ix, t, ntx, 9);
+            const long nV = (long)(2 * t) * nn + 2 * ix;
+            double ul[9], vl[9];
+#pragma unroll
+            for (int a = 0; a < 9; ++a) {
+                const long n = nV + (a / 3) * nn + a % 3;
+                ul[a] = u_old[n];
+                vl[a] = v_old[n];
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                Pq[q] = pg[tp + q * 64];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s11[i] = S.i11[ts + i * 64];
+                s12[i] = S.i12[ts + i * 64];
+                s22[i] = S.i22[ts + i * 64];
+            }
+            load_nodal(packed, nV, ct[0]);
+            load_nodal(packed, nV + 1, ct[1]);
+            load_nodal(packed, nV + nn, ct[2]);
+            load_nodal(packed, nV + nn + 1, ct[3]);
+            stress_update(ul, vl, Pq, ihx, ihy, ialpha, dmin2, s11, s12, s22);
+            double cx[9], cy[9];
+            node_contrib_all(s11, s12, s22, hx, hy, cx, cy);
+            const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
+            const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
+            const bool hasB = t > 0;
+            // u^p at the 4 owned nodes of row t (kept in registers; Dirichlet nodes are zero)
+            if (hasL && hasB)
+                node_update_packed(K, ct[0], ul[0], vl[0], ((al8x + a6x) + l2x) + cx[0], ((al8y + a6y) + l2y) + cy[0], 9. * iarea, unu[0], unv[0]);
+            else
+                unu[0] = unv[0] = 0.;
+            if (hasB)
+                node_update_packed(K, ct[1], ul[1], vl[1], a7x + cx[1], a7y + cy[1], 4.5 * iarea, unu[1], unv[1]);
+            else
+                unu[1] = unv[1] = 0.;
+            if (hasL)
+                node_update_packed(K, ct[2], ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, unu[2], unv[2]);
+            else
+                unu[2] = unv[2] = 0.;
+            node_update_packed(K, ct[3], ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, unu[3], unv[3]);
+            a6x = cx[6], a6y = cy[6], a7x = cx[7], a7y = cy[7];
+            al8x = from_left(cx[8]), al8y = from_left(cy[8]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                unu[k] = unv[k] = 0.; // node row 2*ny is the top boundary
+        }
+
+        // ------------------------------------------------------------------ B(t): sub-iteration p+1 on row r = t-1
+        const int r = t - 1;
+        if (r >= tbeg && r >= y0 - 1 && r < y1) { // wave-uniform
+            // u^p at the 9 nodes of element (ix, r): own nodes of rows r and t, the right neighbour's V / EY
+            double ul[9], vl[9];
+            ul[0] = upu[0], vl[0] = upv[0];
+            ul[1] = upu[1], vl[1] = upv[1];
+            ul[3] = upu[2], vl[3] = upv[2];
+            ul[4] = upu[3], vl[4] = upv[3];
+            ul[6] = unu[0], vl[6] = unv[0];
+            ul[7] = unu[1], vl[7] = unv[1];
+            const double r2u = from_right(upu[0]), r2v = from_right(upv[0]);
+            const double r5u = from_right(upu[2]), r5v = from_right(upv[2]);
+            const double r8u = from_right(unu[0]), r8v = from_right(unv[0]);
+            ul[2] = lastcol ? 0. : r2u, vl[2] = lastcol ? 0. : r2v; // node column 2*nx is the right boundary
+            ul[5] = lastcol ? 0. : r5u, vl[5] = lastcol ? 0. : r5v;
+            ul[8] = lastcol ? 0. : r8u, vl[8] = lastcol ? 0. : r8v;
+            stress_update(ul, vl, Pk, ihx, ihy, ialpha, dmin2, sp11, sp12, sp22);
+            const bool store = own && r >= y0;
+            if (store) {
+                const long ts = tile_off(ix, r, ntx, 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    S.o11[ts + i * 64] = sp11[i];
+                    S.o12[ts + i * 64] = sp12[i];
+                    S.o22[ts + i * 64] = sp22[i];
+                }
+            }
+            double cx[9], cy[9];
+            node_contrib_all(sp11, sp12, sp22, hx, hy, cx, cy);
+            const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
+            const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
+            if (r >= y0) { // wave-uniform: rows below y0 only feed the carried contributions
+                const bool hasB = r > 0;
+                const long nV = (long)(2 * r) * nn + 2 * ix;
+                double un, vn;
+                if (hasL && hasB)
+                    node_update_packed(K, ck[0], upu[0], upv[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea, un, vn);
+                else
+                    un = vn = 0.;
+                if (store)
+                    u_new[nV] = un, v_new[nV] = vn;
+                if (hasB)
+                    node_update_packed(K, ck[1], upu[1], upv[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, un, vn);
+                else
+                    un = vn = 0.;
+                if (store)
+                    u_new[nV + 1] = un, v_new[nV + 1] = vn;
+                if (hasL)
+                    node_update_packed(K, ck[2], upu[2], upv[2], l5x + cx[3], l5y + cy[3], 4.5 * iarea, un, vn);
+                else
+                    un = vn = 0.;
+                if (store)
+                    u_new[nV + nn] = un, v_new[nV + nn] = vn;
+                node_update_packed(K, ck[3], upu[3], upv[3], cx[4], cy[4], 2.25 * iarea, un, vn);
+                if (store) {
+                    u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
+                    if (lastcol) {
+                        u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
+                        u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
+                    }
+                    if (r == ny - 1) {
+                        u_new[nV + 2 * nn] = 0., v_new[nV + 2 * nn] = 0.;
+                        u_new[nV + 2 * nn + 1] = 0., v_new[nV + 2 * nn + 1] = 0.;
+                        if (lastcol)
+                            u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
+                    }
+                }
+            }
+            b6x = cx[6], b6y = cy[6], b7x = cx[7], b7y = cy[7];
+            bl8x = from_left(cx[8]), bl8y = from_left(cy[8]);
+        }
+
+        // ------------------------------------------------------------------ rotate: row t becomes "the row below"
+        if (doA) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                sp11[i] = s11[i];
+                sp12[i] = s12[i];
+                sp22[i] = s22[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                Pk[q] = Pq[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                upu[k] = unu[k];
+                upv[k] = unv[k];
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    ck[k][j] = ct[k][j];
+            }
+        }
+    }
+}
+
+} // namespace nsdg_mevp_detail
+
+using namespace nsdg_mevp_detail;
+
+// two sub-iterations on the owned rows [j0, j1) of the local array
+int nsdg_launch_mevp_fused2(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
+    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg)
+{
+    const int ncw = nsdg_div_up(ctx->nx, 61); // 61 owned columns per wave
+    int R = ctx->strip_rows;
+    if (R <= 0) {
+        // every wave marches R+3 rows of A and R+1 rows of B (~2R+4 stress updates for 2R useful ones);
+        // same round-counting rule as in the single-iteration kernel, with one resident wave per SIMD
+        const long slots = 1L * 4 * ctx->num_cus;
+        double best = 1e30;
+        R = 16;
+        for (int r = 4; r <= 256; ++r) {
+            const long waves = (long)nsdg_div_up(j1 - j0, r) * ncw;
+            const long rounds = (waves + slots - 1) / slots;
+            const double cost = rounds * (r + 2.0) + (rounds == 1 ? 2.0 : 0.0);
+            if (cost < best) {
+                best = cost;
+                R = r;
+            }
+        }
+    }
+    const int nstrips = nsdg_div_up(j1 - j0, R);
+    const long nwaves = (long)ncw * nstrips;
+    const StressPtrs2 S = { s11i, s12i, s22i, s11, s12, s22 };
+    const nsdg_mevp_params& P = ctx->mevp;
+    const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
+    hipLaunchKernelGGL(mevp_fused2_kernel, dim3(nsdg_div_up(nwaves, 4)), dim3(256), 0, ctx->stream, K, ctx->nx, ctx->ny, j0, j1, R, ncw, ctx->hx,
+        ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg, u_new, v_new);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}

@@ -28,19 +28,22 @@ def split_rows(ny, world, rank):
 
 
 class RowBlock:
-    """index bookkeeping of one rank's local array"""
+    """index bookkeeping of one rank's local array.  `depth_below` / `depth_above` are the numbers of ghost
+    element rows kept on the interior sides: (1, 1) for one mEVP sub-iteration per pass, (2, 1) for the
+    two-sub-iterations-per-pass kernel, which reads two element rows below and one above the rows it updates."""
 
-    def __init__(self, nx, ny, rank=0, world=1):
-        if ny < world:
-            raise ValueError("fewer element rows than ranks")
+    def __init__(self, nx, ny, rank=0, world=1, depth_below=1, depth_above=1):
+        if ny < world * max(depth_below, depth_above, 1) * 2:
+            raise ValueError("too few element rows per rank for the ghost depth")
         self.nx, self.ny_glob, self.rank, self.world = nx, ny, rank, world
         self.r0, self.r1 = split_rows(ny, world, rank)
-        self.gb = 1 if rank > 0 else 0  # ghost element row below
-        self.gt = 1 if rank < world - 1 else 0  # ghost element row above
+        self.gb = depth_below if rank > 0 else 0  # ghost element rows below
+        self.gt = depth_above if rank < world - 1 else 0  # ghost element rows above
+        self.depth_below, self.depth_above = depth_below, depth_above
         self.lo, self.hi = self.r0 - self.gb, self.r1 + self.gt  # global rows held locally
         self.ny = self.hi - self.lo  # local element rows
         self.j0, self.j1 = self.gb, self.ny - self.gt  # owned local rows
-        self.k0 = 0  # stress is updated from the ghost row below (if any)
+        self.k0 = max(self.j0 - 1, 0)  # single-iteration kernel: stress is updated from one ghost row below
         self.below = rank - 1 if rank > 0 else None
         self.above = rank + 1 if rank < world - 1 else None
 
@@ -52,49 +55,93 @@ class RowBlock:
 
 
 class HaloExchanger:
+    """nearest-neighbour ghost-row exchange.  All slices are contiguous row blocks of their arrays (node
+    rows of [rows, cols] lattices, element rows of tiled [ny, ntx, nc, 64] arrays), so they are sent in
+    place; only coefficient-plane arrays [nc, ny, nx] need a pack/unpack copy."""
+
     def __init__(self, blk, group=None):
         self.blk, self.group = blk, group
-        self._nodal_ops = {}
-
-    def _run(self, ops):
-        if not ops:
-            return
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-
-    def _build_nodal_ops(self, fields):
-        b = self.blk
-        ops = []
-        for f in fields:
-            if b.above is not None:
-                # my two top owned node rows become the lower ghost rows of the rank above
-                ops.append(dist.P2POp(dist.isend, f[2 * b.j1 - 2:2 * b.j1], b.above, self.group))
-                ops.append(dist.P2POp(dist.irecv, f[2 * b.j1:2 * b.j1 + 1], b.above, self.group))
-            if b.below is not None:
-                ops.append(dist.P2POp(dist.isend, f[2 * b.j0:2 * b.j0 + 1], b.below, self.group))
-                ops.append(dist.P2POp(dist.irecv, f[0:2], b.below, self.group))
-        return ops
-
-    def nodal_start(self, fields):
-        """post the ghost-node-row exchange of CG2 arrays [2ny+1, 2nx+1]; returns the requests.
-        The P2P op lists are cached per set of arrays (the sub-cycle ping-pongs between two sets)."""
-        if self.blk.world == 1:
-            return []
-        key = tuple(f.data_ptr() for f in fields)
-        ops = self._nodal_ops.get(key)
-        if ops is None:
-            ops = self._nodal_ops[key] = self._build_nodal_ops(fields)
-        return dist.batch_isend_irecv(ops) if ops else []
+        self._cache = {}
 
     @staticmethod
     def finish(reqs):
         for req in reqs:
             req.wait()
 
-    def nodal(self, fields):
-        """refresh the ghost node rows of CG2 arrays (after a velocity update), blocking form"""
-        self.finish(self.nodal_start(fields))
+    def _post(self, key, build):
+        if self.blk.world == 1:
+            return []
+        ops = self._cache.get(key)
+        if ops is None:
+            ops = self._cache[key] = build()
+        return dist.batch_isend_irecv(ops) if ops else []
 
+    # -- CG2 nodal arrays [2ny+1, 2nx+1]
+    def _nodal_ops(self, fields, rows_down):
+        b = self.blk
+        up = 2 * b.depth_below  # node rows the rank above keeps as ghosts below its first owned row
+        ops = []
+        for f in fields:
+            if b.above is not None:
+                ops.append(dist.P2POp(dist.isend, f[2 * b.j1 - up:2 * b.j1], b.above, self.group))
+                ops.append(dist.P2POp(dist.irecv, f[2 * b.j1:2 * b.j1 + rows_down], b.above, self.group))
+            if b.below is not None:
+                ops.append(dist.P2POp(dist.isend, f[2 * b.j0:2 * b.j0 + rows_down], b.below, self.group))
+                ops.append(dist.P2POp(dist.irecv, f[2 * b.j0 - up:2 * b.j0], b.below, self.group))
+        return ops
+
+    def nodal_start(self, fields, rows_down=1):
+        """post the exchange of the ghost node rows: 2*depth_below rows travel upwards, `rows_down` rows
+        (1 for the single-iteration kernel, 3 for the two-iteration kernel) downwards"""
+        key = ("n", rows_down) + tuple(f.data_ptr() for f in fields)
+        return self._post(key, lambda: self._nodal_ops(fields, rows_down))
+
+    def nodal(self, fields, rows_down=1):
+        self.finish(self.nodal_start(fields, rows_down))
+
+    # -- arrays private to the sub-cycle (stress): rows are taken with ops.private_rows(); for the tiled
+    #    device layout a row range is one contiguous block and travels in place
+    def rows_exchange_start(self, fields, rows_of):
+        b = self.blk
+        if b.world == 1:
+            return [], []
+        key = ("r",) + tuple(f.data_ptr() for f in fields)
+        plan = self._cache.get(key)
+        if plan is None:
+            sends, recvs = [], []  # (view, peer)
+            for f in fields:
+                if b.above is not None:
+                    sends.append((rows_of(f, b.j1 - b.depth_below, b.j1), b.above))
+                    if b.gt:
+                        recvs.append((rows_of(f, b.j1, b.j1 + b.gt), b.above))
+                if b.below is not None:
+                    if b.depth_above:
+                        sends.append((rows_of(f, b.j0, b.j0 + b.depth_above), b.below))
+                    recvs.append((rows_of(f, b.j0 - b.gb, b.j0), b.below))
+            plan = self._cache[key] = (sends, recvs)
+        sends, recvs = plan
+        ops, unpack = [], []
+        for view, peer in sends:
+            ops.append(dist.P2POp(dist.isend, view if view.is_contiguous() else view.contiguous(), peer, self.group))
+        for view, peer in recvs:
+            if view.is_contiguous():
+                ops.append(dist.P2POp(dist.irecv, view, peer, self.group))
+            else:
+                buf = torch.empty(view.shape, dtype=view.dtype, device=view.device)
+                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
+                unpack.append((view, buf))
+        # isend/irecv must be posted in one consistent order on both sides: all sends of a peer pair are matched
+        # with the recvs in list order (fields in order, upward before downward)
+        return (dist.batch_isend_irecv(ops) if ops else []), unpack
+
+    @staticmethod
+    def rows_exchange_finish(reqs, unpack):
+        for req in reqs:
+            req.wait()
+        for view, buf in unpack:
+            view.copy_(buf)
+
+    # -- coefficient planes [nc, ny, nx] (advected fields): pack, exchange, unpack
     def element(self, fields):
         """refresh the ghost element rows of DG arrays [nc, ny, nx] (after a transport stage)"""
         b = self.blk
@@ -103,20 +150,23 @@ class HaloExchanger:
         ops, unpack = [], []
         for f in fields:
             if b.above is not None:
-                sbuf = f[:, b.j1 - 1, :].contiguous()
-                rbuf = torch.empty_like(sbuf)
+                sbuf = f[:, b.j1 - b.depth_below:b.j1, :].contiguous()
                 ops.append(dist.P2POp(dist.isend, sbuf, b.above, self.group))
-                ops.append(dist.P2POp(dist.irecv, rbuf, b.above, self.group))
-                unpack.append((f, b.j1, rbuf))
+                if b.gt:
+                    rbuf = torch.empty_like(f[:, b.j1:b.j1 + b.gt, :].contiguous())
+                    ops.append(dist.P2POp(dist.irecv, rbuf, b.above, self.group))
+                    unpack.append((f, slice(b.j1, b.j1 + b.gt), rbuf))
             if b.below is not None:
-                sbuf = f[:, b.j0, :].contiguous()
-                rbuf = torch.empty_like(sbuf)
-                ops.append(dist.P2POp(dist.isend, sbuf, b.below, self.group))
+                if b.depth_above:
+                    sbuf = f[:, b.j0:b.j0 + b.depth_above, :].contiguous()
+                    ops.append(dist.P2POp(dist.isend, sbuf, b.below, self.group))
+                rbuf = torch.empty_like(f[:, b.j0 - b.gb:b.j0, :].contiguous())
                 ops.append(dist.P2POp(dist.irecv, rbuf, b.below, self.group))
-                unpack.append((f, 0, rbuf))
-        self._run(ops)
-        for f, row, rbuf in unpack:
-            f[:, row, :] = rbuf
+                unpack.append((f, slice(b.j0 - b.gb, b.j0), rbuf))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for f, rows, rbuf in unpack:
+            f[:, rows, :] = rbuf
 
 
 class DynamicsCore:
@@ -132,6 +182,8 @@ class DynamicsCore:
         self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
         self.overlap = overlap
         self._calls = {}
+        # two sub-iterations per pass need the (2, 1) ghost depth; a single domain has no ghosts at all
+        self.two_per_pass = getattr(ops, "mevp_variant", None) == 2 and (blk.world == 1 or (blk.depth_below, blk.depth_above) == (2, 1))
         self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
         nx, ny = blk.nx, blk.ny
         z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
@@ -177,13 +229,34 @@ class DynamicsCore:
         self.v0.copy_(self.v)
         ops.mevp_pack_nodal(self.dt, (self.u0, self.v0), (self.tax, self.tay), (self.uo, self.vo), self.cgh, self.cga,
                             self.packed)
-        split = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 4
-        for _ in range(self.nsub):
+        it = 0
+        if self.two_per_pass:
+            # two sub-iterations per pass (intermediate stress / velocity stay in registers); with several
+            # ranks the ghost rows of the new stress and velocity are refreshed after every pass
+            split2 = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 8
+            while it + 1 < self.nsub:
+                calls = self._iterate2_calls(split2)
+                for c in calls[:-1]:
+                    c()
+                pending = self._ghost_exchange_start() if split2 else None
+                calls[-1]()
+                if pending is None:
+                    pending = self._ghost_exchange_start()
+                self._ghost_exchange_finish(pending)
+                self.u, self.ub = self.ub, self.u
+                self.v, self.vb = self.vb, self.v
+                self.s, self.sb = self.sb, self.s
+                it += 2
+        split = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 4 and not self.two_per_pass
+        for _ in range(self.nsub - it):
             uvn = (self.ub, self.vb)
             calls = self._iterate_calls(split)
             if not split:
                 calls[0]()
-                self.halo.nodal(uvn)
+                if self.two_per_pass:  # keep the deeper ghost zones of the two-iteration passes consistent
+                    self._ghost_exchange_finish(self._ghost_exchange_start())
+                else:
+                    self.halo.nodal(uvn)
             else:
                 # boundary rows first, so that their node rows travel while the interior is computed:
                 # the exchange is posted after the boundary launches and before the interior launch, the
@@ -196,6 +269,44 @@ class DynamicsCore:
             self.u, self.ub = self.ub, self.u
             self.v, self.vb = self.vb, self.v
             self.s, self.sb = self.sb, self.s
+
+    def _ghost_exchange_start(self):
+        """two-iterations-per-pass ghost zones: velocity node rows (4 up, 3 down) and stress rows (2 up, 1 down)"""
+        if self.blk.world == 1:
+            return None
+        reqs = self.halo.nodal_start((self.ub, self.vb), rows_down=3)
+        sreqs, unpack = self.halo.rows_exchange_start(self.sb, self.ops.private_rows)
+        return reqs + sreqs, unpack
+
+    def _ghost_exchange_finish(self, pending):
+        if pending is not None:
+            self.halo.rows_exchange_finish(*pending)
+
+    def _iterate2_calls(self, split):
+        """launches of one two-iteration pass for the current ping-pong parity (bound once, cached):
+        the rows whose results travel to the neighbours first, the interior last"""
+        key = (self.u.data_ptr(), self.s[0].data_ptr(), split, 2)
+        calls = self._calls.get(key)
+        if calls is not None:
+            return calls
+        ops, b = self.ops, self.blk
+        uv, uvn = (self.u, self.v), (self.ub, self.vb)
+        bind = getattr(ops, "bind_mevp_iterate2", None)
+        if bind is None:
+            bind = lambda *a: (lambda: ops.mevp_iterate2(*a))
+        rng = []
+        lo, hi = b.j0, b.j1
+        if split:
+            if b.above is not None:  # top 2 owned element rows: 2 stress rows + 4 node rows go up
+                rng.append((b.j1 - 2, b.j1))
+                hi = b.j1 - 2
+            if b.below is not None:  # bottom 2 owned element rows: 1 stress row + 3 node rows go down
+                rng.append((b.j0, b.j0 + 2))
+                lo = b.j0 + 2
+        rng.append((lo, hi))
+        calls = [bind(j0, j1, self.s, self.sb, uv, uvn, self.packed, self.pg) for (j0, j1) in rng]
+        self._calls[key] = calls
+        return calls
 
     def _iterate_calls(self, split):
         """the launches of one sub-iteration for the current ping-pong parity, bound once and cached"""
@@ -210,7 +321,7 @@ class DynamicsCore:
             bind = lambda *a: (lambda: ops.mevp_iterate(*a))
         rng = []
         if not split:
-            rng.append((b.k0, b.j0, b.j1))
+            rng.append((b.k0, b.j0, b.j1))  # k0 = j0 - 1: the ghost row just below is updated redundantly
         else:
             lo, hi = b.j0, b.j1
             if b.above is not None:  # top owned element row -> the two node rows sent upwards

@@ -12,9 +12,10 @@ def _np(t):
 
 
 class OracleOps:
-    def __init__(self, **mevp):
+    def __init__(self, mevp_variant=1, **mevp):
         self.p = O.mevp_params(**mevp)
         self.cp = O.column_params()
+        self.mevp_variant = mevp_variant  # 2: the driver uses mevp_iterate2 (two sub-iterations per pass)
 
     def column_step(self, dt, state, forcing, newice, diag=None):
         # plane views ([ny, nx] slices of the DG arrays) are contiguous: flatten without copying
@@ -58,6 +59,23 @@ class OracleOps:
         O.mevp_stress(self.nx, self.ny, k0, j1, self.hx, self.hy, self.p, _np(uv_old[0]), _np(uv_old[1]), _np(pg), *so)
         O.mevp_velocity(self.nx, self.ny, j0, j1, self.hx, self.hy, dt, self.p, so, [_np(x) for x in uv_old],
                         [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga)
+
+    def mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        """two sub-iterations on the owned rows [j0, j1), reading two rows below / one above, exactly the
+        dependency region of the two-iterations-per-pass kernel (csrc/mevp_fused2.hip)"""
+        dt, u0v0, tau, ocean, cgh, cga = self.nodal
+        ny = self.ny
+        a0, a1 = max(j0 - 2, 0), min(j1, ny - 1)  # rows of sub-iteration p
+        sp = [_np(x).copy() for x in s_in]
+        uo = [_np(x) for x in uv_old]
+        O.mevp_stress(self.nx, ny, a0, a1 + 1, self.hx, self.hy, self.p, uo[0], uo[1], _np(pg), *sp)
+        up = [x.copy() for x in uo]
+        O.mevp_velocity(self.nx, ny, max(j0 - 1, 0), a1 + 1, self.hx, self.hy, dt, self.p, sp, uo, up, u0v0, tau, ocean, cgh, cga)
+        O.mevp_stress(self.nx, ny, max(j0 - 1, 0), j1, self.hx, self.hy, self.p, up[0], up[1], _np(pg), *sp)
+        for a, b in zip(sp, s_out):
+            _np(b)[:, j0:j1] = a[:, j0:j1]
+        O.mevp_velocity(self.nx, ny, j0, j1, self.hx, self.hy, dt, self.p, sp, up, [_np(x) for x in uv_new], u0v0, tau, ocean,
+                        cgh, cga)
 
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):
         res = O.prepare_advection(self.nx, self.ny, order, _np(u), _np(v))

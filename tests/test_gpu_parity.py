@@ -271,7 +271,7 @@ def test_mevp_single_iteration_matches_oracle(ctx, variant):
         assert_close(thost(d, nx), o, 1e-12, 1e-12 * np.max(np.abs(o)), name)
     assert_close(host(dun), un, 1e-11, 1e-13 * np.max(np.abs(un)), "u_new")
     assert_close(host(dvn), vn, 1e-11, 1e-13 * np.max(np.abs(vn)), "v_new")
-    ctx.set_mevp_variant(1)
+    ctx.set_mevp_variant(2)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -300,7 +300,7 @@ def test_mevp_subcycle_matches_oracle(ctx, variant):
     # Dirichlet rows/columns are exactly zero
     g = host(du)
     assert np.all(g[0] == 0) and np.all(g[-1] == 0) and np.all(g[:, 0] == 0) and np.all(g[:, -1] == 0)
-    ctx.set_mevp_variant(1)
+    ctx.set_mevp_variant(2)
 
 
 def test_mevp_row_block_equals_full_domain_bitwise(ctx):
@@ -334,7 +334,7 @@ def test_mevp_row_block_equals_full_domain_bitwise(ctx):
             assert torch.equal(f[lo:], p)  # tiled arrays: element rows are the leading dimension
         assert torch.equal(un[2 * r0:], pun[2:])
         assert torch.equal(vn[2 * r0:], pvn[2:])
-    ctx.set_mevp_variant(1)
+    ctx.set_mevp_variant(2)
 
 
 def test_mevp_fused_strip_size_does_not_change_results(ctx):
@@ -361,7 +361,7 @@ def test_mevp_fused_strip_size_does_not_change_results(ctx):
             assert torch.equal(a, c)
     for a, c in zip(results[0], results[1]):
         assert_close(host(c), host(a), 1e-12, 1e-13 * float(a.abs().max()), "fused vs two-kernel")
-    ctx.set_mevp_variant(1)
+    ctx.set_mevp_variant(2)
     ctx.set_mevp_strip_rows(0)
 
 
@@ -420,3 +420,93 @@ def test_coupled_step_matches_oracle(ctx):
         assert_close(a, b, 1e-9, 1e-11 * np.max(np.abs(b)), "coupled " + name)
     assert_close(g.col["tice0"].cpu().numpy(), o.col["tice0"].numpy(), 1e-10, 1e-12, "coupled tice0")
     ctx.set_mevp_params(ctx.mevp_default_params())
+
+
+def test_mevp_two_iterations_per_pass_equals_two_single_passes_bitwise(ctx):
+    """variant 2 keeps the intermediate stress / velocity of a pair of sub-iterations in registers;
+    it must reproduce two launches of the single-iteration fused kernel bit for bit, for any strip
+    height, and agree with the oracle"""
+    for (nx, ny) in ((130, 45), (61, 9), (200, 3)):
+        b = Box(ctx, nx, ny)
+        rng = np.random.default_rng(37)
+        u, v, s = mevp_state(b, rng)
+        pg_o = O.ice_strength(nx, ny, b.po, b.H, b.A)
+        cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+        tax, tay = O.wind_stress(b.po, b.ua, b.va)
+        packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
+        pg = tdev(pg_o)
+        s_in = [tdev(x) for x in s]
+        # reference: two single-iteration passes
+        ctx.set_mevp_variant(1)
+        ctx.set_mevp_strip_rows(0)
+        mid = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+        ctx.mevp_iterate(0, 0, ny, s_in, mid[:3], (dev(u), dev(v)), (mid[3], mid[4]), packed, pg)
+        ref = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+        ctx.mevp_iterate(0, 0, ny, mid[:3], ref[:3], (mid[3], mid[4]), (ref[3], ref[4]), packed, pg)
+        ctx.set_mevp_variant(2)
+        for rows in (1, 4, 7, 16, 64, 0):
+            ctx.set_mevp_strip_rows(rows)
+            out = [torch.zeros_like(x) for x in s_in] + [torch.full_like(dev(u), 7.0), torch.full_like(dev(v), 7.0)]
+            ctx.mevp_iterate2(0, ny, s_in, out[:3], (dev(u), dev(v)), (out[3], out[4]), packed, pg)
+            for a, c in zip(ref, out):
+                assert torch.equal(a, c), (nx, ny, rows)
+        # and against the oracle
+        so = [x.copy() for x in s]
+        uo_, vo_ = u.copy(), v.copy()
+        O.mevp_subcycle(nx, ny, b.bt.hx, b.bt.hy, 120.0, 2, b.po, so, uo_, vo_, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga, pg_o)
+        assert_close(host(ref[3]), uo_, 1e-10, 1e-12 * np.max(np.abs(uo_)), "u after two sub-iterations")
+        assert_close(thost(ref[0], nx), so[0], 1e-10, 1e-12 * np.max(np.abs(so[0])), "s11 after two sub-iterations")
+    ctx.set_mevp_variant(2)
+    ctx.set_mevp_strip_rows(0)
+
+
+def test_mevp_subcycle_variant2_matches_oracle(ctx):
+    ctx.set_mevp_variant(2)
+    b = Box(ctx, 48, 40, alpha=300.0, beta=300.0)
+    nx, ny = b.nx, b.ny
+    pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
+    cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+    tax, tay = O.wind_stress(b.po, b.ua, b.va)
+    shape = (2 * ny + 1, 2 * nx + 1)
+    u, v = np.zeros(shape), np.zeros(shape)
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    du, dv, ds = dev(u), dev(v), [tdev(x) for x in s]
+    scratch = torch.zeros(10 * u.size + 3 * ds[0].numel(), dtype=torch.float64, device="cuda")
+    nsub = 25  # 12 double passes + one single sub-iteration
+    ctx.mevp_subcycle(120.0, nsub, ds, du, dv, dev(u.copy()), dev(v.copy()), dev(tax), dev(tay), dev(b.uo), dev(b.vo), dev(cgh),
+                      dev(cga), tdev(pg), scratch)
+    O.mevp_subcycle(nx, ny, b.bt.hx, b.bt.hy, 120.0, nsub, b.po, s, u, v, u.copy(), v.copy(), tax, tay, b.uo, b.vo, cgh, cga, pg)
+    assert_close(host(du), u, 1e-9, 1e-11 * np.max(np.abs(u)), "u after subcycle (variant 2)")
+    assert_close(thost(ds[0], nx), s[0], 1e-9, 1e-10 * np.max(np.abs(s[0])), "s11 after subcycle (variant 2)")
+    ctx.set_mevp_variant(2)
+
+
+def test_mevp_two_per_pass_row_block_equals_full_domain_bitwise(ctx):
+    """variant 2 on a row-block sub-domain (2 ghost element rows below, 1 above, as the multi-rank driver
+    keeps them) reproduces the full-domain pass bit for bit on the rows it owns"""
+    ctx.set_mevp_variant(2)
+    b = Box(ctx, 90, 40)
+    nx, ny = b.nx, b.ny
+    rng = np.random.default_rng(53)
+    u, v, s = mevp_state(b, rng)
+    pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
+    cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+    tax, tay = O.wind_stress(b.po, b.ua, b.va)
+    packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
+    full = [torch.zeros_like(tdev(x)) for x in s] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+    ctx.mevp_iterate2(0, ny, [tdev(x) for x in s], full[:3], (dev(u), dev(v)), (full[3], full[4]), packed, tdev(pg))
+    # middle rank: owns global rows [14, 27); local array = rows [12, 28)
+    r0, r1 = 14, 27
+    lo, hi = r0 - 2, r1 + 1
+    sl_e = lambda a: np.ascontiguousarray(a[:, lo:hi])
+    sl_n = lambda a: np.ascontiguousarray(a[2 * lo:2 * hi + 1])
+    ctx.set_grid(nx, hi - lo, b.bt.hx, b.bt.hy)
+    ppacked = pack(ctx, 120.0, *[sl_n(x) for x in (0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)])
+    part = [torch.zeros_like(tdev(sl_e(x))) for x in s] + [torch.zeros_like(dev(sl_n(u))), torch.zeros_like(dev(sl_n(v)))]
+    for (j0, j1) in ((2, 4), (4, 10), (10, r1 - lo)):  # three launches over row ranges, like the overlapping driver
+        ctx.mevp_iterate2(j0, j1, [tdev(sl_e(x)) for x in s], part[:3], (dev(sl_n(u)), dev(sl_n(v))), (part[3], part[4]), ppacked,
+                          tdev(sl_e(pg)))
+    for k in range(3):
+        assert torch.equal(full[k][r0:r1], part[k][2:2 + r1 - r0])
+    for k in (3, 4):
+        assert torch.equal(full[k][2 * r0:2 * r1], part[k][4:4 + 2 * (r1 - r0)])

@@ -38,7 +38,7 @@ def column_fields_2d(seed=5):
     return f
 
 
-def run_core(rank, world, overlap=True, coupled=False):
+def run_core(rank, world, overlap=True, coupled=False, variant=1):
     from oracle_ops import OracleOps
 
     bt = synthetic.BoxTest(NX, NY)
@@ -48,9 +48,11 @@ def run_core(rank, world, overlap=True, coupled=False):
     H[1:3] += 0.02 * rng.standard_normal((2, NY, NX))
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
-    blk = rowblock.RowBlock(NX, NY, rank, world)
+    depth = (2, 1) if variant == 2 else (1, 1)
+    blk = rowblock.RowBlock(NX, NY, rank, world, *depth)
     cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
-    core = cls(OracleOps(alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"), overlap=overlap)
+    core = cls(OracleOps(mevp_variant=variant, alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"),
+               overlap=overlap)
     core.load_global(H, A, uo, vo, 3.0 * ua, 3.0 * va)
     if coupled:
         core.load_column(column_fields_2d())
@@ -59,12 +61,12 @@ def run_core(rank, world, overlap=True, coupled=False):
     return core
 
 
-def worker(rank, world, port, outdir, overlap=True, coupled=False):
+def worker(rank, world, port, outdir, overlap=True, coupled=False, variant=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        core = run_core(rank, world, overlap, coupled)
+        core = run_core(rank, world, overlap, coupled, variant)
         out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
         out["s11"] = core.owned(core.s[0]).clone()
         if coupled:
@@ -80,6 +82,8 @@ def test_rowblock_index_bookkeeping():
     for world in (1, 2, 3, 8):
         rows = []
         for r in range(world):
+            d = rowblock.RowBlock(16, 37, r, world, 2, 1)
+            assert (d.gb, d.gt) == (2 if r > 0 else 0, 1 if r < world - 1 else 0) and d.k0 == max(d.j0 - 1, 0)
             b = rowblock.RowBlock(16, 37, r, world)
             assert b.ny == (b.r1 - b.r0) + b.gb + b.gt
             assert (b.j0, b.j1) == (b.gb, b.ny - b.gt)
@@ -91,14 +95,17 @@ def test_rowblock_index_bookkeeping():
         rowblock.RowBlock(4, 2, 0, 3)
 
 
-@pytest.mark.parametrize("world,overlap", [(2, True), (3, True), (3, False)])
-def test_row_block_run_equals_single_domain_bitwise(world, overlap, tmp_path):
+@pytest.mark.parametrize("world,overlap,variant", [(2, True, 1), (3, True, 1), (3, False, 1), (2, True, 2), (3, True, 2), (3, False, 2)])
+def test_row_block_run_equals_single_domain_bitwise(world, overlap, variant, tmp_path):
     """overlap=True: boundary rows are computed and sent first, the interior follows (3 launches per
     sub-iteration); overlap=False: one launch then a blocking exchange.  Both must equal the 1-rank run."""
-    ref = run_core(0, 1)
+    ref = run_core(0, 1, variant=variant)  # NSUB = 5: two double passes + one single sub-iteration for variant 2
     assert float(ref.u.abs().max()) > 1e-5
+    if variant == 2:
+        one = run_core(0, 1, variant=1)  # pass structure does not change the arithmetic
+        assert torch.equal(one.u, ref.u) and torch.equal(one.s[0], ref.s[0]) and torch.equal(one.H, ref.H)
     port = free_port()
-    mp.spawn(worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, str(tmp_path), overlap, False, variant), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
     for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):  # oracle ops keep [nc, ny, nx] planes
         got = torch.cat([p[key] for p in parts], dim=1)
@@ -111,10 +118,10 @@ def test_row_block_run_equals_single_domain_bitwise(world, overlap, tmp_path):
 
 def test_coupled_thermodynamics_dynamics_row_blocks(tmp_path):
     """BASELINE config 5 in miniature: column physics + dynamics per step, 2 ranks == 1 rank bitwise"""
-    ref = run_core(0, 1, coupled=True)
+    ref = run_core(0, 1, coupled=True, variant=2)
     assert float((ref.A[0] - 1.0).abs().max()) > 1e-3  # the thermodynamics changed the concentration
     port = free_port()
-    mp.spawn(worker, args=(2, port, str(tmp_path), True, True), nprocs=2, join=True)
+    mp.spawn(worker, args=(2, port, str(tmp_path), True, True, 2), nprocs=2, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2)]
     for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
         assert torch.equal(torch.cat([p[key] for p in parts], dim=1), full), key
