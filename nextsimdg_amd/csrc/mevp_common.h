@@ -42,6 +42,37 @@ __device__ __forceinline__ long tile_off(int ix, int iy, int ntx, int nc)
 //   int p_a L_n  / m_a :  a=0: (1, 4, 1)/6       a=1: (-1, 0, 1)       a=2: (2, -4, 2)
 // and the same without the 1/m_a for the divergence.  tests compare against the oracle's dense,
 // quadrature-built operators.
+// Division-free elementary functions for the hot loop.  The hardware seeds (v_rcp_f64, v_rsq_f64) are
+// refined by Newton steps to full double accuracy (relative error <~ 2e-16, not correctly rounded);
+// the library routines add range scaling and special-case handling (v_div_scale/fmas/fixup, v_ldexp,
+// v_cmp_class) that the mEVP operands never need: the arguments are finite, positive and far from the
+// subnormal range (Delta^2 >= Delta_min^2 = 4e-18; denominators >= rho h_min/dt).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    // y <- y + y*(1 - x y^2)/2, twice
+    double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    // sqrt(x) = x * rsqrt(x), one Goldschmidt-style correction on the product; exact zero stays zero
+    const double y = fast_rsqrt(x);
+    double g = x * y;
+    g = __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);
+    return x > 0. ? g : 0.;
+}
+
 constexpr double SF_G = 0.3872983346207417; // Gauss abscissa sqrt(3/5)/2 on [-1/2, 1/2]
 constexpr double SF_P2E = 1. / 15.; // p2 at the outer Gauss points
 constexpr double SF_P2M = -1. / 12.; // p2 at the middle Gauss point
@@ -86,23 +117,21 @@ __device__ __forceinline__ void sf_grad(const double (&U)[9], double (&dxi)[8], 
 __device__ __forceinline__ void sf_eval(const double (&c)[8], double (&V)[9])
 {
     double T0[3], T1[3], T2[3]; // T_b[qx] = sum_a C[a][b] p_a(xi_qx)
+    // every output is one fused expression: S -+ g*c = fma(-+g, c, S)
     {
-        const double S = c[0] + SF_P2E * c[3], D = SF_G * c[1];
-        T0[0] = S - D, T0[2] = S + D, T0[1] = c[0] + SF_P2M * c[3];
+        const double S = c[0] + SF_P2E * c[3];
+        T0[0] = S - SF_G * c[1], T0[2] = S + SF_G * c[1], T0[1] = c[0] + SF_P2M * c[3];
     }
     {
-        const double S = c[2] + SF_P2E * c[6], D = SF_G * c[5];
-        T1[0] = S - D, T1[2] = S + D, T1[1] = c[2] + SF_P2M * c[6];
+        const double S = c[2] + SF_P2E * c[6];
+        T1[0] = S - SF_G * c[5], T1[2] = S + SF_G * c[5], T1[1] = c[2] + SF_P2M * c[6];
     }
-    {
-        const double D = SF_G * c[7];
-        T2[0] = c[4] - D, T2[2] = c[4] + D, T2[1] = c[4];
-    }
+    T2[0] = c[4] - SF_G * c[7], T2[2] = c[4] + SF_G * c[7], T2[1] = c[4];
 #pragma unroll
     for (int qx = 0; qx < 3; ++qx) {
-        const double S = T0[qx] + SF_P2E * T2[qx], D = SF_G * T1[qx];
-        V[qx] = S - D;
-        V[6 + qx] = S + D;
+        const double S = T0[qx] + SF_P2E * T2[qx];
+        V[qx] = S - SF_G * T1[qx];
+        V[6 + qx] = S + SF_G * T1[qx];
         V[3 + qx] = T0[qx] + SF_P2M * T2[qx];
     }
 }
@@ -144,25 +173,16 @@ __device__ __forceinline__ void sf_project(const double (&t)[9], double (&R)[8])
 __device__ __forceinline__ void sf_gxi(const double (&c)[8], double (&G)[9])
 {
     double X0[3], X1[3], X2[3]; // X_b[ax]
-    {
-        const double t = c[1] * (1. / 3.);
-        X0[0] = t - c[0], X0[1] = -2. * t, X0[2] = t + c[0];
-    }
-    {
-        const double t = c[5] * (1. / 3.);
-        X1[0] = t - c[2], X1[1] = -2. * t, X1[2] = t + c[2];
-    }
-    {
-        const double t = c[7] * (1. / 3.);
-        X2[0] = t - c[4], X2[1] = -2. * t, X2[2] = t + c[4];
-    }
+    constexpr double T3 = 1. / 3.;
+    X0[0] = c[1] * T3 - c[0], X0[1] = c[1] * (-2. * T3), X0[2] = c[1] * T3 + c[0];
+    X1[0] = c[5] * T3 - c[2], X1[1] = c[5] * (-2. * T3), X1[2] = c[5] * T3 + c[2];
+    X2[0] = c[7] * T3 - c[4], X2[1] = c[7] * (-2. * T3), X2[2] = c[7] * T3 + c[4];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        const double p = X0[ax] * (1. / 6.), q = X1[ax] * (1. / 12.), r = X2[ax] * (1. / 90.);
-        const double pr = p + r;
-        G[ax] = pr - q;
-        G[3 + ax] = 4. * p - 2. * r;
-        G[6 + ax] = pr + q;
+        const double pr = X0[ax] * (1. / 6.) + X2[ax] * (1. / 90.);
+        G[ax] = pr - X1[ax] * (1. / 12.);
+        G[3 + ax] = X0[ax] * (4. / 6.) - X2[ax] * (2. / 90.);
+        G[6 + ax] = pr + X1[ax] * (1. / 12.);
     }
 }
 
@@ -171,21 +191,18 @@ __device__ __forceinline__ void sf_geta(const double (&c)[8], double (&G)[9])
 {
     double X0[3], X1[3]; // X_b[ax], b = 0, 1
     {
-        const double p = c[0] * (1. / 6.), q = c[1] * (1. / 12.), r = c[3] * (1. / 90.);
-        const double pr = p + r;
-        X0[0] = pr - q, X0[1] = 4. * p - 2. * r, X0[2] = pr + q;
+        const double pr = c[0] * (1. / 6.) + c[3] * (1. / 90.);
+        X0[0] = pr - c[1] * (1. / 12.), X0[1] = c[0] * (4. / 6.) - c[3] * (2. / 90.), X0[2] = pr + c[1] * (1. / 12.);
     }
     {
-        const double p = c[2] * (1. / 6.), q = c[5] * (1. / 12.), r = c[6] * (1. / 90.);
-        const double pr = p + r;
-        X1[0] = pr - q, X1[1] = 4. * p - 2. * r, X1[2] = pr + q;
+        const double pr = c[2] * (1. / 6.) + c[6] * (1. / 90.);
+        X1[0] = pr - c[5] * (1. / 12.), X1[1] = c[2] * (4. / 6.) - c[6] * (2. / 90.), X1[2] = pr + c[5] * (1. / 12.);
     }
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        const double t = X1[ax] * (1. / 3.);
-        G[ax] = t - X0[ax];
-        G[3 + ax] = -2. * t;
-        G[6 + ax] = t + X0[ax];
+        G[ax] = X1[ax] * (1. / 3.) - X0[ax];
+        G[3 + ax] = X1[ax] * (-2. / 3.);
+        G[6 + ax] = X1[ax] * (1. / 3.) + X0[ax];
     }
 }
 
@@ -213,7 +230,7 @@ __device__ __forceinline__ void stress_projected(const double (&ul)[9], const do
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         const double d2 = dmin2 + 1.25 * (e11[q] * e11[q] + e22[q] * e22[q]) + 1.5 * e11[q] * e22[q] + e12[q] * e12[q];
-        const double pd = P[q] * rsqrt(d2);
+        const double pd = P[q] * fast_rsqrt(d2);
         t11[q] = pd * (0.625 * e11[q] + 0.375 * e22[q]) - 0.5 * P[q];
         t22[q] = pd * (0.625 * e22[q] + 0.375 * e11[q]) - 0.5 * P[q];
         t12[q] = pd * 0.25 * e12[q];
@@ -299,8 +316,8 @@ __device__ __forceinline__ void node_update_packed(const NodalConsts& K, const d
     double divy, double ilumped, double& un, double& vn)
 {
     const double du = c[4] - uu, dv = c[5] - vv;
-    const double drag = c[1] * sqrt(du * du + dv * dv);
-    const double denom = 1. / (K.k2 * c[0] + drag);
+    const double drag = c[1] * fast_sqrt(du * du + dv * dv);
+    const double denom = fast_rcp(K.k2 * c[0] + drag);
     const double c1 = K.k1 * c[0], cor = K.k3 * c[0];
     un = denom * (c1 * uu + c[2] + drag * c[4] + cor * vv + divx * ilumped);
     vn = denom * (c1 * vv + c[3] + drag * c[5] - cor * uu + divy * ilumped);
