@@ -145,7 +145,8 @@ def column_bench(args, device):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["dynamics", "column"], default="dynamics")
+    ap.add_argument("--workload", choices=["dynamics", "column", "coupled"], default="dynamics",
+                    help="dynamics (default, BASELINE metric), column physics only, or dynamics + column thermodynamics (config 5)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -200,7 +201,13 @@ def main():
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
     depth = (2, 1) if ctx.mevp_variant == 2 else (1, 1)  # ghost element rows below / above
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
-    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, device)
+    coupled = args.workload == "coupled"
+    core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device)
+    if coupled:  # seeded thermodynamic forcing of SURVEY.md section 8(d), held constant in time; calm wind over most of the box
+        cs, cf, _ = synthetic.column_fields(nx * ny)
+        col = {k: v.reshape(ny, nx) for k, v in {**cs, **cf}.items() if k not in ("hice", "cice")}
+        core.load_column(col)
+        del cs, cf, col
     H, A = bt.dg_fields()
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
@@ -246,7 +253,7 @@ def main():
             "metric": "element-steps/sec (dynamics+transport)", "value": value, "unit": "element-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
+            "config": {"workload": ("column thermodynamics + " if coupled else "") + "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
                                    "512 km box test, dt=120 s, alpha=beta=%.0f (stability bound of the mesh)" % (nx, ny, nsub, alpha),
                        "decomposition": "%d row block(s), ghost-row send/recv" % world,
                        "mevp_passes": "two sub-iterations per kernel pass" if core.two_per_pass else "one sub-iteration per kernel pass",

@@ -46,4 +46,31 @@ private:
     static char**& argv();
 };
 
+
+// ConfiguredModule.hpp -- applies the [Modules] section of the configuration to the ModuleLoader
+// (reference: core/src/ConfiguredModule.cpp:19-61).  Keys are "Modules.<fully qualified interface>",
+// values implementation names; an unknown module key is ignored, an unknown implementation of a
+// known module throws std::domain_error.
+class ConfiguredModule {
+public:
+    static const std::string MODULE_PREFIX;
+    static void parseConfigurator();
+    static std::string addPrefix(const std::string& moduleName);
+};
+
+// CommandLineParser.hpp -- the three command-line options of the executable, as in the reference
+// (core/src/CommandLineParser.cpp:23-61): --help/-h, --config-file F, --config-files F1 F2 ...;
+// the file names are returned in command-line order.  Anything else is left for Configurator.
+class CommandLineParser {
+public:
+    CommandLineParser(int argc, char* argv[]);
+    std::vector<std::string> getConfigFileNames() const { return m_configFilenames; }
+    bool helpRequested() const { return m_help; }
+    static std::string helpText();
+
+private:
+    std::vector<std::string> m_configFilenames;
+    bool m_help = false;
+};
+
 } // namespace Nextsim

@@ -18,7 +18,7 @@
 #include <vector>
 
 #include "Configured.hpp"
-#include "IModelStep.hpp"
+#include "Iterator.hpp"
 
 struct nsdg_ctx;
 

@@ -9,7 +9,7 @@
 #pragma once
 #include <vector>
 
-#include "IModelStep.hpp"
+#include "Iterator.hpp"
 
 struct nsdg_ctx;
 

@@ -13,6 +13,33 @@
 
 namespace Nextsim {
 
+//! The element cursor of a structure S (protocol of core/src/modules/include/IStructure.hpp:96-122), kept
+//! outside the interface so that any container with resetCursor / validCursor / cursorData / incrCursor can use it.
+template <class S, class E> class StructureCursor {
+public:
+    explicit StructureCursor(S& structure)
+        : m_s(structure)
+    {
+    }
+    S& operator=(const int position) const
+    {
+        if (position == 0)
+            m_s.resetCursor();
+        return m_s;
+    }
+    operator bool() const { return m_s.validCursor(); }
+    E& operator*() const { return m_s.cursorData(); }
+    E* operator->() const { return &m_s.cursorData(); }
+    S& operator++() const
+    {
+        m_s.incrCursor();
+        return m_s;
+    }
+
+private:
+    S& m_s;
+};
+
 class IStructure {
 public:
     IStructure()
@@ -48,30 +75,8 @@ public:
     virtual ElementData& cursorData() = 0;
     virtual void incrCursor() = 0;
 
-    class Cursor {
-    public:
-        explicit Cursor(IStructure& o)
-            : owner(o)
-        {
-        }
-        IStructure& operator=(const int i) const
-        {
-            if (i == 0)
-                owner.resetCursor();
-            return owner;
-        }
-        operator bool() const { return owner.validCursor(); }
-        ElementData& operator*() const { return owner.cursorData(); }
-        ElementData* operator->() const { return &owner.cursorData(); }
-        IStructure& operator++() const
-        {
-            owner.incrCursor();
-            return owner;
-        }
-
-    private:
-        IStructure& owner;
-    };
+    //! `cursor = 0` rewinds, `bool(cursor)` tests validity, `*cursor` / `cursor->` give the element, `++cursor` advances
+    typedef StructureCursor<IStructure, ElementData> Cursor;
     const Cursor cursor;
 
     // node names of the restart layout (core/src/modules/include/IStructure.hpp:127-132)

@@ -4,7 +4,10 @@
 #include <memory>
 #include <string>
 
+#include <iostream>
+
 #include "Configured.hpp"
+#include "ModuleLoader.hpp"
 #include "HipStep.hpp"
 #include "Iterator.hpp"
 #include "RectGrid.hpp"
@@ -31,5 +34,67 @@ private:
     std::shared_ptr<IStructure> dataStructure;
     std::string initialFileName, finalFileName;
 };
+
+
+// ---- implementation (header-only: the class is a few lines of glue)
+template <>
+inline const std::map<int, std::string> Configured<Model>::keyMap = {
+    { Model::RESTARTFILE_KEY, "model.init_file" }, // core/src/Model.cpp:23-29
+    { Model::STARTTIME_KEY, "model.start" },
+    { Model::STOPTIME_KEY, "model.stop" },
+    { Model::RUNLENGTH_KEY, "model.run_length" },
+    { Model::TIMESTEP_KEY, "model.time_step" },
+    { Model::STRUCTURE_KEY, "model.structure" }, // new: structure type when there is no init file
+    { Model::FINALFILE_KEY, "model.final_file" }, // new: defaults to the reference's fixed "restart.nc" role
+};
+
+inline Model::Model()
+    : modelStep(ModuleLoader::getLoader().getInstance<IModelStep>())
+{
+    iterator.setIterant(modelStep.get());
+    finalFileName = "restart.nsdg";
+}
+
+inline Model::~Model()
+{
+    try {
+        if (dataStructure)
+            writeRestartFile();
+    } catch (std::exception& e) {
+        // swallowed, as in the reference destructor
+    }
+}
+
+inline void Model::configure()
+{
+    const std::string startTimeStr = getConfiguration(keyMap.at(STARTTIME_KEY), std::string("0"));
+    const std::string stopTimeStr = getConfiguration(keyMap.at(STOPTIME_KEY), std::string("1"));
+    const std::string durationStr = getConfiguration(keyMap.at(RUNLENGTH_KEY), std::string(""));
+    const std::string stepStr = getConfiguration(keyMap.at(TIMESTEP_KEY), std::string("1"));
+    iterator.parseAndSet(startTimeStr, stopTimeStr, durationStr, stepStr);
+
+    initialFileName = getConfiguration(keyMap.at(RESTARTFILE_KEY), std::string(""));
+    finalFileName = getConfiguration(keyMap.at(FINALFILE_KEY), finalFileName);
+    modelStep->setInitFile(initialFileName);
+    const std::string type = RectGrid::typeInFile(initialFileName);
+    if (!type.empty()) {
+        dataStructure = StructureFactory::generateFromFile(initialFileName);
+        dataStructure->init(initialFileName);
+    } else { // no readable sidecar (e.g. the reference's NetCDF dev1.res.nc): constants from init.* keys
+        dataStructure = StructureFactory::generate(getConfiguration(keyMap.at(STRUCTURE_KEY), std::string("devgrid")));
+        dataStructure->init("");
+    }
+    modelStep->setInitialData(*dataStructure);
+    modelStep->init();
+    DummyExternalData::setAll(*dataStructure); // core/src/Model.cpp:76
+}
+
+inline void Model::run() { iterator.run(); }
+
+inline void Model::writeRestartFile()
+{
+    modelStep->writeRestartFile(finalFileName);
+    std::cout << "Restart file written to " << finalFileName << std::endl;
+}
 
 } // namespace Nextsim

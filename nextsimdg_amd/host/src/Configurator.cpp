@@ -3,6 +3,9 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <stdexcept>
+
+#include "ModuleLoader.hpp"
 
 namespace Nextsim {
 
@@ -114,6 +117,56 @@ bool Configurator::lookup(const std::string& key, std::string& value)
         }
     }
     return false;
+}
+
+
+// ---- ConfiguredModule
+const std::string ConfiguredModule::MODULE_PREFIX = "Modules";
+
+std::string ConfiguredModule::addPrefix(const std::string& moduleName) { return MODULE_PREFIX + "." + moduleName; }
+
+void ConfiguredModule::parseConfigurator()
+{
+    ModuleLoader& loader = ModuleLoader::getLoader();
+    for (const std::string& module : loader.listModules()) {
+        std::string impl;
+        if (!Configurator::lookup(addPrefix(module), impl))
+            continue; // not mentioned: keep the current selection
+        bool known = false;
+        for (const std::string& name : loader.listImplementations(module))
+            known = known || (name == impl);
+        if (!known)
+            throw std::domain_error("Invalid implementation \"" + impl + "\" of module " + module + ".");
+        loader.setImplementation(module, impl);
+    }
+}
+
+// ---- CommandLineParser
+std::string CommandLineParser::helpText()
+{
+    return "neXtSIM_DG (MI355X) command line options:\n"
+           "  -h [ --help ]            print help message\n"
+           "  --config-file arg        specify a configuration file\n"
+           "  --config-files arg...    specify a list of configuration files\n"
+           "  --section.key=value      override any configuration value\n";
+}
+
+CommandLineParser::CommandLineParser(int argc, char* argv[])
+{
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--help" || a == "-h") {
+            m_help = true;
+        } else if (a == "--config-file") {
+            if (i + 1 < argc)
+                m_configFilenames.push_back(argv[++i]);
+        } else if (a.rfind("--config-file=", 0) == 0) {
+            m_configFilenames.push_back(a.substr(14));
+        } else if (a == "--config-files") { // multitoken: every following token up to the next option
+            while (i + 1 < argc && std::string(argv[i + 1]).rfind("-", 0) != 0)
+                m_configFilenames.push_back(argv[++i]);
+        }
+    }
 }
 
 } // namespace Nextsim

@@ -3,8 +3,6 @@
 #include <cstdio>
 #include <iostream>
 
-#include "CommandLineParser.hpp"
-#include "ConfiguredModule.hpp"
 #include "Configurator.hpp"
 #include "DynamicsStep.hpp"
 #include "Model.hpp"

@@ -10,8 +10,6 @@
 #include <sstream>
 #include <typeinfo>
 
-#include "CommandLineParser.hpp"
-#include "ConfiguredModule.hpp"
 #include "Configurator.hpp"
 #include "DynamicsStep.hpp"
 #include "Model.hpp"
