@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libnsdg.so")
+LIB_PATH = os.environ.get("NSDG_LIB", os.path.join(HERE, "lib", "libnsdg.so"))  # NSDG_LIB: A/B builds of the same ABI
 
 c_double_p = C.POINTER(C.c_double)
 NDIAG = 15

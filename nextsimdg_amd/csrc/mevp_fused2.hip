@@ -36,6 +36,162 @@ struct StressPtrs2 {
 __device__ __forceinline__ double from_left(double x) { return __shfl_up(x, 1); }
 __device__ __forceinline__ double from_right(double x) { return __shfl_down(x, 1); }
 
+// Everything of one element row that sub-iteration p+1 needs from sub-iteration p.  Two such sets
+// alternate between "being written by A(t)" and "being read by B(t+1)", so nothing is copied when the
+// march advances.
+struct RowCarry {
+    double s11[8], s12[8], s22[8]; // S^p of the row (relaxed in place to S^{p+1} by B)
+    double P[9]; // ice strength at the Gauss points
+    double c[4][6]; // packed momentum coefficients of the 4 owned nodes (V, EX, EY, C)
+    double u[4], v[4]; // u^p, v^p at those nodes
+};
+
+struct MarchConst {
+    NodalConsts K;
+    int nx, ny, y0, y1, tbeg, tend, ix, ntx, nn;
+    bool own, hasL, lastcol;
+    double hx, hy, ihx, ihy, iarea, ialpha, dmin2;
+};
+
+// contributions of a row to its top nodes, carried to the next row of the march
+struct TopCarry {
+    double x6 = 0., y6 = 0., x7 = 0., y7 = 0., xl8 = 0., yl8 = 0.; // 6: top-left, 7: top-mid of my column, 8 of the left column
+};
+
+// One march step: A(t) = sub-iteration p on row t into `cur`; B(t) = sub-iteration p+1 on row t-1 from `prev`.
+__device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry& cur, RowCarry& prev, TopCarry& ca, TopCarry& cb,
+    const StressPtrs2& S, const double* __restrict__ u_old, const double* __restrict__ v_old, const double* __restrict__ packed,
+    const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+{
+    const int nn = M.nn, ix = M.ix;
+    // ---------------------------------------------------------------------- A(t): sub-iteration p on row t
+    if (t <= M.tend) { // the last march step only drains B
+        const long ts = tile_off(ix, t, M.ntx, 8), tp = tile_off(ix, t, M.ntx, 9);
+        const long nV = (long)(2 * t) * nn + 2 * ix;
+        double ul[9], vl[9];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+            const long n = nV + (a / 3) * nn + a % 3;
+            ul[a] = u_old[n];
+            vl[a] = v_old[n];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+            cur.P[q] = pg[tp + q * 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            cur.s11[i] = S.i11[ts + i * 64];
+            cur.s12[i] = S.i12[ts + i * 64];
+            cur.s22[i] = S.i22[ts + i * 64];
+        }
+        load_nodal(packed, nV, cur.c[0]);
+        load_nodal(packed, nV + 1, cur.c[1]);
+        load_nodal(packed, nV + nn, cur.c[2]);
+        load_nodal(packed, nV + nn + 1, cur.c[3]);
+        stress_update(ul, vl, cur.P, M.ihx, M.ihy, M.ialpha, M.dmin2, cur.s11, cur.s12, cur.s22);
+        double cx[9], cy[9];
+        node_contrib_all(cur.s11, cur.s12, cur.s22, M.hx, M.hy, cx, cy);
+        const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
+        const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
+        const bool hasB = t > 0;
+        // u^p at the 4 owned nodes of row t (kept in registers; Dirichlet nodes are zero)
+        if (M.hasL && hasB)
+            node_update_packed(M.K, cur.c[0], ul[0], vl[0], ((ca.xl8 + ca.x6) + l2x) + cx[0], ((ca.yl8 + ca.y6) + l2y) + cy[0], 9. * M.iarea,
+                cur.u[0], cur.v[0]);
+        else
+            cur.u[0] = cur.v[0] = 0.;
+        if (hasB)
+            node_update_packed(M.K, cur.c[1], ul[1], vl[1], ca.x7 + cx[1], ca.y7 + cy[1], 4.5 * M.iarea, cur.u[1], cur.v[1]);
+        else
+            cur.u[1] = cur.v[1] = 0.;
+        if (M.hasL)
+            node_update_packed(M.K, cur.c[2], ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * M.iarea, cur.u[2], cur.v[2]);
+        else
+            cur.u[2] = cur.v[2] = 0.;
+        node_update_packed(M.K, cur.c[3], ul[4], vl[4], cx[4], cy[4], 2.25 * M.iarea, cur.u[3], cur.v[3]);
+        ca.x6 = cx[6], ca.y6 = cy[6], ca.x7 = cx[7], ca.y7 = cy[7];
+        ca.xl8 = from_left(cx[8]), ca.yl8 = from_left(cy[8]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            cur.u[k] = cur.v[k] = 0.; // node row 2*ny is the top boundary
+    }
+
+    // ---------------------------------------------------------------------- B(t): sub-iteration p+1 on row r = t-1
+    const int r = t - 1;
+    if (r >= M.tbeg && r >= M.y0 - 1 && r < M.y1) { // wave-uniform
+        // u^p at the 9 nodes of element (ix, r): own nodes of rows r and t, the right neighbour's V / EY
+        double ul[9], vl[9];
+        ul[0] = prev.u[0], vl[0] = prev.v[0];
+        ul[1] = prev.u[1], vl[1] = prev.v[1];
+        ul[3] = prev.u[2], vl[3] = prev.v[2];
+        ul[4] = prev.u[3], vl[4] = prev.v[3];
+        ul[6] = cur.u[0], vl[6] = cur.v[0];
+        ul[7] = cur.u[1], vl[7] = cur.v[1];
+        const double r2u = from_right(prev.u[0]), r2v = from_right(prev.v[0]);
+        const double r5u = from_right(prev.u[2]), r5v = from_right(prev.v[2]);
+        const double r8u = from_right(cur.u[0]), r8v = from_right(cur.v[0]);
+        ul[2] = M.lastcol ? 0. : r2u, vl[2] = M.lastcol ? 0. : r2v; // node column 2*nx is the right boundary
+        ul[5] = M.lastcol ? 0. : r5u, vl[5] = M.lastcol ? 0. : r5v;
+        ul[8] = M.lastcol ? 0. : r8u, vl[8] = M.lastcol ? 0. : r8v;
+        stress_update(ul, vl, prev.P, M.ihx, M.ihy, M.ialpha, M.dmin2, prev.s11, prev.s12, prev.s22);
+        const bool store = M.own && r >= M.y0;
+        if (store) {
+            const long ts = tile_off(ix, r, M.ntx, 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                S.o11[ts + i * 64] = prev.s11[i];
+                S.o12[ts + i * 64] = prev.s12[i];
+                S.o22[ts + i * 64] = prev.s22[i];
+            }
+        }
+        double cx[9], cy[9];
+        node_contrib_all(prev.s11, prev.s12, prev.s22, M.hx, M.hy, cx, cy);
+        const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
+        const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
+        if (r >= M.y0) { // wave-uniform: rows below y0 only feed the carried contributions
+            const bool hasB = r > 0;
+            const long nV = (long)(2 * r) * nn + 2 * ix;
+            double un, vn;
+            if (M.hasL && hasB)
+                node_update_packed(M.K, prev.c[0], prev.u[0], prev.v[0], ((cb.xl8 + cb.x6) + l2x) + cx[0], ((cb.yl8 + cb.y6) + l2y) + cy[0],
+                    9. * M.iarea, un, vn);
+            else
+                un = vn = 0.;
+            if (store)
+                u_new[nV] = un, v_new[nV] = vn;
+            if (hasB)
+                node_update_packed(M.K, prev.c[1], prev.u[1], prev.v[1], cb.x7 + cx[1], cb.y7 + cy[1], 4.5 * M.iarea, un, vn);
+            else
+                un = vn = 0.;
+            if (store)
+                u_new[nV + 1] = un, v_new[nV + 1] = vn;
+            if (M.hasL)
+                node_update_packed(M.K, prev.c[2], prev.u[2], prev.v[2], l5x + cx[3], l5y + cy[3], 4.5 * M.iarea, un, vn);
+            else
+                un = vn = 0.;
+            if (store)
+                u_new[nV + nn] = un, v_new[nV + nn] = vn;
+            node_update_packed(M.K, prev.c[3], prev.u[3], prev.v[3], cx[4], cy[4], 2.25 * M.iarea, un, vn);
+            if (store) {
+                u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
+                if (M.lastcol) {
+                    u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
+                    u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
+                }
+                if (r == M.ny - 1) {
+                    u_new[nV + 2 * nn] = 0., v_new[nV + 2 * nn] = 0.;
+                    u_new[nV + 2 * nn + 1] = 0., v_new[nV + 2 * nn + 1] = 0.;
+                    if (M.lastcol)
+                        u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
+                }
+            }
+        }
+        cb.x6 = cx[6], cb.y6 = cy[6], cb.x7 = cx[7], cb.y7 = cy[7];
+        cb.xl8 = from_left(cx[8]), cb.yl8 = from_left(cy[8]);
+    }
+}
+
 __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int R, int ncw, double hx, double hy,
     double ialpha, double dmin2, StressPtrs2 S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
@@ -43,180 +199,33 @@ __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx,
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int strip = wave / ncw, cw = wave - strip * ncw;
-    const int y0 = j0 + strip * R;
-    if (y0 >= j1)
+    MarchConst M;
+    M.y0 = j0 + strip * R;
+    if (M.y0 >= j1)
         return; // wave-uniform
-    const int y1 = min(y0 + R, j1);
+    M.y1 = min(M.y0 + R, j1);
     const int ixr = cw * 61 - 2 + lane;
     const bool valid = ixr >= 0 && ixr < nx;
-    const bool own = valid && lane >= 2 && lane <= 62;
-    const int ix = min(max(ixr, 0), nx - 1);
-    const bool hasL = ix > 0, lastcol = ix == nx - 1;
-    const int ntx = tiles_per_row(nx);
-    const int nn = 2 * nx + 1;
-    const double ihx = 1. / hx, ihy = 1. / hy, iarea = ihx * ihy;
+    M.K = K;
+    M.nx = nx, M.ny = ny;
+    M.own = valid && lane >= 2 && lane <= 62;
+    M.ix = min(max(ixr, 0), nx - 1);
+    M.hasL = M.ix > 0, M.lastcol = M.ix == nx - 1;
+    M.ntx = tiles_per_row(nx);
+    M.nn = 2 * nx + 1;
+    M.hx = hx, M.hy = hy, M.ihx = 1. / hx, M.ihy = 1. / hy, M.iarea = M.ihx * M.ihy;
+    M.ialpha = ialpha, M.dmin2 = dmin2;
+    M.tbeg = max(M.y0 - 2, 0), M.tend = min(M.y1, ny - 1); // A runs on rows tbeg .. tend
 
-    // state carried from A(t-1) to B(t): everything of element row t-1 that sub-iteration p+1 needs
-    double sp11[8], sp12[8], sp22[8]; // S^p(t-1)
-    double Pk[9]; // ice strength at the Gauss points of row t-1
-    double ck[4][6]; // packed momentum coefficients of the 4 owned nodes (V, EX, EY, C) of row t-1
-    double upu[4], upv[4]; // u^p, v^p at those nodes
-    // contributions of the row below to its top nodes (6: top-left, 7: top-mid of my column, 8 of the left column)
-    double a6x = 0., a6y = 0., a7x = 0., a7y = 0., al8x = 0., al8y = 0.; // sub-iteration p   (row t-1)
-    double b6x = 0., b6y = 0., b7x = 0., b7y = 0., bl8x = 0., bl8y = 0.; // sub-iteration p+1 (row t-2)
+    RowCarry X, Y; // alternate between "written by A" and "read by B": no copies when the march advances
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        upu[k] = upv[k] = 0.;
-
-    const int tbeg = max(y0 - 2, 0), tend = min(y1, ny - 1); // A runs on rows tbeg .. tend
-    for (int t = tbeg; t <= tend + 1; ++t) {
-        // ------------------------------------------------------------------ A(t): sub-iteration p on row t
-        double s11[8], s12[8], s22[8], Pq[9], ct[4][6], unu[4], unv[4];
-        const bool doA = t <= tend; // the last march step only drains B
-        if (doA) {
-            const long ts = tile_off(ix, t, ntx, 8), tp = tile_off(ix, t, ntx, 9);
-            const long nV = (long)(2 * t) * nn + 2 * ix;
-            double ul[9], vl[9];
-#pragma unroll
-            for (int a = 0; a < 9; ++a) {
-                const long n = nV + (a / 3) * nn + a % 3;
-                ul[a] = u_old[n];
-                vl[a] = v_old[n];
-            }
-#pragma unroll
-            for (int q = 0; q < 9; ++q)
-                Pq[q] = pg[tp + q * 64];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s11[i] = S.i11[ts + i * 64];
-                s12[i] = S.i12[ts + i * 64];
-                s22[i] = S.i22[ts + i * 64];
-            }
-            load_nodal(packed, nV, ct[0]);
-            load_nodal(packed, nV + 1, ct[1]);
-            load_nodal(packed, nV + nn, ct[2]);
-            load_nodal(packed, nV + nn + 1, ct[3]);
-            stress_update(ul, vl, Pq, ihx, ihy, ialpha, dmin2, s11, s12, s22);
-            double cx[9], cy[9];
-            node_contrib_all(s11, s12, s22, hx, hy, cx, cy);
-            const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
-            const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
-            const bool hasB = t > 0;
-            // u^p at the 4 owned nodes of row t (kept in registers; Dirichlet nodes are zero)
-            if (hasL && hasB)
-                node_update_packed(K, ct[0], ul[0], vl[0], ((al8x + a6x) + l2x) + cx[0], ((al8y + a6y) + l2y) + cy[0], 9. * iarea, unu[0], unv[0]);
-            else
-                unu[0] = unv[0] = 0.;
-            if (hasB)
-                node_update_packed(K, ct[1], ul[1], vl[1], a7x + cx[1], a7y + cy[1], 4.5 * iarea, unu[1], unv[1]);
-            else
-                unu[1] = unv[1] = 0.;
-            if (hasL)
-                node_update_packed(K, ct[2], ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, unu[2], unv[2]);
-            else
-                unu[2] = unv[2] = 0.;
-            node_update_packed(K, ct[3], ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, unu[3], unv[3]);
-            a6x = cx[6], a6y = cy[6], a7x = cx[7], a7y = cy[7];
-            al8x = from_left(cx[8]), al8y = from_left(cy[8]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                unu[k] = unv[k] = 0.; // node row 2*ny is the top boundary
-        }
-
-        // ------------------------------------------------------------------ B(t): sub-iteration p+1 on row r = t-1
-        const int r = t - 1;
-        if (r >= tbeg && r >= y0 - 1 && r < y1) { // wave-uniform
-            // u^p at the 9 nodes of element (ix, r): own nodes of rows r and t, the right neighbour's V / EY
-            double ul[9], vl[9];
-            ul[0] = upu[0], vl[0] = upv[0];
-            ul[1] = upu[1], vl[1] = upv[1];
-            ul[3] = upu[2], vl[3] = upv[2];
-            ul[4] = upu[3], vl[4] = upv[3];
-            ul[6] = unu[0], vl[6] = unv[0];
-            ul[7] = unu[1], vl[7] = unv[1];
-            const double r2u = from_right(upu[0]), r2v = from_right(upv[0]);
-            const double r5u = from_right(upu[2]), r5v = from_right(upv[2]);
-            const double r8u = from_right(unu[0]), r8v = from_right(unv[0]);
-            ul[2] = lastcol ? 0. : r2u, vl[2] = lastcol ? 0. : r2v; // node column 2*nx is the right boundary
-            ul[5] = lastcol ? 0. : r5u, vl[5] = lastcol ? 0. : r5v;
-            ul[8] = lastcol ? 0. : r8u, vl[8] = lastcol ? 0. : r8v;
-            stress_update(ul, vl, Pk, ihx, ihy, ialpha, dmin2, sp11, sp12, sp22);
-            const bool store = own && r >= y0;
-            if (store) {
-                const long ts = tile_off(ix, r, ntx, 8);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    S.o11[ts + i * 64] = sp11[i];
-                    S.o12[ts + i * 64] = sp12[i];
-                    S.o22[ts + i * 64] = sp22[i];
-                }
-            }
-            double cx[9], cy[9];
-            node_contrib_all(sp11, sp12, sp22, hx, hy, cx, cy);
-            const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
-            const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
-            if (r >= y0) { // wave-uniform: rows below y0 only feed the carried contributions
-                const bool hasB = r > 0;
-                const long nV = (long)(2 * r) * nn + 2 * ix;
-                double un, vn;
-                if (hasL && hasB)
-                    node_update_packed(K, ck[0], upu[0], upv[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea, un, vn);
-                else
-                    un = vn = 0.;
-                if (store)
-                    u_new[nV] = un, v_new[nV] = vn;
-                if (hasB)
-                    node_update_packed(K, ck[1], upu[1], upv[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, un, vn);
-                else
-                    un = vn = 0.;
-                if (store)
-                    u_new[nV + 1] = un, v_new[nV + 1] = vn;
-                if (hasL)
-                    node_update_packed(K, ck[2], upu[2], upv[2], l5x + cx[3], l5y + cy[3], 4.5 * iarea, un, vn);
-                else
-                    un = vn = 0.;
-                if (store)
-                    u_new[nV + nn] = un, v_new[nV + nn] = vn;
-                node_update_packed(K, ck[3], upu[3], upv[3], cx[4], cy[4], 2.25 * iarea, un, vn);
-                if (store) {
-                    u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
-                    if (lastcol) {
-                        u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
-                        u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
-                    }
-                    if (r == ny - 1) {
-                        u_new[nV + 2 * nn] = 0., v_new[nV + 2 * nn] = 0.;
-                        u_new[nV + 2 * nn + 1] = 0., v_new[nV + 2 * nn + 1] = 0.;
-                        if (lastcol)
-                            u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
-                    }
-                }
-            }
-            b6x = cx[6], b6y = cy[6], b7x = cx[7], b7y = cy[7];
-            bl8x = from_left(cx[8]), bl8y = from_left(cy[8]);
-        }
-
-        // ------------------------------------------------------------------ rotate: row t becomes "the row below"
-        if (doA) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                sp11[i] = s11[i];
-                sp12[i] = s12[i];
-                sp22[i] = s22[i];
-            }
-#pragma unroll
-            for (int q = 0; q < 9; ++q)
-                Pk[q] = Pq[q];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                upu[k] = unu[k];
-                upv[k] = unv[k];
-#pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    ck[k][j] = ct[k][j];
-            }
-        }
+        Y.u[k] = Y.v[k] = 0.;
+    TopCarry ca, cb; // sub-iteration p (row t-1) and p+1 (row t-2)
+    for (int t = M.tbeg; t <= M.tend + 1; t += 2) {
+        march_step(M, t, X, Y, ca, cb, S, u_old, v_old, packed, pg, u_new, v_new);
+        if (t + 1 <= M.tend + 1)
+            march_step(M, t + 1, Y, X, ca, cb, S, u_old, v_old, packed, pg, u_new, v_new);
     }
 }
 
