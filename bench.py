@@ -60,6 +60,18 @@ def cpu_baseline(nsub_full, budget_s=12.0):
             O.lib(omp)
         except Exception:
             continue
+        if omp and n == 192:
+            # the all-cores figure needs enough rows for every thread: re-build the sample at 768 x 768
+            n = 768
+            bt = synthetic.BoxTest(n, n)
+            H, A = bt.dg_fields()
+            pg = O.ice_strength(n, n, p, H, A)
+            cgh, cga = O.dg_to_cg(n, n, H), O.dg_to_cg(n, n, A)
+            uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
+            ua, va = [np.ascontiguousarray(a) for a in bt.wind(0.0)]
+            tax, tay = O.wind_stress(p, ua, va)
+            u, v = np.zeros_like(uo), np.zeros_like(uo)
+            s = [np.zeros((8, n, n)) for _ in range(3)]
         O.mevp_subcycle(n, n, bt.hx, bt.hy, 120.0, 1, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg, omp=omp)
         t0 = time.perf_counter()
         k = 0
@@ -82,7 +94,7 @@ def cpu_baseline(nsub_full, budget_s=12.0):
                      "has no dynamics code to time" % (out[False][2], nsub_full),
            "subiters_per_s": out[False][1]}
     if True in out:
-        res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1]}
+        res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1], "sample": "OpenMP build, 768x768 box test"}
     return res
 
 
@@ -131,6 +143,17 @@ def column_bench(args, device):
         O.column_step(O.column_params(), 600.0, st, fo, ni)
         reps += 1
     cpu = reps * m / (time.perf_counter() - c0)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    big = 1 << 24  # large enough for every host core to have work
+    st, fo, ni = synthetic.column_fields(big)
+    O.column_step(O.column_params(), 600.0, st, fo, ni, omp=True)
+    c0 = time.perf_counter()
+    reps_omp = 0
+    while time.perf_counter() - c0 < 5.0:
+        O.column_step(O.column_params(), 600.0, st, fo, ni, omp=True)
+        reps_omp += 1
+    cpu_all = reps_omp * big / (time.perf_counter() - c0)
     achieved = n * 160 / (ms * 1e-3) / 1e9
     print(json.dumps({
         "metric": "element-steps/sec (column physics)", "value": n * args.steps / elapsed, "unit": "element-steps/s", "n_gpus": 1,
@@ -140,12 +163,74 @@ def column_bench(args, device):
         "roofline": {"bound": "hbm", "kernel": "column_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": n * 160, "avg_launch_ms": ms},
         "cpu_baseline": {"value": cpu, "unit": "element-steps/s", "cores": 1, "kind": "port",
-                         "sample": "oracle/column_oracle.c, %d steps of 2^20 seeded elements, single thread" % reps}}), flush=True)
+                         "sample": "oracle/column_oracle.c, %d steps of 2^20 seeded elements, single thread" % reps,
+                         "all_cores": {"value": cpu_all, "cores": cores, "sample": "OpenMP build, %d steps of 2^24 elements" % reps_omp}}}), flush=True)
+
+
+def transport_bench(args, device):
+    """BASELINE config 2: DG advection-only rotating patch (default 512x512 DG1, SSP-RK2); a step = one RK
+    step of one field.  Algorithmic traffic per element-step: stages x (read phi + write phi'
+    + DG velocity + owned edge-normal velocities) = 256 B for DG1, 504 B for DG2 (one field)."""
+    order = args.order
+    n = args.nx
+    ctx = abi.Context(device)
+    ctx.set_grid(n, n, 1.0 / n, 1.0 / n)
+    phi, u, v, _ = synthetic.rotating_patch(n, n, order)
+    nc, ng = {0: 1, 1: 3, 2: 6}[order], order + 1
+    z = lambda *sh: torch.zeros(*sh, dtype=torch.float64, device=device)
+    put = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    adv = (z(nc, n, n), z(nc, n, n), z(ng, n, n + 1), z(ng, n + 1, n))
+    ctx.prepare_advection(order, put(u), put(v), *adv)
+    d = put(phi)
+    scratch = z(2 * phi.size)
+    dt = 0.1 / (2 * order + 1) * (1.0 / n) / np.pi
+    m0 = float(d[0].sum())
+    for _ in range(max(args.warmup, 1)):
+        ctx.transport_step(order, dt, [d], adv, scratch)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(ctx.stream)
+    for _ in range(args.steps):
+        ctx.transport_step(order, dt, [d], adv, scratch)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / args.steps
+    if abs(float(d[0].sum()) - m0) > 1e-11 * abs(m0):
+        raise SystemExit("transport bench lost mass: invalid run")
+    stages = order + 1
+    per_stage = 8 * nc * 2 + 2 * 8 * nc + 2 * ng * 8
+    alg = n * n * stages * per_stage
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    m = 256
+    ph, uu, vv, _ = synthetic.rotating_patch(m, m, order)
+    adv_o = O.prepare_advection(m, m, order, uu, vv)
+    c0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - c0 < 8.0:
+        O.transport_step(m, m, 1.0 / m, 1.0 / m, order, dt, ph, adv_o)
+        reps += 1
+    cpu = reps * m * m / (time.perf_counter() - c0)
+    achieved = alg / (ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "element-steps/sec (DG%d transport)" % order, "value": n * n * args.steps / elapsed, "unit": "element-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%dx%d DG%d advection-only rotating patch, SSP-RK%d, 1 field" % (n, n, order, stages)},
+        "roofline": {"bound": "hbm", "kernel": "transport_stage_kernel<%d> x %d" % (order, stages), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg / stages,
+                     "avg_launch_ms": ms / stages},
+        "cpu_baseline": {"value": cpu, "unit": "element-steps/s", "cores": 1, "kind": "port",
+                         "sample": "oracle/dyn_oracle.c, %d RK steps of a 256x256 grid, single thread" % reps}}), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["dynamics", "column", "coupled"], default="dynamics",
+    ap.add_argument("--order", type=int, default=1, help="DG order of the transport workload")
+    ap.add_argument("--workload", choices=["dynamics", "column", "coupled", "transport"], default="dynamics",
                     help="dynamics (default, BASELINE metric), column physics only, or dynamics + column thermodynamics (config 5)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -181,10 +266,10 @@ def main():
     if world > 1:
         dist.barrier()
 
-    if args.workload == "column":
+    if args.workload in ("column", "transport"):
         if world != 1:
-            raise SystemExit("the column workload is a single-GPU measurement")
-        return column_bench(args, device)
+            raise SystemExit("the %s workload is a single-GPU measurement" % args.workload)
+        return column_bench(args, device) if args.workload == "column" else transport_bench(args, device)
 
     nx, ny, nsub = args.nx, args.ny, args.nsub
     L = 512e3

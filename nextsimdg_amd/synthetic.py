@@ -82,6 +82,8 @@ def rotating_patch(nx, ny, order, kind="bump"):
         r2 = (x - 0.5) ** 2 + (y - 0.25) ** 2
         if kind == "bump":
             return np.exp(-50.0 * r2 / 0.25)
+        if kind == "narrow":  # tails < 1e-7 where the velocity cut-off starts: the exact solution is a rigid rotation
+            return np.exp(-800.0 * r2)
         r = np.sqrt(r2) / 0.15
         return np.where(r < 1, 0.5 * (1 + np.cos(np.pi * np.minimum(r, 1))), 0.0)
 

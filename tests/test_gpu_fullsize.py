@@ -125,3 +125,28 @@ def test_config3_1024_point_symmetry(ctx):
         assert scale > 1e-6
         assert float((f + torch.flip(f, (0, 1))).abs().max()) <= 1e-11 * scale
     ctx.set_mevp_params(ctx.mevp_default_params())
+
+
+def test_config2_convergence_rate_one_revolution(ctx):
+    """BASELINE config 2 / SURVEY.md section 8(d): DG1 rotating patch, ONE full revolution, L2 error against the
+    initial field and its convergence rate over 128^2 / 256^2 / 512^2 (expected ~2 for DG1)"""
+    order = 1
+    errs = []
+    for n in (128, 256, 512):
+        phi, u, v, phi0 = synthetic.rotating_patch(n, n, order, kind="narrow")
+        ctx.set_grid(n, n, 1.0 / n, 1.0 / n)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")
+        adv = (z(3, n, n), z(3, n, n), z(2, n, n + 1), z(2, n + 1, n))
+        ctx.prepare_advection(order, dev(u), dev(v), *adv)
+        d = dev(phi)
+        scratch = z(2 * phi.size)
+        steps = int(np.ceil(1.0 / (0.15 / 3 * (1.0 / n) / np.pi)))
+        dt = 1.0 / steps
+        m0 = float(d[0].sum())
+        for _ in range(steps):
+            ctx.transport_step(order, dt, [d], adv, scratch)
+        assert abs(float(d[0].sum()) - m0) <= 1e-11 * abs(m0)
+        errs.append(basis.l2_error(d.cpu().numpy(), phi0, 1.0, 1.0))
+    rates = [np.log2(errs[i] / errs[i + 1]) for i in range(2)]
+    assert errs[2] < errs[1] < errs[0]
+    assert rates[1] > 1.7, (errs, rates)
