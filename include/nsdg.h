@@ -159,6 +159,12 @@ int nsdg_dg_to_cg(nsdg_ctx* ctx, int32_t ncoef, const double* f_dg, double* f_cg
 /* P = pstar * max(H,0) * exp(-C (1 - clamp(A,0,1))) at the 3x3 Gauss points of rows [j0, j1) */
 int nsdg_ice_strength(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* H, const double* A, double* pg);
 
+/* Analytic forcing provider for the square box test of side domain_size [m] at model time t [s], evaluated on
+ * the device on the CG2 lattice of the local array (which must start at the domain's origin): cyclone wind
+ * (ua, va) and circular ocean current (uo, vo); either pair may be NULL.  Stands in for the reference's constant
+ * DummyExternalData (core/src/include/DummyExternalData.hpp:22-34) on the dynamics side. */
+int nsdg_boxtest_forcing(nsdg_ctx* ctx, double domain_size, double t, double* ua, double* va, double* uo, double* vo);
+
 /* tau_a = c_atm * rho_atm * |u_a| u_a at nnodes nodes */
 int nsdg_wind_stress(nsdg_ctx* ctx, int64_t nnodes, const double* ua, const double* va, double* tax, double* tay);
 

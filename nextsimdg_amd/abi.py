@@ -59,6 +59,7 @@ SYMBOLS = {
     "nsdg_transport_step": (C.c_int, [VP, I32, D, I32, C.POINTER(VP)] + [VP] * 5),
     "nsdg_dg_to_cg": (C.c_int, [VP, I32, VP, VP]),
     "nsdg_ice_strength": (C.c_int, [VP, I32, I32, VP, VP, VP]),
+    "nsdg_boxtest_forcing": (C.c_int, [VP, D, D, VP, VP, VP, VP]),
     "nsdg_wind_stress": (C.c_int, [VP, I64, VP, VP, VP, VP]),
     "nsdg_mevp_stress": (C.c_int, [VP, I32, I32] + [VP] * 6),
     "nsdg_mevp_pack_nodal": (C.c_int, [VP, D] + [VP] * 9),
@@ -263,6 +264,11 @@ class Context:
     def ice_strength(self, H, A, pg, j0=0, j1=None):
         _check_f64(H, A, pg)
         self._call(self.lib.nsdg_ice_strength(self.h, j0, self.ny if j1 is None else j1, _ptr(H), _ptr(A), _ptr(pg)))
+
+    def boxtest_forcing(self, domain_size, t, wind=None, ocean=None):
+        ts = list(wind or (None, None)) + list(ocean or (None, None))
+        _check_f64(*ts)
+        self._call(self.lib.nsdg_boxtest_forcing(self.h, float(domain_size), float(t), *[_ptr(x) for x in ts]))
 
     def wind_stress(self, ua, va, tax, tay):
         _check_f64(ua, va, tax, tay)

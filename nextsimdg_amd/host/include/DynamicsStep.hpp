@@ -12,8 +12,8 @@
 //     dynamics.alpha/.beta   mEVP parameters (0 = stability bound of the mesh, see stableAlpha())
 //     dynamics.thermodynamics  run the column physics first       (false)
 // The structure's cell means initialise the DG fields: H <- hice, A <- cice (coefficient 0; higher
-// coefficients start at zero) and receive them back at stop().  Ocean current and wind are the analytic
-// box-test fields of nextsimdg_amd/synthetic.py (BoxTest), evaluated on the host once.
+// coefficients start at zero) and receive them back at stop().  Ocean current and wind come from the
+// device-side forcing provider nsdg_boxtest_forcing (the wind is re-evaluated at every step's model time).
 #pragma once
 #include <vector>
 
@@ -58,6 +58,7 @@ private:
     int nsub = 120;
     bool thermo = false;
     long m_steps = 0;
+    double m_time = 0; // model time of the next step [s]
     double m_umax = 0, m_sumH = 0, m_sumA = 0;
 };
 

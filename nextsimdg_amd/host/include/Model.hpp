@@ -11,6 +11,7 @@
 #include "HipStep.hpp"
 #include "Iterator.hpp"
 #include "RectGrid.hpp"
+#include "Timer.hpp"
 
 namespace Nextsim {
 
@@ -67,6 +68,7 @@ inline Model::~Model()
 
 inline void Model::configure()
 {
+    ScopedTimer t("configure");
     const std::string startTimeStr = getConfiguration(keyMap.at(STARTTIME_KEY), std::string("0"));
     const std::string stopTimeStr = getConfiguration(keyMap.at(STOPTIME_KEY), std::string("1"));
     const std::string durationStr = getConfiguration(keyMap.at(RUNLENGTH_KEY), std::string(""));
@@ -89,7 +91,11 @@ inline void Model::configure()
     DummyExternalData::setAll(*dataStructure); // core/src/Model.cpp:76
 }
 
-inline void Model::run() { iterator.run(); }
+inline void Model::run()
+{
+    ScopedTimer t("run");
+    iterator.run();
+}
 
 inline void Model::writeRestartFile()
 {

@@ -8,6 +8,7 @@
 
 #include "../../../include/nsdg.h"
 #include "ModuleLoader.hpp"
+#include "Timer.hpp"
 #include "PhysicsModules.hpp"
 
 namespace Nextsim {
@@ -76,8 +77,9 @@ void DynamicsStep::init()
     }
 }
 
-void DynamicsStep::start(const Iterator::TimePoint&)
+void DynamicsStep::start(const Iterator::TimePoint& startTime)
 {
+    ScopedTimer timer("start (upload)");
     if (!pStructure)
         throw std::logic_error("DynamicsStep: setInitialData() was not called");
     if (!ctx)
@@ -109,25 +111,9 @@ void DynamicsStep::start(const Iterator::TimePoint&)
     // cell means -> DG coefficient 0
     checkHip(hipMemcpy(d[H], f.hice.data(), N * sizeof(double), hipMemcpyHostToDevice), "upload H");
     checkHip(hipMemcpy(d[A], f.cice.data(), N * sizeof(double), hipMemcpyHostToDevice), "upload A");
-    // analytic box-test forcing on the CG2 lattice (nextsimdg_amd/synthetic.py: BoxTest.ocean / .wind at t = 0)
-    std::vector<double> uo(NN), vo(NN), ua(NN), va(NN);
-    const int nn = 2 * nxf + 1;
-    const double ang = 72. * 3.14159265358979323846 / 180., ca = std::cos(ang), sa = std::sin(ang), cm = 0.5 * L, R = 0.2 * L;
-    for (int gy = 0; gy < 2 * nyf + 1; ++gy)
-        for (int gx = 0; gx < nn; ++gx) {
-            const long n = (long)gy * nn + gx;
-            const double x = gx * (L / (2 * nxf)), y = gy * (L / (2 * nyf));
-            uo[n] = 0.01 * (2 * y - L) / L;
-            vo[n] = 0.01 * (L - 2 * x) / L;
-            const double dx = cm - x, dy = cm - y, r = std::sqrt(dx * dx + dy * dy);
-            const double s = 15.0 * std::exp(-r / R) / R;
-            ua[n] = s * (ca * dx + sa * dy) * R / 1e5;
-            va[n] = s * (-sa * dx + ca * dy) * R / 1e5;
-        }
-    checkHip(hipMemcpy(d[UO], uo.data(), NN * sizeof(double), hipMemcpyHostToDevice), "upload ocean");
-    checkHip(hipMemcpy(d[VO], vo.data(), NN * sizeof(double), hipMemcpyHostToDevice), "upload ocean");
-    checkHip(hipMemcpy(d[UA], ua.data(), NN * sizeof(double), hipMemcpyHostToDevice), "upload wind");
-    checkHip(hipMemcpy(d[VA], va.data(), NN * sizeof(double), hipMemcpyHostToDevice), "upload wind");
+    // analytic box-test forcing, evaluated on the device (ocean once, wind at the current model time every step)
+    check(nsdg_boxtest_forcing(ctx, L, (double)startTime, d[UA], d[VA], d[UO], d[VO]), "forcing");
+    m_time = (double)startTime;
     if (thermo) { // column planes: hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice
         const std::vector<double>* planes[13] = { &f.hsnow, nullptr, &f.sst, &f.sss, &f.tair, &f.tdew, &f.slp, &f.qsw, &f.qlw, &f.mld,
             &f.snowfall, &f.wind, &f.newice };
@@ -139,6 +125,7 @@ void DynamicsStep::start(const Iterator::TimePoint&)
 
 void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
 {
+    ScopedTimer timer("iterate");
     if (!d_block)
         start(0);
     const double dt = dtSeconds;
@@ -154,6 +141,7 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
                   c + 9 * N, c + 10 * N, c + 11 * N, c + 12 * N, nullptr),
             "column step");
     }
+    check(nsdg_boxtest_forcing(ctx, L, m_time, d[UA], d[VA], nullptr, nullptr), "forcing"); // the cyclone moves
     check(nsdg_dg_to_cg(ctx, 6, d[H], d[CGH]), "dg_to_cg");
     check(nsdg_dg_to_cg(ctx, 6, d[A], d[CGA]), "dg_to_cg");
     check(nsdg_ice_strength(ctx, 0, nyf, d[H], d[A], d[PG]), "ice_strength");
@@ -167,10 +155,12 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
     double* fields[2] = { d[H], d[A] };
     check(nsdg_transport_step(ctx, 2, dt, 2, fields, d[VXDG], d[VYDG], d[UNX], d[UNY], d[T1]), "transport_step"); // T1,T2 contiguous: 24N scratch
     ++m_steps;
+    m_time += dt;
 }
 
 void DynamicsStep::stop(const Iterator::TimePoint&)
 {
+    ScopedTimer timer("stop (download)");
     if (!d_block)
         return;
     check(nsdg_ctx_synchronize(ctx), "DynamicsStep::stop");

@@ -7,6 +7,7 @@
 
 #include "../../../include/nsdg.h"
 #include "ModuleLoader.hpp"
+#include "Timer.hpp"
 #include "PhysicsModules.hpp"
 
 namespace Nextsim {
@@ -80,6 +81,7 @@ void HipStep::start(const Iterator::TimePoint&) { upload(); }
 
 void HipStep::iterate(const Iterator::Duration& dt)
 {
+    ScopedTimer timer("iterate");
     if (!resident)
         upload();
     double* b = d_block;

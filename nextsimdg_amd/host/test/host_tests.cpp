@@ -15,6 +15,7 @@
 #include "Model.hpp"
 #include "ModuleLoader.hpp"
 #include "PhysicsModules.hpp"
+#include "Timer.hpp"
 
 using namespace Nextsim;
 
@@ -237,6 +238,41 @@ static void test_iterator()
     CHECK(e.iterates == 1);
 }
 
+static void test_timer()
+{ // tick/tock tree (core/test/Timer_test.cpp:18-86 only prints; here the tree is asserted)
+    Timer t("root");
+    t.tick("outer");
+    for (int i = 0; i < 3; ++i) {
+        t.tick("inner");
+        t.tock("inner");
+    }
+    t.tick("other");
+    t.tock();
+    CHECK_THROWS_AS(t.tock("inner"), std::logic_error); // the running node is "outer"
+    t.tock("outer");
+    t.tock(); // at the root: no-op
+    CHECK(t.ticks({ "outer" }) == 1 && t.ticks({ "outer", "inner" }) == 3 && t.ticks({ "outer", "other" }) == 1);
+    CHECK(t.ticks({ "inner" }) == 0 && t.wallSeconds({ "nope" }) == 0.);
+    CHECK(t.wallSeconds({ "outer" }) >= t.wallSeconds({ "outer", "inner" }));
+    int synced = 0;
+    t.setDeviceSync([&synced] { ++synced; });
+    {
+        t.tick("with sync");
+        t.tock();
+    }
+    CHECK(synced == 1);
+    std::ostringstream os;
+    t.report(os);
+    const std::string rep = os.str();
+    CHECK(rep.find("root: ticks = 1") == 0);
+    CHECK(rep.find("+- outer: ticks = 1") != std::string::npos && rep.find("inner: ticks = 3") != std::string::npos);
+    CHECK(rep.find("% of parent") != std::string::npos && rep.find("ms/tick") != std::string::npos);
+    {
+        ScopedTimer s("scoped");
+    }
+    CHECK(Timer::main.ticks({ "scoped" }) == 1);
+}
+
 static void test_physics_config()
 { // physics/test/NextsimPhysics_test.cpp:21-45 + [Modules] selection as at :178-189
     Configurator::clear();
@@ -425,6 +461,7 @@ int main(int argc, char** argv)
             test_configurator();
             test_command_line_parser();
             test_iterator();
+            test_timer();
             test_physics_config();
             test_structure();
         } else {

@@ -107,9 +107,27 @@ def test_dynamics_step_executable_matches_python_driver(host_build, gpu, tmp_pat
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
     core.load_global(H, A, uo, vo, ua, va)
-    for _ in range(3):
+    for k in range(3):
+        ctx.set_grid(nx, ny, bt.hx, bt.hy)
+        ctx.boxtest_forcing(bt.L, 120.0 * k, wind=(core.ua, core.va))  # the cyclone moves with model time
+        if k == 1:  # the device forcing provider reproduces the numpy formulae
+            wa, wb = bt.wind(120.0)
+            assert float((core.ua.cpu() - torch.from_numpy(wa)).abs().max()) < 1e-13 * float(np.abs(wa).max())
+            assert float((core.va.cpu() - torch.from_numpy(wb)).abs().max()) < 1e-13 * float(np.abs(wb).max())
         core.step()
     want = [float(core.u.abs().max()), float(core.H[0].sum()), float(core.A[0].sum())]
     assert want[0] > 1e-6
     for g, w in zip(got, want):
         assert abs(g - w) <= 1e-10 * abs(w), (got, want)
+
+
+@pytest.mark.gpu
+def test_timing_report(host_build, gpu, tmp_path):
+    """model.timing = true prints the hierarchical timer tree (Timer::report format of the reference,
+    core/src/Timer.cpp:141-198) with device work charged to the node that enqueued it"""
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"), "--model.timing=true",
+                   "--model.stop=4", "--model.final_file=%s" % os.path.join(str(tmp_path), "r.nsdg")], cwd=str(tmp_path))
+    assert rc == 0, out
+    assert re.search(r"Total: ticks = 1", out) and re.search(r"run: ticks = 1", out), out
+    assert re.search(r"iterate: ticks = 4 .*ms/tick", out), out
+    assert "configure" in out and "% of parent" in out
