@@ -55,6 +55,7 @@ SYMBOLS = {
     "nsdg_grid_set": (C.c_int, [VP, I32, I32, D, D]),
     "nsdg_mevp_variant_set": (C.c_int, [VP, I32]),
     "nsdg_prepare_advection": (C.c_int, [VP, I32] + [VP] * 6),
+    "nsdg_transport_variant_set": (C.c_int, [VP, I32, I32]),
     "nsdg_transport_stage": (C.c_int, [VP, I32, I32, I32, D, D, D, I32, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
     "nsdg_transport_step": (C.c_int, [VP, I32, D, I32, C.POINTER(VP)] + [VP] * 5),
     "nsdg_dg_to_cg": (C.c_int, [VP, I32, VP, VP]),
@@ -236,6 +237,9 @@ class Context:
 
     def set_mevp_occupancy(self, waves_per_simd):
         self._call(self.lib.nsdg_mevp_occupancy_set(self.h, waves_per_simd))
+
+    def set_transport_variant(self, variant, strip_rows=0):
+        self._call(self.lib.nsdg_transport_variant_set(self.h, variant, strip_rows))
 
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):
         _check_f64(u, v, vx, vy, unx, uny)

@@ -55,44 +55,26 @@ struct FieldPtrs {
             acc += t_ * (val);   \
     } while (0)
 
+// edge-normal velocities of one element at the NG edge Gauss points
+template <int NG>
+struct EdgeVel {
+    double l[NG], r[NG], b[NG], t[NG];
+};
+
+// dphi_i/dt * m_i of one element from its own coefficients c, the four neighbours' coefficients (zero
+// outside the array), its DG velocity (already divided by hx, hy) and its edge-normal velocities
 template <int ORDER>
-__global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, int j0, int j1, double ihx, double ihy,
-    double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
-    const double* __restrict__ un_x, const double* __restrict__ un_y)
+__device__ __forceinline__ void transport_rhs(const double (&c)[DG<ORDER>::NC], const double (&cl)[DG<ORDER>::NC],
+    const double (&cr)[DG<ORDER>::NC], const double (&cb)[DG<ORDER>::NC], const double (&ct)[DG<ORDER>::NC],
+    const double (&vx)[DG<ORDER>::NC], const double (&vy)[DG<ORDER>::NC], const EdgeVel<DG<ORDER>::NG>& E, double ihx, double ihy,
+    double (&rhs)[DG<ORDER>::NC])
 {
     constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG, NQ = DG<ORDER>::NQ;
-    const int ix = blockIdx.x * 64 + threadIdx.x;
-    const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
-    if (ix >= nx || iy >= j1)
-        return;
-    const double* __restrict__ phis = fp.phis[blockIdx.z];
-    const double* __restrict__ phi0 = fp.phi0[blockIdx.z];
-    double* __restrict__ out = fp.out[blockIdx.z];
-    const long N = (long)nx * ny;
-    const long e = (long)iy * nx + ix;
-    const bool hasL = ix > 0, hasR = ix + 1 < nx, hasB = iy > 0, hasT = iy + 1 < ny;
-
-    double c[NC], cl[NC], cr[NC], cb[NC], ct[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        c[k] = phis[k * N + e];
-        cl[k] = hasL ? phis[k * N + e - 1] : 0.;
-        cr[k] = hasR ? phis[k * N + e + 1] : 0.;
-        cb[k] = hasB ? phis[k * N + e - nx] : 0.;
-        ct[k] = hasT ? phis[k * N + e + nx] : 0.;
-    }
-    double rhs[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k)
         rhs[k] = 0.;
 
     if constexpr (ORDER > 0) { // cell term: int phi v . grad psi_i
-        double vx[NC], vy[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            vx[k] = vx_dg[k * N + e] * ihx;
-            vy[k] = vy_dg[k * N + e] * ihy;
-        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             double f = 0., wx = 0., wy = 0.;
@@ -110,13 +92,9 @@ __global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, in
             }
         }
     }
-    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
-    const long exl = (long)iy * (nx + 1) + ix; // left vertical edge; right = exl + 1
-    const long eyb = (long)iy * nx + ix; // bottom horizontal edge; top = eyb + nx
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const double unl = un_x[g * NEX + exl], unr = un_x[g * NEX + exl + 1];
-        const double unb = un_y[g * NEY + eyb], unt = un_y[g * NEY + eyb + nx];
+        const double unl = E.l[g], unr = E.r[g], unb = E.b[g], unt = E.t[g];
         double in_r = 0., in_l = 0., in_t = 0., in_b = 0., out_r = 0., out_l = 0., out_t = 0., out_b = 0.;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
@@ -142,6 +120,49 @@ __global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, in
             FMA_TAB(rhs[i], t_gw<ORDER>(g) * t_b<ORDER>(g, i), fb);
         }
     }
+}
+
+// Default stage kernel: one lane per element, all five coefficient sets gathered from memory (the vertical
+// neighbours mostly hit L2).
+template <int ORDER>
+__global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, int j0, int j1, double ihx, double ihy,
+    double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
+    const double* __restrict__ un_x, const double* __restrict__ un_y)
+{
+    constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
+    if (ix >= nx || iy >= j1)
+        return;
+    const double* __restrict__ phis = fp.phis[blockIdx.z];
+    const double* __restrict__ phi0 = fp.phi0[blockIdx.z];
+    double* __restrict__ out = fp.out[blockIdx.z];
+    const long N = (long)nx * ny;
+    const long e = (long)iy * nx + ix;
+    const bool hasL = ix > 0, hasR = ix + 1 < nx, hasB = iy > 0, hasT = iy + 1 < ny;
+
+    double c[NC], cl[NC], cr[NC], cb[NC], ct[NC], vx[NC], vy[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        c[k] = phis[k * N + e];
+        cl[k] = hasL ? phis[k * N + e - 1] : 0.;
+        cr[k] = hasR ? phis[k * N + e + 1] : 0.;
+        cb[k] = hasB ? phis[k * N + e - nx] : 0.;
+        ct[k] = hasT ? phis[k * N + e + nx] : 0.;
+        vx[k] = ORDER > 0 ? vx_dg[k * N + e] * ihx : 0.;
+        vy[k] = ORDER > 0 ? vy_dg[k * N + e] * ihy : 0.;
+    }
+    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
+    const long exl = (long)iy * (nx + 1) + ix; // left vertical edge; right = exl + 1
+    const long eyb = (long)iy * nx + ix; // bottom horizontal edge; top = eyb + nx
+    EdgeVel<NG> E;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        E.l[g] = un_x[g * NEX + exl], E.r[g] = un_x[g * NEX + exl + 1];
+        E.b[g] = un_y[g * NEY + eyb], E.t[g] = un_y[g * NEY + eyb + nx];
+    }
+    double rhs[NC];
+    transport_rhs<ORDER>(c, cl, cr, cb, ct, vx, vy, E, ihx, ihy, rhs);
     if (a != 0.) {
 #pragma unroll
         for (int i = 0; i < NC; ++i)
@@ -150,6 +171,85 @@ __global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, in
 #pragma unroll
         for (int i = 0; i < NC; ++i)
             out[i * N + e] = b * (c[i] + dt * IMASS[i] * rhs[i]);
+    }
+}
+
+// Alternative stage kernel (nsdg_transport_variant_set(ctx, 1, rows)): a wave owns 64 columns x R rows of one field and marches bottom to top with a
+// three-row window of coefficients in registers, so every row of phi is read from HBM once (plus 2/R for
+// the window start) instead of up to three times;  measured at 2048^2 DG2 it is not faster than the gather
+// kernel (1.51-1.76 ms vs 1.55 ms per RK3 step of two fields: fewer, longer waves), so it is not the default; the left/right neighbours are re-read through L1 (same cache
+// lines as the wave's own row).  The horizontal-edge velocities of the row's bottom are the previous row's
+// top and stay in registers too.  Same arithmetic (transport_rhs) as the reference form: bit-identical.
+template <int ORDER>
+__global__ __launch_bounds__(256) void transport_march_kernel(int nx, int ny, int j0, int j1, int R, int ncw, double ihx, double ihy,
+    double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
+    const double* __restrict__ un_x, const double* __restrict__ un_y)
+{
+    constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = wave / ncw, cw = wave - strip * ncw;
+    const int y0 = j0 + strip * R;
+    if (y0 >= j1)
+        return; // wave-uniform
+    const int y1 = min(y0 + R, j1);
+    const int ix = cw * 64 + lane;
+    if (ix >= nx)
+        return; // no cross-lane operation below: inactive lanes may leave
+    const double* __restrict__ phis = fp.phis[blockIdx.y];
+    const double* __restrict__ phi0 = fp.phi0[blockIdx.y];
+    double* __restrict__ out = fp.out[blockIdx.y];
+    const long N = (long)nx * ny;
+    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
+    const bool hasL = ix > 0, hasR = ix + 1 < nx;
+
+    double cb[NC], c[NC], ct[NC];
+    EdgeVel<NG> E;
+    {
+        const long e = (long)y0 * nx + ix;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            c[k] = phis[k * N + e];
+            cb[k] = y0 > 0 ? phis[k * N + e - nx] : 0.;
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            E.t[g] = un_y[g * NEY + (long)y0 * nx + ix]; // becomes the bottom edge of row y0
+    }
+    for (int t = y0; t < y1; ++t) {
+        const long e = (long)t * nx + ix;
+        double cl[NC], cr[NC], vx[NC], vy[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            ct[k] = t + 1 < ny ? phis[k * N + e + nx] : 0.;
+            cl[k] = hasL ? phis[k * N + e - 1] : 0.;
+            cr[k] = hasR ? phis[k * N + e + 1] : 0.;
+            vx[k] = ORDER > 0 ? vx_dg[k * N + e] * ihx : 0.;
+            vy[k] = ORDER > 0 ? vy_dg[k * N + e] * ihy : 0.;
+        }
+        const long exl = (long)t * (nx + 1) + ix;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            E.b[g] = E.t[g];
+            E.l[g] = un_x[g * NEX + exl], E.r[g] = un_x[g * NEX + exl + 1];
+            E.t[g] = un_y[g * NEY + e + nx];
+        }
+        double rhs[NC];
+        transport_rhs<ORDER>(c, cl, cr, cb, ct, vx, vy, E, ihx, ihy, rhs);
+        if (a != 0.) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                out[i * N + e] = a * phi0[i * N + e] + b * (c[i] + dt * IMASS[i] * rhs[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                out[i * N + e] = b * (c[i] + dt * IMASS[i] * rhs[i]);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            cb[k] = c[k];
+            c[k] = ct[k];
+        }
     }
 }
 
@@ -211,9 +311,19 @@ template <int ORDER>
 int launch_stage(nsdg_ctx* ctx, int j0, int j1, double dt, double a, double b, int nfields, const FieldPtrs& fp,
     const double* vx, const double* vy, const double* unx, const double* uny)
 {
-    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4), nfields);
-    hipLaunchKernelGGL(transport_stage_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, 1. / ctx->hx,
-        1. / ctx->hy, dt, a, b, fp, vx, vy, unx, uny);
+    if (ctx->transport_variant == 0) {
+        const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4), nfields);
+        hipLaunchKernelGGL(transport_stage_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, 1. / ctx->hx,
+            1. / ctx->hy, dt, a, b, fp, vx, vy, unx, uny);
+    } else {
+        // strip height: enough waves to fill the chip several times over (the kernel is light: ~8 waves/SIMD),
+        // few enough rows of window start-up; 16 rows = 12 % extra reads of phi
+        const int ncw = nsdg_div_up(ctx->nx, 64);
+        const int R = ctx->transport_rows > 0 ? ctx->transport_rows : 16;
+        const long nwaves = (long)ncw * nsdg_div_up(j1 - j0, R);
+        hipLaunchKernelGGL(transport_march_kernel<ORDER>, dim3(nsdg_div_up(nwaves, 4), nfields), dim3(256), 0, ctx->stream, ctx->nx,
+            ctx->ny, j0, j1, R, ncw, 1. / ctx->hx, 1. / ctx->hy, dt, a, b, fp, vx, vy, unx, uny);
+    }
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }
@@ -231,6 +341,16 @@ int stage_dispatch(nsdg_ctx* ctx, int order, int j0, int j1, double dt, double a
 } // namespace
 
 extern "C" {
+
+int nsdg_transport_variant_set(nsdg_ctx* ctx, int32_t variant, int32_t strip_rows)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(variant == 0 || variant == 1, "variant must be 0 (gather) or 1 (march)");
+    NSDG_CHECK_ARG(strip_rows >= 0 && strip_rows <= 4096, "strip rows must be in 0..4096 (0 = default)");
+    ctx->transport_variant = variant;
+    ctx->transport_rows = strip_rows;
+    return NSDG_OK;
+}
 
 int nsdg_prepare_advection(nsdg_ctx* ctx, int32_t order, const double* u, const double* v, double* vx_dg, double* vy_dg,
     double* un_x, double* un_y)
