@@ -1,0 +1,180 @@
+"""The multi-rank driver on ONE GPU: every "rank" is a thread with its own nsdg context and its own row
+block; ghost rows travel through an in-process mailbox instead of RCCL.  This runs the real HIP kernels on
+real ghost-row layouts (depth (2,1) for the two-iterations-per-pass kernel, (1,1) otherwise), with the same
+DynamicsCore / RowBlock code the bench uses, and must reproduce the single-domain run bit for bit.  (What it
+cannot cover is RCCL itself: there is one GPU per test box.)"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from nextsimdg_amd import abi, rowblock, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+class Mailbox:
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.box = {}
+        self.error = None
+
+    def put(self, key, tensor):
+        with self.cv:
+            self.box.setdefault(key, []).append(tensor)
+            self.cv.notify_all()
+
+    def get(self, key):
+        with self.cv:
+            ok = self.cv.wait_for(lambda: self.error is not None or self.box.get(key), timeout=120)
+            if self.error is not None or not ok:
+                raise RuntimeError("peer failed or timed out")
+            return self.box[key].pop(0)
+
+
+class ThreadExchanger(rowblock.HaloExchanger):
+    """same slicing logic as HaloExchanger, transport = clone into a mailbox / copy out of it"""
+
+    def __init__(self, blk, mailbox):
+        super().__init__(blk)
+        self.mb = mailbox
+
+    def _exchange(self, sends, recvs):
+        for view, peer in sends:
+            self.mb.put((self.blk.rank, peer), view.clone())
+        return recvs
+
+    def _complete(self, recvs):
+        for view, peer in recvs:
+            view.copy_(self.mb.get((peer, self.blk.rank)))
+
+    # nodal arrays
+    def nodal_start(self, fields, rows_down=1):
+        b = self.blk
+        if b.world == 1:
+            return []
+        up = 2 * b.depth_below
+        sends, recvs = [], []
+        for f in fields:
+            if b.above is not None:
+                sends.append((f[2 * b.j1 - up:2 * b.j1], b.above))
+                recvs.append((f[2 * b.j1:2 * b.j1 + rows_down], b.above))
+            if b.below is not None:
+                sends.append((f[2 * b.j0:2 * b.j0 + rows_down], b.below))
+                recvs.append((f[2 * b.j0 - up:2 * b.j0], b.below))
+        return [self._exchange(sends, recvs)]
+
+    def finish(self, reqs):
+        for recvs in reqs:
+            self._complete(recvs)
+
+    def rows_exchange_start(self, fields, rows_of, nodal_fields=(), rows_down=1):
+        b = self.blk
+        if b.world == 1:
+            return [], []
+        sends, recvs = [], []
+        for f in fields:
+            if b.above is not None:
+                sends.append((rows_of(f, b.j1 - b.depth_below, b.j1), b.above))
+                if b.gt:
+                    recvs.append((rows_of(f, b.j1, b.j1 + b.gt), b.above))
+            if b.below is not None:
+                if b.depth_above:
+                    sends.append((rows_of(f, b.j0, b.j0 + b.depth_above), b.below))
+                recvs.append((rows_of(f, b.j0 - b.gb, b.j0), b.below))
+        pending = [self._exchange(sends, recvs)] + (self.nodal_start(nodal_fields, rows_down) if nodal_fields else [])
+        return pending, []
+
+    def rows_exchange_finish(self, reqs, unpack):
+        self.finish(reqs)
+
+    def element(self, fields):
+        b = self.blk
+        if b.world == 1:
+            return
+        sends, recvs = [], []
+        for f in fields:
+            if b.above is not None:
+                sends.append((f[:, b.j1 - b.depth_below:b.j1, :], b.above))
+                if b.gt:
+                    recvs.append((f[:, b.j1:b.j1 + b.gt, :], b.above))
+            if b.below is not None:
+                if b.depth_above:
+                    sends.append((f[:, b.j0:b.j0 + b.depth_above, :], b.below))
+                recvs.append((f[:, b.j0 - b.gb:b.j0, :], b.below))
+        self._complete(self._exchange(sends, recvs))
+
+
+def fields(nx, ny):
+    bt = synthetic.BoxTest(nx, ny)
+    rng = np.random.default_rng(71)
+    H, A = bt.dg_fields()
+    A[0] -= 0.3 * rng.random((ny, nx))
+    H[1:3] += 0.02 * rng.standard_normal((2, ny, nx))
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    return bt, H, A, uo, vo, 3.0 * ua, 3.0 * va
+
+
+def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, overlap):
+    try:
+        ctx = abi.Context(torch.device("cuda:0"))
+        ctx.set_mevp_variant(variant)
+        ctx.set_mevp_params(ctx.mevp_default_params(alpha=300.0, beta=300.0))
+        bt, H, A, uo, vo, ua, va = fields(nx, ny)
+        depth = (2, 1) if variant == 2 else (1, 1)
+        blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
+        cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
+        core = cls(ctx, blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cuda"), exchanger=ThreadExchanger(blk, mailbox),
+                   overlap=overlap)
+        core.load_global(H, A, uo, vo, ua, va)
+        if coupled:
+            st, fo, _ = synthetic.column_fields(nx * ny, 5)
+            col = {k: v.reshape(ny, nx) for k, v in {**st, **fo}.items()}
+            col["wind"] = 0.2 * col["wind"]
+            core.load_column(col)
+        for _ in range(nsteps):
+            core.step()
+        torch.cuda.synchronize()
+        out[rank] = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
+        out[rank]["s11"] = core.owned(core.s[0]).clone()
+    except BaseException as e:  # noqa: BLE001 -- wake the peers up, then re-raise in the main thread
+        with mailbox.cv:
+            mailbox.error = e
+            mailbox.cv.notify_all()
+        out[rank] = e
+
+
+def run_world(world, variant, coupled, nx, ny, nsub, nsteps, overlap=True):
+    mailbox, out = Mailbox(), {}
+    threads = [threading.Thread(target=run_rank, args=(r, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, overlap))
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r in range(world):
+        if isinstance(out[r], BaseException):
+            raise out[r]
+    return out
+
+
+@pytest.mark.parametrize("world,variant,coupled", [(2, 2, False), (3, 2, False), (4, 2, True), (3, 1, False), (2, 1, True)])
+def test_row_blocks_on_one_gpu_equal_single_domain_bitwise(gpu, world, variant, coupled):
+    nx, ny, nsub, nsteps = 150, 64, 7, 2  # odd nsub: double passes + one single sub-iteration
+    ref = run_world(1, variant, coupled, nx, ny, nsub, nsteps)[0]
+    assert float(ref["u"].abs().max()) > 1e-5
+    parts = run_world(world, variant, coupled, nx, ny, nsub, nsteps)
+    for key, dim in (("H", 1), ("A", 1), ("u", 0), ("v", 0), ("s11", 0)):
+        got = torch.cat([parts[r][key] for r in range(world)], dim=dim)
+        assert got.shape == ref[key].shape, key
+        assert torch.equal(got, ref[key]), (key, world, variant)
+
+
+def test_overlap_split_does_not_change_results(gpu):
+    a = run_world(3, 2, False, 150, 64, 6, 1, overlap=True)
+    b = run_world(3, 2, False, 150, 64, 6, 1, overlap=False)
+    for r in range(3):
+        for k in a[r]:
+            assert torch.equal(a[r][k], b[r][k])
