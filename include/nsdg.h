@@ -186,6 +186,12 @@ int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, con
 int nsdg_mevp_pack_nodal(nsdg_ctx* ctx, double dt, const double* u0, const double* v0, const double* tax,
     const double* tay, const double* uo, const double* vo, const double* cgh, const double* cga, double* packed);
 
+/* The whole per-step nodal preparation in one launch: nodal means of the DG2 fields H and A, wind stress of
+ * (ua, va) and coefficient packing -- equivalent to nsdg_dg_to_cg x2 + nsdg_wind_stress + nsdg_mevp_pack_nodal
+ * (bit-identical `packed`) without materialising cgH, cgA and tau_a.  u0, v0: velocity at the start of the step. */
+int nsdg_mevp_prepare(nsdg_ctx* ctx, double dt, const double* H, const double* A, const double* ua, const double* va,
+    const double* uo, const double* vo, const double* u0, const double* v0, double* packed);
+
 /* mEVP velocity update of the nodes owned (bottom-left) by element rows [j0, j1) */
 int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11, const double* s12,
     const double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
@@ -211,7 +217,7 @@ int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_
     double* u_new, double* v_new, const double* packed, const double* pg);
 
 /* nsub sub-iterations over the whole local array (packs the nodal coefficients, then iterates);
- * result in s11/s12/s22 and u, v.  scratch: 10*(2nx+1)*(2ny+1) + 24*nx*ny doubles, 16-byte aligned
+ * result in s11/s12/s22 and u, v (u0/v0 may be the same arrays as u/v).  scratch: 10*(2nx+1)*(2ny+1) + 24*nx*ny doubles, 16-byte aligned
  * (packed coefficients + ping-pong copies of the velocity and the stress). */
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u,
     double* v, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,

@@ -64,6 +64,7 @@ SYMBOLS = {
     "nsdg_wind_stress": (C.c_int, [VP, I64, VP, VP, VP, VP]),
     "nsdg_mevp_stress": (C.c_int, [VP, I32, I32] + [VP] * 6),
     "nsdg_mevp_pack_nodal": (C.c_int, [VP, D] + [VP] * 9),
+    "nsdg_mevp_prepare": (C.c_int, [VP, D] + [VP] * 9),
     "nsdg_mevp_velocity": (C.c_int, [VP, I32, I32] + [VP] * 8),
     "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate2": (C.c_int, [VP, I32, I32] + [VP] * 12),
@@ -288,6 +289,12 @@ class Context:
         if packed.numel() < 8 * cgh.numel():
             raise NsdgError("packed nodal buffer too small: need %d doubles" % (8 * cgh.numel()))
         self._call(self.lib.nsdg_mevp_pack_nodal(self.h, float(dt), *[_ptr(t) for t in ts]))
+
+    def mevp_prepare(self, dt, H, A, wind, ocean, u0v0, packed):
+        """nodal means of H and A + wind stress + coefficient packing in one launch"""
+        ts = [H, A, wind[0], wind[1], ocean[0], ocean[1], u0v0[0], u0v0[1], packed]
+        _check_f64(*ts)
+        self._call(self.lib.nsdg_mevp_prepare(self.h, float(dt), *[_ptr(t) for t in ts]))
 
     def mevp_velocity(self, j0, j1, s, uv_old, uv_new, packed):
         ts = [s[0], s[1], s[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed]

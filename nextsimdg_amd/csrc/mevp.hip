@@ -149,26 +149,6 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(NodalConsts K, int n
     }
 }
 
-// per-step momentum coefficients, 6 doubles per node (layout: mevp_common.h)
-__global__ __launch_bounds__(256) void mevp_pack_nodal_kernel(nsdg_mevp_params P, long nnodes, double dt,
-    const double* __restrict__ u0, const double* __restrict__ v0, const double* __restrict__ tax,
-    const double* __restrict__ tay, const double* __restrict__ uo, const double* __restrict__ vo,
-    const double* __restrict__ cgh, const double* __restrict__ cga, double* __restrict__ packed)
-{
-    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= nnodes)
-        return;
-    const double h = fmax(cgh[n], P.h_min);
-    const double a = fmin(fmax(cga[n], 0.), 1.);
-    const double mdt = P.rho_ice * h / dt;
-    const double cor = P.rho_ice * h * P.fc;
-    const double uoc = uo[n], voc = vo[n];
-    double2* out = reinterpret_cast<double2*>(packed + n * NODAL_STRIDE);
-    out[0] = make_double2(h, a * (P.c_ocean * P.rho_ocean));
-    out[1] = make_double2(mdt * u0[n] + a * tax[n] - cor * voc, mdt * v0[n] + a * tay[n] + cor * uoc);
-    out[2] = make_double2(uoc, voc);
-}
-
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double psi_rt(int c, double x, double y)
 {
@@ -182,14 +162,9 @@ __device__ __forceinline__ double psi_rt(int c, double x, double y)
     }
 }
 
-// nodal average of a DG field: one lane per CG2 node, gathers the 1/2/4 adjacent elements
-__global__ __launch_bounds__(256) void dg_to_cg_kernel(int nx, int ny, int nc, const double* __restrict__ f, double* __restrict__ g)
+// nodal average of a DG field at CG2 node (gx, gy): mean over the 1/2/4 adjacent elements of the DG value there
+__device__ __forceinline__ double node_average(int nx, int ny, int nc, const double* __restrict__ f, int gx, int gy)
 {
-    const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int gy = blockIdx.y * 4 + threadIdx.y;
-    const int nn = 2 * nx + 1, nm = 2 * ny + 1;
-    if (gx >= nn || gy >= nm)
-        return;
     const long N = (long)nx * ny;
     const int ix_hi = gx / 2, ix_lo = (gx % 2 == 0) ? gx / 2 - 1 : gx / 2;
     const int iy_hi = gy / 2, iy_lo = (gy % 2 == 0) ? gy / 2 - 1 : gy / 2;
@@ -207,7 +182,69 @@ __global__ __launch_bounds__(256) void dg_to_cg_kernel(int nx, int ny, int nc, c
             s += val;
             ++cnt;
         }
-    g[(long)gy * nn + gx] = s / cnt;
+    return s / cnt;
+}
+
+// per-step momentum coefficients of one node, 6 doubles (layout: mevp_common.h)
+__device__ __forceinline__ void pack_node(const nsdg_mevp_params& P, double dt, double u0, double v0, double tax, double tay,
+    double uoc, double voc, double cgh, double cga, double* __restrict__ dst)
+{
+    const double h = fmax(cgh, P.h_min);
+    const double a = fmin(fmax(cga, 0.), 1.);
+    const double mdt = P.rho_ice * h / dt;
+    const double cor = P.rho_ice * h * P.fc;
+    double2* out = reinterpret_cast<double2*>(dst);
+    out[0] = make_double2(h, a * (P.c_ocean * P.rho_ocean));
+    out[1] = make_double2(mdt * u0 + a * tax - cor * voc, mdt * v0 + a * tay + cor * uoc);
+    out[2] = make_double2(uoc, voc);
+}
+
+__device__ __forceinline__ void wind_tau(double f_atm, double ua, double va, double& tax, double& tay)
+{
+    const double m = sqrt(ua * ua + va * va);
+    tax = f_atm * m * ua;
+    tay = f_atm * m * va;
+}
+
+__global__ __launch_bounds__(256) void mevp_pack_nodal_kernel(nsdg_mevp_params P, long nnodes, double dt,
+    const double* __restrict__ u0, const double* __restrict__ v0, const double* __restrict__ tax,
+    const double* __restrict__ tay, const double* __restrict__ uo, const double* __restrict__ vo,
+    const double* __restrict__ cgh, const double* __restrict__ cga, double* __restrict__ packed)
+{
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nnodes)
+        return;
+    pack_node(P, dt, u0[n], v0[n], tax[n], tay[n], uo[n], vo[n], cgh[n], cga[n], packed + n * NODAL_STRIDE);
+}
+
+// All per-step nodal preparation of the momentum equation in one pass over the CG2 lattice: nodal means of
+// H and A (dg_to_cg), wind stress, coefficient packing -- without materialising cgH, cgA, tau_a.
+__global__ __launch_bounds__(256) void mevp_prepare_kernel(nsdg_mevp_params P, int nx, int ny, double dt,
+    const double* __restrict__ H, const double* __restrict__ A, const double* __restrict__ ua, const double* __restrict__ va,
+    const double* __restrict__ uo, const double* __restrict__ vo, const double* __restrict__ u0, const double* __restrict__ v0,
+    double* __restrict__ packed)
+{
+    const int gx = blockIdx.x * 64 + threadIdx.x;
+    const int gy = blockIdx.y * 4 + threadIdx.y;
+    const int nn = 2 * nx + 1, nm = 2 * ny + 1;
+    if (gx >= nn || gy >= nm)
+        return;
+    const long n = (long)gy * nn + gx;
+    const double cgh = node_average(nx, ny, 6, H, gx, gy), cga = node_average(nx, ny, 6, A, gx, gy);
+    double tax, tay;
+    wind_tau(P.c_atm * P.rho_atm, ua[n], va[n], tax, tay);
+    pack_node(P, dt, u0[n], v0[n], tax, tay, uo[n], vo[n], cgh, cga, packed + n * NODAL_STRIDE);
+}
+
+// one lane per CG2 node
+__global__ __launch_bounds__(256) void dg_to_cg_kernel(int nx, int ny, int nc, const double* __restrict__ f, double* __restrict__ g)
+{
+    const int gx = blockIdx.x * 64 + threadIdx.x;
+    const int gy = blockIdx.y * 4 + threadIdx.y;
+    const int nn = 2 * nx + 1, nm = 2 * ny + 1;
+    if (gx >= nn || gy >= nm)
+        return;
+    g[(long)gy * nn + gx] = node_average(nx, ny, nc, f, gx, gy);
 }
 
 __global__ __launch_bounds__(256) void ice_strength_kernel(int nx, int ny, int j0, int j1, double pstar, double compaction,
@@ -246,10 +283,7 @@ __global__ __launch_bounds__(256) void wind_stress_kernel(long n, double f_atm, 
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    const double a = ua[i], b = va[i];
-    const double m = sqrt(a * a + b * b);
-    tax[i] = f_atm * m * a;
-    tay[i] = f_atm * m * b;
+    wind_tau(f_atm, ua[i], va[i], tax[i], tay[i]);
 }
 
 // Analytic forcing of the 512 km box test on the CG2 lattice at model time t (seconds): circular ocean
@@ -397,6 +431,22 @@ int nsdg_mevp_pack_nodal(nsdg_ctx* ctx, double dt, const double* u0, const doubl
     return NSDG_OK;
 }
 
+int nsdg_mevp_prepare(nsdg_ctx* ctx, double dt, const double* H, const double* A, const double* ua, const double* va,
+    const double* uo, const double* vo, const double* u0, const double* v0, double* packed)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(H && A && ua && va && uo && vo && u0 && v0 && packed, "null field pointer");
+    NSDG_CHECK_ARG(dt > 0, "dt must be positive");
+    NSDG_CHECK_ARG(((uintptr_t)packed & 15) == 0, "packed must be 16-byte aligned");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const dim3 block(64, 4), grid(nsdg_div_up(2 * ctx->nx + 1, 64), nsdg_div_up(2 * ctx->ny + 1, 4));
+    hipLaunchKernelGGL(mevp_prepare_kernel, grid, block, 0, ctx->stream, ctx->mevp, ctx->nx, ctx->ny, dt, H, A, ua, va, uo, vo, u0, v0,
+        packed);
+    NSDG_CHECK_LAUNCH();
+    ctx->pack_dt = dt;
+    return NSDG_OK;
+}
+
 int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11, const double* s12, const double* s22,
     const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed)
 {
@@ -476,7 +526,8 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(nsub >= 0, "negative sub-iteration count");
     NSDG_CHECK_ARG(u && v && s11 && s12 && s22 && scratch, "null field pointer");
-    NSDG_CHECK_ARG(u0 != u && v0 != v, "u0/v0 (velocity at step start) must not alias the iterate u/v");
+    // u0/v0 may alias u/v: they are consumed by the coefficient packing before the first pass writes u, v
+    NSDG_CHECK_ARG(u0 && v0, "null field pointer");
     NSDG_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
     const long nnodes = (long)(2 * ctx->nx + 1) * (2 * ctx->ny + 1);
     const long M = nsdg_tiled_len(ctx->nx, ctx->ny, 8);

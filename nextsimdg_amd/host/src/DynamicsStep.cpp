@@ -142,13 +142,12 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
             "column step");
     }
     check(nsdg_boxtest_forcing(ctx, L, m_time, d[UA], d[VA], nullptr, nullptr), "forcing"); // the cyclone moves
+    check(nsdg_ice_strength(ctx, 0, nyf, d[H], d[A], d[PG]), "ice_strength");
+    // nsdg_mevp_subcycle takes the unpacked nodal fields (general entry point); u0/v0 may alias u/v
     check(nsdg_dg_to_cg(ctx, 6, d[H], d[CGH]), "dg_to_cg");
     check(nsdg_dg_to_cg(ctx, 6, d[A], d[CGA]), "dg_to_cg");
-    check(nsdg_ice_strength(ctx, 0, nyf, d[H], d[A], d[PG]), "ice_strength");
     check(nsdg_wind_stress(ctx, NN, d[UA], d[VA], d[TAX], d[TAY]), "wind_stress");
-    checkHip(hipMemcpyAsync(d[U0], d[U], NN * sizeof(double), hipMemcpyDeviceToDevice, nullptr), "u0");
-    checkHip(hipMemcpyAsync(d[V0], d[V], NN * sizeof(double), hipMemcpyDeviceToDevice, nullptr), "v0");
-    check(nsdg_mevp_subcycle(ctx, dt, nsub, d[S11], d[S12], d[S22], d[U], d[V], d[U0], d[V0], d[TAX], d[TAY], d[UO], d[VO], d[CGH], d[CGA],
+    check(nsdg_mevp_subcycle(ctx, dt, nsub, d[S11], d[S12], d[S22], d[U], d[V], d[U], d[V], d[TAX], d[TAY], d[UO], d[VO], d[CGH], d[CGA],
               d[PG], d[SCRATCH]),
         "mevp_subcycle");
     check(nsdg_prepare_advection(ctx, 2, d[U], d[V], d[VXDG], d[VYDG], d[UNX], d[UNY]), "prepare_advection");

@@ -204,9 +204,8 @@ class DynamicsCore:
         self.sb = [ops.private_zeros(8, ny, nx, device) for _ in range(3)]
         self.pg = ops.private_zeros(9, ny, nx, device)
         self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
-        self.u0, self.v0 = z(*nodal), z(*nodal)
-        self.ua, self.va, self.tax, self.tay = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
-        self.uo, self.vo, self.cgh, self.cga = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
+        self.ua, self.va = z(*nodal), z(*nodal)
+        self.uo, self.vo = z(*nodal), z(*nodal)
         self.packed = z(nodal[0] * nodal[1] * 8)  # per-step momentum coefficients, 8 per node
         self.adv = (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
         self.t1 = [z(6, ny, nx), z(6, ny, nx)]
@@ -231,14 +230,10 @@ class DynamicsCore:
 
     def momentum(self):
         ops, b = self.ops, self.blk
-        ops.dg_to_cg(self.H, self.cgh)
-        ops.dg_to_cg(self.A, self.cga)
         ops.ice_strength(self.H, self.A, self.pg, 0, b.ny)
-        ops.wind_stress(self.ua, self.va, self.tax, self.tay)
-        self.u0.copy_(self.u)
-        self.v0.copy_(self.v)
-        ops.mevp_pack_nodal(self.dt, (self.u0, self.v0), (self.tax, self.tay), (self.uo, self.vo), self.cgh, self.cga,
-                            self.packed)
+        # nodal means of H and A, wind stress and the packed momentum coefficients in one launch; the velocity at
+        # the start of the step is read from the current iterate (it is only needed inside the packing)
+        ops.mevp_prepare(self.dt, self.H, self.A, (self.ua, self.va), (self.uo, self.vo), (self.u, self.v), self.packed)
         it = 0
         if self.two_per_pass:
             # two sub-iterations per pass (intermediate stress / velocity stay in registers); with several

@@ -47,6 +47,12 @@ class OracleOps:
         _np(tax)[:] = a
         _np(tay)[:] = b
 
+    def mevp_prepare(self, dt, H, A, wind, ocean, u0v0, packed):
+        cgh, cga = O.dg_to_cg(self.nx, self.ny, _np(H)), O.dg_to_cg(self.nx, self.ny, _np(A))
+        tau = O.wind_stress(self.p, _np(wind[0]), _np(wind[1]))
+        # u0, v0 alias the iterate in the driver: keep copies, as the packed coefficients do on the device
+        self.nodal = (dt, [_np(x).copy() for x in u0v0], list(tau), [_np(x) for x in ocean], cgh, cga)
+
     def mevp_pack_nodal(self, dt, u0v0, tau, ocean, cgh, cga, packed):
         # the oracle has no packed layout: remember the per-step fields the coefficients are made from
         self.nodal = (dt, [_np(x) for x in u0v0], [_np(x) for x in tau], [_np(x) for x in ocean], _np(cgh), _np(cga))

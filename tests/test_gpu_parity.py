@@ -536,3 +536,25 @@ def test_transport_march_equals_gather_kernel_bitwise(ctx, order):
         for a, c in zip(outs[0], o):
             assert torch.equal(a, c)
     ctx.set_transport_variant(0, 0)
+
+
+def test_mevp_prepare_equals_separate_kernels_bitwise(ctx):
+    """the fused per-step nodal preparation (nodal means of H, A + wind stress + packing) writes exactly
+    what dg_to_cg x2 + wind_stress + mevp_pack_nodal write"""
+    b = Box(ctx, 97, 41)
+    nx, ny = b.nx, b.ny
+    rng = np.random.default_rng(67)
+    shape = (2 * ny + 1, 2 * nx + 1)
+    u0, v0 = dev(0.1 * rng.standard_normal(shape)), dev(0.1 * rng.standard_normal(shape))
+    dH, dA = dev(b.H), dev(b.A)
+    ua, va, uo, vo = dev(b.ua), dev(b.va), dev(b.uo), dev(b.vo)
+    z = lambda: torch.zeros(shape, dtype=torch.float64, device="cuda")
+    cgh, cga, tax, tay = z(), z(), z(), z()
+    ctx.dg_to_cg(dH, cgh)
+    ctx.dg_to_cg(dA, cga)
+    ctx.wind_stress(ua, va, tax, tay)
+    p1 = torch.zeros(8 * u0.numel(), dtype=torch.float64, device="cuda")
+    ctx.mevp_pack_nodal(120.0, (u0, v0), (tax, tay), (uo, vo), cgh, cga, p1)
+    p2 = torch.zeros_like(p1)
+    ctx.mevp_prepare(120.0, dH, dA, (ua, va), (uo, vo), (u0, v0), p2)
+    assert torch.equal(p1, p2)
