@@ -123,32 +123,26 @@ __device__ __forceinline__ void transport_rhs(const double (&c)[DG<ORDER>::NC], 
 }
 
 // Default stage kernel: one lane per element, all five coefficient sets gathered from memory (the vertical
-// neighbours mostly hit L2).
+// neighbours hit L2: the time does not depend on the workgroup height).  The fields advected by the same
+// velocity are processed by the same lane, so the DG velocity and the edge velocities are loaded once.
 template <int ORDER>
-__global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, int j0, int j1, double ihx, double ihy,
+__global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, int j0, int j1, int nfields, double ihx, double ihy,
     double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
     const double* __restrict__ un_x, const double* __restrict__ un_y)
 {
     constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
     const int ix = blockIdx.x * 64 + threadIdx.x;
-    const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
+    const int iy = j0 + blockIdx.y * blockDim.y + threadIdx.y;
     if (ix >= nx || iy >= j1)
         return;
-    const double* __restrict__ phis = fp.phis[blockIdx.z];
-    const double* __restrict__ phi0 = fp.phi0[blockIdx.z];
-    double* __restrict__ out = fp.out[blockIdx.z];
     const long N = (long)nx * ny;
     const long e = (long)iy * nx + ix;
     const bool hasL = ix > 0, hasR = ix + 1 < nx, hasB = iy > 0, hasT = iy + 1 < ny;
 
-    double c[NC], cl[NC], cr[NC], cb[NC], ct[NC], vx[NC], vy[NC];
+    // the advecting velocity is shared by all fields: load it once per element
+    double vx[NC], vy[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
-        c[k] = phis[k * N + e];
-        cl[k] = hasL ? phis[k * N + e - 1] : 0.;
-        cr[k] = hasR ? phis[k * N + e + 1] : 0.;
-        cb[k] = hasB ? phis[k * N + e - nx] : 0.;
-        ct[k] = hasT ? phis[k * N + e + nx] : 0.;
         vx[k] = ORDER > 0 ? vx_dg[k * N + e] * ihx : 0.;
         vy[k] = ORDER > 0 ? vy_dg[k * N + e] * ihy : 0.;
     }
@@ -161,16 +155,30 @@ __global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, in
         E.l[g] = un_x[g * NEX + exl], E.r[g] = un_x[g * NEX + exl + 1];
         E.b[g] = un_y[g * NEY + eyb], E.t[g] = un_y[g * NEY + eyb + nx];
     }
-    double rhs[NC];
-    transport_rhs<ORDER>(c, cl, cr, cb, ct, vx, vy, E, ihx, ihy, rhs);
-    if (a != 0.) {
+    for (int f = 0; f < nfields; ++f) {
+        const double* __restrict__ phis = fp.phis[f];
+        const double* __restrict__ phi0 = fp.phi0[f];
+        double* __restrict__ out = fp.out[f];
+        double c[NC], cl[NC], cr[NC], cb[NC], ct[NC];
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
-            out[i * N + e] = a * phi0[i * N + e] + b * (c[i] + dt * IMASS[i] * rhs[i]);
-    } else {
+        for (int k = 0; k < NC; ++k) {
+            c[k] = phis[k * N + e];
+            cl[k] = hasL ? phis[k * N + e - 1] : 0.;
+            cr[k] = hasR ? phis[k * N + e + 1] : 0.;
+            cb[k] = hasB ? phis[k * N + e - nx] : 0.;
+            ct[k] = hasT ? phis[k * N + e + nx] : 0.;
+        }
+        double rhs[NC];
+        transport_rhs<ORDER>(c, cl, cr, cb, ct, vx, vy, E, ihx, ihy, rhs);
+        if (a != 0.) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
-            out[i * N + e] = b * (c[i] + dt * IMASS[i] * rhs[i]);
+            for (int i = 0; i < NC; ++i)
+                out[i * N + e] = a * phi0[i * N + e] + b * (c[i] + dt * IMASS[i] * rhs[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                out[i * N + e] = b * (c[i] + dt * IMASS[i] * rhs[i]);
+        }
     }
 }
 
@@ -312,8 +320,11 @@ int launch_stage(nsdg_ctx* ctx, int j0, int j1, double dt, double a, double b, i
     const double* vx, const double* vy, const double* unx, const double* uny)
 {
     if (ctx->transport_variant == 0) {
-        const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4), nfields);
-        hipLaunchKernelGGL(transport_stage_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, 1. / ctx->hx,
+        // rows per workgroup: the rows above / below a workgroup's band are read a second time by the neighbouring
+        // workgroup, so taller bands mean fewer redundant reads (band + 2 rows read per band)
+        const int br = ctx->transport_rows > 0 ? ctx->transport_rows : 4;
+        const dim3 block(64, br), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, br));
+        hipLaunchKernelGGL(transport_stage_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, nfields, 1. / ctx->hx,
             1. / ctx->hy, dt, a, b, fp, vx, vy, unx, uny);
     } else {
         // strip height: enough waves to fill the chip several times over (the kernel is light: ~8 waves/SIMD),
@@ -347,6 +358,7 @@ int nsdg_transport_variant_set(nsdg_ctx* ctx, int32_t variant, int32_t strip_row
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
     NSDG_CHECK_ARG(variant == 0 || variant == 1, "variant must be 0 (gather) or 1 (march)");
     NSDG_CHECK_ARG(strip_rows >= 0 && strip_rows <= 4096, "strip rows must be in 0..4096 (0 = default)");
+    NSDG_CHECK_ARG(variant != 0 || strip_rows <= 4, "the gather kernel takes at most 4 rows per workgroup");
     ctx->transport_variant = variant;
     ctx->transport_rows = strip_rows;
     return NSDG_OK;
