@@ -73,6 +73,25 @@ __device__ __forceinline__ double fast_sqrt(double x)
     return x > 0. ? g : 0.;
 }
 
+// Neighbour-lane exchange of the marching kernels as DPP moves (GFX9 wave_shr:1 / wave_shl:1 shift the
+// whole 64-lane wavefront by one lane): two VALU moves per double instead of two ds_bpermute round
+// trips through the LDS crossbar with their s_waitcnt.  The lane without a neighbour keeps its own
+// value (it is a redundant column whose result is discarded) -- same semantics as __shfl_up/down(x, 1).
+__device__ __forceinline__ double lane_from_left(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false); // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_from_right(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false); // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 constexpr double SF_G = 0.3872983346207417; // Gauss abscissa sqrt(3/5)/2 on [-1/2, 1/2]
 constexpr double SF_P2E = 1. / 15.; // p2 at the outer Gauss points
 constexpr double SF_P2M = -1. / 12.; // p2 at the middle Gauss point

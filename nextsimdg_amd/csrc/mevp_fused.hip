@@ -44,7 +44,7 @@ struct StressPtrs {
 __device__ __forceinline__ double shift_up(double x)
 {
     // value of lane-1 (lane 0 keeps its own; it is a redundant column whose result is discarded)
-    return __shfl_up(x, 1);
+    return lane_from_left(x);
 }
 
 template <int MINW>

@@ -33,8 +33,8 @@ struct StressPtrs2 {
     double *o11, *o12, *o22;
 };
 
-__device__ __forceinline__ double from_left(double x) { return __shfl_up(x, 1); }
-__device__ __forceinline__ double from_right(double x) { return __shfl_down(x, 1); }
+__device__ __forceinline__ double from_left(double x) { return lane_from_left(x); }
+__device__ __forceinline__ double from_right(double x) { return lane_from_right(x); }
 
 // Everything of one element row that sub-iteration p+1 needs from sub-iteration p.  Two such sets
 // alternate between "being written by A(t)" and "being read by B(t+1)", so nothing is copied when the
