@@ -26,6 +26,26 @@
 // after every pass.
 #include "mevp_common.h"
 
+#ifdef NSDG_STAMPS
+// Diagnostic build only (tools/ab_build.sh stamps -DNSDG_STAMPS): per-phase shader-cycle totals of one march,
+// s_memtime stamps fenced by scheduling barriers.  Never defined in the product build.
+__device__ unsigned nsdg_stamp_acc[64 * 16];
+#define NSDG_STAMP(k)                                            \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+        stamp_acc[k] += now_ - stamp_last;                       \
+        stamp_last = now_;                                       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define NSDG_STAMP_ARGS , unsigned (&stamp_acc)[10], unsigned& stamp_last
+#define NSDG_STAMP_PASS , stamp_acc, stamp_last
+#else
+#define NSDG_STAMP(k)
+#define NSDG_STAMP_ARGS
+#define NSDG_STAMP_PASS
+#endif
+
 namespace nsdg_mevp_detail {
 
 struct StressPtrs2 {
@@ -61,9 +81,10 @@ struct TopCarry {
 // One march step: A(t) = sub-iteration p on row t into `cur`; B(t) = sub-iteration p+1 on row t-1 from `prev`.
 __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry& cur, RowCarry& prev, TopCarry& ca, TopCarry& cb,
     const StressPtrs2& S, const double* __restrict__ u_old, const double* __restrict__ v_old, const double* __restrict__ packed,
-    const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+    const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new NSDG_STAMP_ARGS)
 {
     const int nn = M.nn, ix = M.ix;
+    NSDG_STAMP(0);
     // ---------------------------------------------------------------------- A(t): sub-iteration p on row t
     if (t <= M.tend) { // the last march step only drains B
         const long ts = tile_off(ix, t, M.ntx, 8), tp = tile_off(ix, t, M.ntx, 9);
@@ -88,9 +109,12 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
         load_nodal(packed, nV + 1, cur.c[1]);
         load_nodal(packed, nV + nn, cur.c[2]);
         load_nodal(packed, nV + nn + 1, cur.c[3]);
+        NSDG_STAMP(1);
         stress_update(ul, vl, cur.P, M.ihx, M.ihy, M.ialpha, M.dmin2, cur.s11, cur.s12, cur.s22);
+        NSDG_STAMP(2);
         double cx[9], cy[9];
         node_contrib_all(cur.s11, cur.s12, cur.s22, M.hx, M.hy, cx, cy);
+        NSDG_STAMP(3);
         const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
         const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
         const bool hasB = t > 0;
@@ -117,6 +141,7 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
             cur.u[k] = cur.v[k] = 0.; // node row 2*ny is the top boundary
     }
 
+    NSDG_STAMP(4);
     // ---------------------------------------------------------------------- B(t): sub-iteration p+1 on row r = t-1
     const int r = t - 1;
     if (r >= M.tbeg && r >= M.y0 - 1 && r < M.y1) { // wave-uniform
@@ -135,6 +160,7 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
         ul[5] = M.lastcol ? 0. : r5u, vl[5] = M.lastcol ? 0. : r5v;
         ul[8] = M.lastcol ? 0. : r8u, vl[8] = M.lastcol ? 0. : r8v;
         stress_update(ul, vl, prev.P, M.ihx, M.ihy, M.ialpha, M.dmin2, prev.s11, prev.s12, prev.s22);
+        NSDG_STAMP(5);
         const bool store = M.own && r >= M.y0;
         if (store) {
             const long ts = tile_off(ix, r, M.ntx, 8);
@@ -146,7 +172,9 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
             }
         }
         double cx[9], cy[9];
+        NSDG_STAMP(6);
         node_contrib_all(prev.s11, prev.s12, prev.s22, M.hx, M.hy, cx, cy);
+        NSDG_STAMP(7);
         const double l2x = from_left(cx[2]), l2y = from_left(cy[2]);
         const double l5x = from_left(cx[5]), l5y = from_left(cy[5]);
         if (r >= M.y0) { // wave-uniform: rows below y0 only feed the carried contributions
@@ -190,6 +218,7 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
         cb.x6 = cx[6], cb.y6 = cy[6], cb.x7 = cx[7], cb.y7 = cy[7];
         cb.xl8 = from_left(cx[8]), cb.yl8 = from_left(cy[8]);
     }
+    NSDG_STAMP(8);
 }
 
 __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int R, int ncw, double hx, double hy,
@@ -222,16 +251,33 @@ __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx,
     for (int k = 0; k < 4; ++k)
         Y.u[k] = Y.v[k] = 0.;
     TopCarry ca, cb; // sub-iteration p (row t-1) and p+1 (row t-2)
+#ifdef NSDG_STAMPS
+    unsigned stamp_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned stamp_last = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
     for (int t = M.tbeg; t <= M.tend + 1; t += 2) {
-        march_step(M, t, X, Y, ca, cb, S, u_old, v_old, packed, pg, u_new, v_new);
+        march_step(M, t, X, Y, ca, cb, S, u_old, v_old, packed, pg, u_new, v_new NSDG_STAMP_PASS);
         if (t + 1 <= M.tend + 1)
-            march_step(M, t + 1, Y, X, ca, cb, S, u_old, v_old, packed, pg, u_new, v_new);
+            march_step(M, t + 1, Y, X, ca, cb, S, u_old, v_old, packed, pg, u_new, v_new NSDG_STAMP_PASS);
     }
+#ifdef NSDG_STAMPS
+    stamp_acc[9] = M.tend + 2 - M.tbeg; // march steps
+    if (lane == 0 && (wave & 63) == 0 && wave / 64 < 64)
+        for (int k = 0; k < 10; ++k)
+            nsdg_stamp_acc[(wave / 64) * 16 + k] = stamp_acc[k];
+#endif
 }
 
 } // namespace nsdg_mevp_detail
 
 using namespace nsdg_mevp_detail;
+
+#ifdef NSDG_STAMPS
+extern "C" int nsdg_debug_read_stamps(unsigned* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nsdg_stamp_acc), sizeof(unsigned) * 64 * 16);
+}
+#endif
 
 // two sub-iterations on the owned rows [j0, j1) of the local array
 int nsdg_launch_mevp_fused2(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,

@@ -1,0 +1,44 @@
+"""Diagnostic: runs a few mEVP passes at 2048x2048 with the -DNSDG_STAMPS build (tools/ab_build.sh stamps -DNSDG_STAMPS)
+and prints the shader cycles per march step spent in each phase of mevp_fused2_kernel (median over sampled waves)."""
+import ctypes
+import os
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+os.environ["NSDG_LIB"] = os.path.join(root, "nextsimdg_amd", "lib", "alt", sys.argv[1] if len(sys.argv) > 1 else "stamps", "libnsdg.so")
+import numpy as np
+import torch
+
+from nextsimdg_amd import abi, rowblock, synthetic
+
+nx = ny = 2048
+L, dt, nsub = 512e3, 120.0, 8
+dev = torch.device("cuda:0")
+ctx = abi.Context(dev)
+bt = synthetic.BoxTest(nx, ny, L)
+alpha = bt.stable_alpha(dt)
+ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+blk = rowblock.RowBlock(nx, ny, 0, 1, 2, 1)
+core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev)
+H, A = bt.dg_fields()
+uo, vo = bt.ocean()
+ua, va = bt.wind(0.0)
+core.load_global(H, A, uo, vo, ua, va)
+for _ in range(2):
+    core.step()
+torch.cuda.synchronize()
+lib = abi.load_library()
+out = (ctypes.c_uint * (64 * 16))()
+rc = lib.nsdg_debug_read_stamps(out)
+a = np.array(out[:], dtype=np.float64).reshape(64, 16)
+a = a[a[:, 9] > 0]
+steps = a[:, 9:10]
+per = a[:, :9] / steps
+names = ["step start -> A loads issued (B tail of previous step included)", "A: loads issued (addressing)", "A: stress update", "A: nodal contributions",
+         "A: node updates + carries", "B: stress update", "B: stress stores", "B: nodal contributions", "B: node updates + stores"]
+print("waves sampled %d, march steps per wave %s" % (len(a), sorted(set(a[:, 9].astype(int)))))
+med = np.median(per, axis=0)
+for k in range(9):
+    print("%-70s %8.0f cycles/step  (min %6.0f max %6.0f)" % (names[k], med[k], per[:, k].min(), per[:, k].max()))
+print("%-70s %8.0f" % ("sum", med.sum()))
