@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="mEVP kernel variant (default: library default)")
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
+    ap.add_argument("--passes-per-exchange", type=int, default=4,
+                    help="N > 1: two-iteration mEVP passes between two ghost-row exchanges (ghost depth 2k / 2k-1 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -284,7 +286,9 @@ def main():
     bt = synthetic.BoxTest(nx, ny, L)
     alpha = bt.stable_alpha(dt)  # alpha = beta from the linear-stability bound of the sub-cycle on this mesh
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
-    depth = (2, 1) if ctx.mevp_variant == 2 else (1, 1)  # ghost element rows below / above
+    # ghost element rows below / above: (2k, 2k-1) for k two-iteration passes between two exchanges
+    kpass = max(1, min(args.passes_per_exchange, (ny // world) // 16)) if world > 1 else 1
+    depth = (2 * kpass, 2 * kpass - 1) if ctx.mevp_variant == 2 else (1, 1)
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
     coupled = args.workload == "coupled"
     core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device)
@@ -340,7 +344,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("column thermodynamics + " if coupled else "") + "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
                                    "512 km box test, dt=120 s, alpha=beta=%.0f (stability bound of the mesh)" % (nx, ny, nsub, alpha),
-                       "decomposition": "%d row block(s), ghost-row send/recv" % world,
+                       "decomposition": "%d row block(s), ghost-row send/recv" % world + (
+                           ", ghost depth %d/%d rows, one exchange per %d mEVP passes" % (depth[0], depth[1], core.group_passes) if world > 1 else ""),
                        "mevp_passes": "two sub-iterations per kernel pass" if core.two_per_pass else "one sub-iteration per kernel pass",
                        "mevp_variant": args.variant if args.variant is not None else "default"},
             "roofline": {"bound": "hbm", "kernel": "mEVP sub-iteration", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx,
 #ifdef NSDG_STAMPS
     unsigned stamp_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned stamp_last = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned stamp_t0 = stamp_last, stamp_rt0 = (unsigned)__builtin_amdgcn_s_memrealtime(); // 100 MHz reference
 #endif
     for (int t = M.tbeg; t <= M.tend + 1; t += 2) {
         march_step(M, t, X, Y, ca, cb, S, u_old, v_old, packed, pg, u_new, v_new NSDG_STAMP_PASS);
@@ -262,9 +263,12 @@ __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx,
     }
 #ifdef NSDG_STAMPS
     stamp_acc[9] = M.tend + 2 - M.tbeg; // march steps
-    if (lane == 0 && (wave & 63) == 0 && wave / 64 < 64)
+    if (lane == 0 && (wave & 63) == 0 && wave / 64 < 64) {
         for (int k = 0; k < 10; ++k)
             nsdg_stamp_acc[(wave / 64) * 16 + k] = stamp_acc[k];
+        nsdg_stamp_acc[(wave / 64) * 16 + 10] = (unsigned)__builtin_amdgcn_s_memtime() - stamp_t0; // shader cycles of the march
+        nsdg_stamp_acc[(wave / 64) * 16 + 11] = (unsigned)__builtin_amdgcn_s_memrealtime() - stamp_rt0; // the same in 10 ns ticks
+    }
 #endif
 }
 

@@ -8,9 +8,15 @@ send/recv of ghost rows through torch.distributed (backend "nccl" = RCCL over xG
 "gloo" in the CPU tests) -- there is no collective on the data path:
 
   per mEVP sub-iteration : velocity node rows   up: 2 rows x (u,v) x (2nx+1)     down: 1 row x (u,v)
-                           (the stress of the ghost row below is NOT exchanged: it is updated
-                            redundantly by the rank itself, bit-identically to its owner)
-  per RK stage           : one ghost element row of each advected field in both directions
+   (single-iteration       (the stress of the ghost row below is NOT exchanged: it is updated
+    kernel)                 redundantly by the rank itself, bit-identically to its owner)
+  per GROUP of k passes  : two-iterations-per-pass kernel with ghost depth (2k, 2k-1): 2k stress rows + 4k node
+   (2k sub-iterations)     rows travel up, 2k-1 stress rows + 4k-1 node rows down.  Between two exchanges a
+                           rank runs k passes on a row range that shrinks by 2 rows on each side per pass --
+                           the ghost rows are advanced redundantly, bit-identically to their owners -- so the
+                           number of messages per step drops by k (latency-avoiding halo)
+  per RK stage           : the ghost element rows of each advected field in both directions (ghost depth
+                           >= 3: once per step, the first two stages advance ghost rows redundantly)
 
 Ownership of CG2 nodes is bottom-left: rank r owns node rows [2*r0, 2*r1); the global top node row is a
 Dirichlet boundary.  Node rows of a [rows, cols] array are contiguous, so velocity halos are sent
@@ -29,8 +35,11 @@ def split_rows(ny, world, rank):
 
 class RowBlock:
     """index bookkeeping of one rank's local array.  `depth_below` / `depth_above` are the numbers of ghost
-    element rows kept on the interior sides: (1, 1) for one mEVP sub-iteration per pass, (2, 1) for the
-    two-sub-iterations-per-pass kernel, which reads two element rows below and one above the rows it updates."""
+    element rows kept on the interior sides: (1, 1) for one mEVP sub-iteration per pass, (2k, 2k-1) for the
+    two-sub-iterations-per-pass kernel with k passes between two ghost-row exchanges.  That kernel reads the
+    stress of two element rows below and one above the rows it updates and the velocity up to the bottom node
+    row of the second element row above (owned by that row), so complete rows shrink by 2 per pass on both
+    sides; k = 1 gives the (2, 1) of an exchange after every pass."""
 
     def __init__(self, nx, ny, rank=0, world=1, depth_below=1, depth_above=1):
         if ny < world * max(depth_below, depth_above, 1) * 2:
@@ -92,7 +101,7 @@ class HaloExchanger:
 
     def nodal_start(self, fields, rows_down=1):
         """post the exchange of the ghost node rows: 2*depth_below rows travel upwards, `rows_down` rows
-        (1 for the single-iteration kernel, 3 for the two-iteration kernel) downwards"""
+        (1 for the single-iteration kernel, 2*depth_above + 1 for the two-iteration kernel) downwards"""
         key = ("n", rows_down) + tuple(f.data_ptr() for f in fields)
         return self._post(key, lambda: self._nodal_ops(fields, rows_down))
 
@@ -192,8 +201,10 @@ class DynamicsCore:
         self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
         self.overlap = overlap
         self._calls = {}
-        # two sub-iterations per pass need the (2, 1) ghost depth; a single domain has no ghosts at all
-        self.two_per_pass = getattr(ops, "mevp_variant", None) == 2 and (blk.world == 1 or (blk.depth_below, blk.depth_above) == (2, 1))
+        # two sub-iterations per pass need a (2k, 2k-1) ghost depth; a single domain has no ghosts at all
+        deep = blk.depth_below >= 2 and blk.depth_below % 2 == 0 and blk.depth_above == blk.depth_below - 1
+        self.two_per_pass = getattr(ops, "mevp_variant", None) == 2 and (blk.world == 1 or deep)
+        self.group_passes = blk.depth_below // 2 if (self.two_per_pass and blk.world > 1) else 1  # passes between two exchanges
         self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
         nx, ny = blk.nx, blk.ny
         z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
@@ -236,22 +247,29 @@ class DynamicsCore:
         ops.mevp_prepare(self.dt, self.H, self.A, (self.ua, self.va), (self.uo, self.vo), (self.u, self.v), self.packed)
         it = 0
         if self.two_per_pass:
-            # two sub-iterations per pass (intermediate stress / velocity stay in registers); with several
-            # ranks the ghost rows of the new stress and velocity are refreshed after every pass
-            split2 = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 8
+            # two sub-iterations per pass (intermediate stress / velocity stay in registers).  With several ranks
+            # the passes run in groups of k = group_passes: pass i of a group of m covers the owned rows plus
+            # 2(m-i) ghost rows on each side (what the remaining passes of the group will read), and only
+            # after the last pass the ghost rows of the new stress and velocity are exchanged.
+            k = self.group_passes
+            split2 = self.overlap and b.world > 1 and (b.j1 - b.j0) >= b.depth_below + b.depth_above + 5
             while it + 1 < self.nsub:
-                calls = self._iterate2_calls(split2)
-                for c in calls[:-1]:
-                    c()
-                pending = self._ghost_exchange_start() if split2 else None
-                calls[-1]()
-                if pending is None:
-                    pending = self._ghost_exchange_start()
-                self._ghost_exchange_finish(pending)
-                self.u, self.ub = self.ub, self.u
-                self.v, self.vb = self.vb, self.v
-                self.s, self.sb = self.sb, self.s
-                it += 2
+                m = min(k, (self.nsub - it) // 2)
+                for i in range(1, m + 1):
+                    last = i == m
+                    calls = self._iterate2_calls(split2 and last, m - i)
+                    for c in calls[:-1]:
+                        c()
+                    pending = self._ghost_exchange_start() if (split2 and last) else None
+                    calls[-1]()
+                    if last:
+                        if pending is None:
+                            pending = self._ghost_exchange_start()
+                        self._ghost_exchange_finish(pending)
+                    self.u, self.ub = self.ub, self.u
+                    self.v, self.vb = self.vb, self.v
+                    self.s, self.sb = self.sb, self.s
+                    it += 2
         split = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 4 and not self.two_per_pass
         for _ in range(self.nsub - it):
             uvn = (self.ub, self.vb)
@@ -276,19 +294,22 @@ class DynamicsCore:
             self.s, self.sb = self.sb, self.s
 
     def _ghost_exchange_start(self):
-        """two-iterations-per-pass ghost zones: velocity node rows (4 up, 3 down) and stress rows (2 up, 1 down)"""
+        """two-iterations-per-pass ghost zones of depth (2k, 2k-1): velocity node rows (4k up, 4k-1 down) and
+        stress rows (2k up, 2k-1 down) in one batch"""
         if self.blk.world == 1:
             return None
-        return self.halo.rows_exchange_start(self.sb, self.ops.private_rows, nodal_fields=(self.ub, self.vb), rows_down=3)
+        return self.halo.rows_exchange_start(self.sb, self.ops.private_rows, nodal_fields=(self.ub, self.vb),
+                                             rows_down=2 * self.blk.depth_above + 1)
 
     def _ghost_exchange_finish(self, pending):
         if pending is not None:
             self.halo.rows_exchange_finish(*pending)
 
-    def _iterate2_calls(self, split):
-        """launches of one two-iteration pass for the current ping-pong parity (bound once, cached):
-        the rows whose results travel to the neighbours first, the interior last"""
-        key = (self.u.data_ptr(), self.s[0].data_ptr(), split, 2)
+    def _iterate2_calls(self, split, ext=0):
+        """launches of one two-iteration pass for the current ping-pong parity (bound once, cached).
+        ext > 0: a pass inside a group, one launch over the owned rows extended by 2*ext ghost rows on each
+        side.  ext == 0 and split: the rows whose results travel to the neighbours first, the interior last"""
+        key = (self.u.data_ptr(), self.s[0].data_ptr(), split, 2, ext)
         calls = self._calls.get(key)
         if calls is not None:
             return calls
@@ -298,14 +319,14 @@ class DynamicsCore:
         if bind is None:
             bind = lambda *a: (lambda: ops.mevp_iterate2(*a))
         rng = []
-        lo, hi = b.j0, b.j1
-        if split:
-            if b.above is not None:  # top 2 owned element rows: 2 stress rows + 4 node rows go up
-                rng.append((b.j1 - 2, b.j1))
-                hi = b.j1 - 2
-            if b.below is not None:  # bottom 2 owned element rows: 1 stress row + 3 node rows go down
-                rng.append((b.j0, b.j0 + 2))
-                lo = b.j0 + 2
+        lo, hi = max(b.j0 - 2 * ext, 0), min(b.j1 + 2 * ext, b.ny)
+        if split and ext == 0:
+            if b.above is not None:  # top owned element rows: depth_below stress rows + 2*depth_below node rows go up
+                rng.append((b.j1 - b.depth_below, b.j1))
+                hi = b.j1 - b.depth_below
+            if b.below is not None:  # bottom owned element rows: depth_above stress rows + 2*depth_above+1 node rows go down
+                rng.append((b.j0, b.j0 + b.depth_above + 1))
+                lo = b.j0 + b.depth_above + 1
         rng.append((lo, hi))
         calls = [bind(j0, j1, self.s, self.sb, uv, uvn, self.packed, self.pg) for (j0, j1) in rng]
         self._calls[key] = calls
@@ -342,11 +363,18 @@ class DynamicsCore:
         ops, b = self.ops, self.blk
         ops.prepare_advection(self.ORDER, self.u, self.v, *self.adv)
         f = [self.H, self.A]
-        # Shu-Osher SSP-RK3: out = a*phi0 + b*(phis + dt L(phis))
-        ops.transport_stage(self.ORDER, b.j0, b.j1, self.dt, 0.0, 1.0, f, f, self.t1, self.adv)
-        self.halo.element(self.t1)
-        ops.transport_stage(self.ORDER, b.j0, b.j1, self.dt, 0.75, 0.25, f, self.t1, self.t2, self.adv)
-        self.halo.element(self.t2)
+        # Shu-Osher SSP-RK3: out = a*phi0 + b*(phis + dt L(phis)).  A stage reads one element row on each side
+        # of the rows it updates: with at least 3 ghost rows per interior side the first two stages also
+        # advance 2 / 1 ghost rows redundantly (bit-identically to their owners) and the ghost rows are
+        # exchanged once per step instead of after every stage.
+        deep = b.world > 1 and min(b.depth_below, b.depth_above) >= 3
+        ext = (lambda e: (max(b.j0 - e, 0), min(b.j1 + e, b.ny))) if deep else (lambda e: (b.j0, b.j1))
+        ops.transport_stage(self.ORDER, *ext(2), self.dt, 0.0, 1.0, f, f, self.t1, self.adv)
+        if not deep:
+            self.halo.element(self.t1)
+        ops.transport_stage(self.ORDER, *ext(1), self.dt, 0.75, 0.25, f, self.t1, self.t2, self.adv)
+        if not deep:
+            self.halo.element(self.t2)
         ops.transport_stage(self.ORDER, b.j0, b.j1, self.dt, 1.0 / 3.0, 2.0 / 3.0, f, self.t2, self.t1, self.adv)
         self.halo.element(self.t1)
         # the new state is t1 (ghost rows refreshed); swap buffers instead of copying

@@ -117,13 +117,13 @@ def fields(nx, ny):
     return bt, H, A, uo, vo, 3.0 * ua, 3.0 * va
 
 
-def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, overlap):
+def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, overlap, group=1):
     try:
         ctx = abi.Context(torch.device("cuda:0"))
         ctx.set_mevp_variant(variant)
         ctx.set_mevp_params(ctx.mevp_default_params(alpha=300.0, beta=300.0))
         bt, H, A, uo, vo, ua, va = fields(nx, ny)
-        depth = (2, 1) if variant == 2 else (1, 1)
+        depth = (2 * group, 2 * group - 1) if variant == 2 else (1, 1)  # `group` passes between two exchanges
         blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
         cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
         core = cls(ctx, blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cuda"), exchanger=ThreadExchanger(blk, mailbox),
@@ -146,9 +146,9 @@ def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, 
         out[rank] = e
 
 
-def run_world(world, variant, coupled, nx, ny, nsub, nsteps, overlap=True):
+def run_world(world, variant, coupled, nx, ny, nsub, nsteps, overlap=True, group=1):
     mailbox, out = Mailbox(), {}
-    threads = [threading.Thread(target=run_rank, args=(r, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, overlap))
+    threads = [threading.Thread(target=run_rank, args=(r, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, overlap, group))
                for r in range(world)]
     for t in threads:
         t.start()
@@ -170,6 +170,20 @@ def test_row_blocks_on_one_gpu_equal_single_domain_bitwise(gpu, world, variant, 
         got = torch.cat([parts[r][key] for r in range(world)], dim=dim)
         assert got.shape == ref[key].shape, key
         assert torch.equal(got, ref[key]), (key, world, variant)
+
+
+@pytest.mark.parametrize("world,group,nsub,coupled", [(2, 2, 9, False), (3, 4, 19, False), (4, 3, 13, True)])
+def test_grouped_passes_with_deep_ghost_zones_bitwise(gpu, world, group, nsub, coupled):
+    """latency-avoiding halo on the real kernels: `group` two-iteration passes between two ghost exchanges on
+    ghost zones of depth (2*group, 2*group - 1), ghost rows advanced redundantly; odd nsub and a shorter last
+    group.  Bit-identical to the single-domain run."""
+    nx, ny, nsteps = 150, 128, 2
+    ref = run_world(1, 2, coupled, nx, ny, nsub, nsteps)[0]
+    assert float(ref["u"].abs().max()) > 1e-5
+    parts = run_world(world, 2, coupled, nx, ny, nsub, nsteps, group=group)
+    for key, dim in (("H", 1), ("A", 1), ("u", 0), ("v", 0), ("s11", 0)):
+        got = torch.cat([parts[r][key] for r in range(world)], dim=dim)
+        assert torch.equal(got, ref[key]), (key, world, group)
 
 
 def test_overlap_split_does_not_change_results(gpu):

@@ -38,7 +38,7 @@ def column_fields_2d(seed=5):
     return f
 
 
-def run_core(rank, world, overlap=True, coupled=False, variant=1):
+def run_core(rank, world, overlap=True, coupled=False, variant=1, group=1, nsub=NSUB):
     from oracle_ops import OracleOps
 
     bt = synthetic.BoxTest(NX, NY)
@@ -48,10 +48,10 @@ def run_core(rank, world, overlap=True, coupled=False, variant=1):
     H[1:3] += 0.02 * rng.standard_normal((2, NY, NX))
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
-    depth = (2, 1) if variant == 2 else (1, 1)
+    depth = (2 * group, 2 * group - 1) if variant == 2 else (1, 1)  # `group` passes between two ghost exchanges
     blk = rowblock.RowBlock(NX, NY, rank, world, *depth)
     cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
-    core = cls(OracleOps(mevp_variant=variant, alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, NSUB, torch.device("cpu"),
+    core = cls(OracleOps(mevp_variant=variant, alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cpu"),
                overlap=overlap)
     core.load_global(H, A, uo, vo, 3.0 * ua, 3.0 * va)
     if coupled:
@@ -61,12 +61,14 @@ def run_core(rank, world, overlap=True, coupled=False, variant=1):
     return core
 
 
-def worker(rank, world, port, outdir, overlap=True, coupled=False, variant=1):
+def worker(rank, world, port, outdir, overlap=True, coupled=False, variant=1, group=1, nsub=NSUB):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        core = run_core(rank, world, overlap, coupled, variant)
+        core = run_core(rank, world, overlap, coupled, variant, group, nsub)
+        if variant == 2 and world > 1:
+            assert core.two_per_pass and core.group_passes == group
         out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
         out["s11"] = core.owned(core.s[0]).clone()
         if coupled:
@@ -114,6 +116,22 @@ def test_row_block_run_equals_single_domain_bitwise(world, overlap, variant, tmp
         got = torch.cat([p[key] for p in parts], dim=0)
         assert got.shape == full.shape
         assert torch.equal(got, full), key
+
+
+@pytest.mark.parametrize("world,overlap,group,nsub", [(2, True, 2, 9), (3, True, 2, 9), (2, False, 3, 15), (2, True, 3, 7)])
+def test_grouped_passes_with_deep_ghost_zones_bitwise(world, overlap, group, nsub, tmp_path):
+    """latency-avoiding halo: `group` two-iteration passes between two exchanges on ghost zones of depth
+    (2*group, 2*group - 1); the ghost rows are advanced redundantly.  nsub is odd (a trailing single
+    sub-iteration) and not a multiple of the group (a shorter last group).  Must equal the 1-rank run."""
+    ref = run_core(0, 1, variant=2, nsub=nsub)
+    assert float(ref.u.abs().max()) > 1e-5
+    port = free_port()
+    mp.spawn(worker, args=(world, port, str(tmp_path), overlap, False, 2, group, nsub), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
+        assert torch.equal(torch.cat([p[key] for p in parts], dim=1), full), key
+    for key, full in (("u", ref.u), ("v", ref.v)):
+        assert torch.equal(torch.cat([p[key] for p in parts], dim=0), full), key
 
 
 def test_coupled_thermodynamics_dynamics_row_blocks(tmp_path):

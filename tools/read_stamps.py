@@ -42,3 +42,6 @@ med = np.median(per, axis=0)
 for k in range(9):
     print("%-70s %8.0f cycles/step  (min %6.0f max %6.0f)" % (names[k], med[k], per[:, k].min(), per[:, k].max()))
 print("%-70s %8.0f" % ("sum", med.sum()))
+clk = a[:, 10] / (a[:, 11] * 10e-9) / 1e9
+print("in-kernel shader clock (s_memtime / s_memrealtime): median %.2f GHz (min %.2f, max %.2f); march of one wave %.3f ms"
+      % (np.median(clk), clk.min(), clk.max(), np.median(a[:, 11]) * 10e-6))
