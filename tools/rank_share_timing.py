@@ -1,0 +1,60 @@
+"""Diagnostic: GPU time of ONE rank's share of the 2048x2048 dynamics step for a world of W row blocks, measured
+on a single GPU with the ghost exchanges replaced by no-ops (the values in the ghost rows go stale, only the
+timing is meaningful).  Gives the compute-side bound on the strong-scaling speed-up that the 8-GPU run of the
+driver can reach: T(1 block) / T(share).  usage: python tools/rank_share_timing.py [W ...]"""
+import os
+import sys
+import time
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import torch
+
+from nextsimdg_amd import abi, rowblock, synthetic
+
+
+class NullExchanger(rowblock.HaloExchanger):
+    def _post(self, key, build):
+        return []
+
+    def rows_exchange_start(self, fields, rows_of, nodal_fields=(), rows_down=1):
+        return [], []
+
+    def element(self, fields):
+        return
+
+
+def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3):
+    dev = torch.device("cuda:0")
+    ctx = abi.Context(dev)
+    L, dt = 512e3, 120.0
+    bt = synthetic.BoxTest(nx, ny, L)
+    alpha = bt.stable_alpha(dt)
+    ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+    rank = world // 2
+    depth = (2 * kpass, 2 * kpass - 1)
+    blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
+    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=NullExchanger(blk) if world > 1 else None)
+    H, A = bt.dg_fields()
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    core.load_global(H, A, uo, vo, ua, va)
+    core.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        core.step()
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, host / steps * 1e3, blk.ny
+
+
+if __name__ == "__main__":
+    worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    base = None
+    for w in worlds:
+        for k in ((1,) if w == 1 else (1, 4)):
+            ms, host_ms, rows = run(w, k)
+            base = ms if w == 1 else base
+            print("world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
+                  % (w, k, rows, ms, host_ms, "%.2f" % (base / ms) if base else "-"), flush=True)
