@@ -53,7 +53,7 @@ inline Model::Model()
     : modelStep(ModuleLoader::getLoader().getInstance<IModelStep>())
 {
     iterator.setIterant(modelStep.get());
-    finalFileName = "restart.nsdg";
+    finalFileName = "restart.nc"; // core/src/Model.cpp:37; written as HDF5 (Hdf5Subset.hpp)
 }
 
 inline Model::~Model()
@@ -79,12 +79,16 @@ inline void Model::configure()
     finalFileName = getConfiguration(keyMap.at(FINALFILE_KEY), finalFileName);
     modelStep->setInitFile(initialFileName);
     const std::string type = RectGrid::typeInFile(initialFileName);
-    if (!type.empty()) {
+    if (!type.empty()) { // NetCDF-4 (HDF5 subset reader) or the raw sidecar
         dataStructure = StructureFactory::generateFromFile(initialFileName);
         dataStructure->init(initialFileName);
-    } else { // no readable sidecar (e.g. the reference's NetCDF dev1.res.nc): constants from init.* keys
+        std::cout << "Initial state read from " << initialFileName << " (structure " << type << ", " << dataStructure->nx() << " x "
+                  << dataStructure->ny() << ")" << std::endl;
+    } else { // no such file: constants from the init.* keys (defaults = run/dev_res.py:10-20 of the reference)
         dataStructure = StructureFactory::generate(getConfiguration(keyMap.at(STRUCTURE_KEY), std::string("devgrid")));
         dataStructure->init("");
+        if (!initialFileName.empty())
+            std::cout << "Initial file " << initialFileName << " not found or not a restart file: constant initial state" << std::endl;
     }
     modelStep->setInitialData(*dataStructure);
     modelStep->init();

@@ -1,9 +1,11 @@
 // RectGrid.hpp -- size-configurable rectangular structure ("rectgrid") and the reference-compatible
 // fixed 10x10 "devgrid" (core/src/modules/DevGrid.cpp:16-48, DevGrid.hpp:24-73).
 //
-// Restart files: the reference writes NetCDF-4 (core/src/DevGridIO.cpp:65-210); neither netCDF nor
-// HDF5 development files exist in this image, so dump()/init() use a documented raw sidecar with
-// the same logical content: a text header
+// Restart files: the reference reads and writes NetCDF-4 (core/src/DevGridIO.cpp:65-210).  Neither netCDF
+// nor the HDF5 development files exist in this image, so init() reads such files -- the reference's own
+// run/dev1.res.nc included -- with the dependency-free HDF5-subset reader of Hdf5Subset.hpp, and dump()
+// writes HDF5 with the same groups / variable names / dimensions when the path ends in .nc, .h5 or .hdf5.
+// Any other path uses a raw sidecar with the same logical content: a text header
 //     NSDG-RESTART 1 / structure.type=<name> / data.x=<nx> / data.y=<ny> / data.nLayers=<n>
 // followed by the float64 variables hice, cice, hsnow, sst, sss (x, y) and tice (x, y, nLayers) in
 // x-major order, little endian.

@@ -1,10 +1,12 @@
 #include "RectGrid.hpp"
 
 #include <cstdint>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
 
+#include "Hdf5Subset.hpp"
 #include "ModuleLoader.hpp"
 
 namespace Nextsim {
@@ -115,14 +117,51 @@ bool readHeader(std::istream& f, std::string& type, int& nx, int& ny, int& nl)
 
 std::string RectGrid::typeInFile(const std::string& filePath)
 {
+    if (Hdf5File::isHdf5(filePath)) { // the reference's NetCDF-4 layout: group "structure", attribute "type" (StructureFactory.cpp:46-58)
+        try {
+            return Hdf5File(filePath).stringAttribute("/" + metadataNodeName(), typeNodeName());
+        } catch (const Hdf5Error&) {
+            return std::string();
+        }
+    }
     std::ifstream f(filePath, std::ios::binary);
     std::string type;
     int a, b, c;
     return (f && readHeader(f, type, a, b, c)) ? type : std::string();
 }
 
+namespace {
+bool wantsHdf5(const std::string& path)
+{
+    for (const char* ext : { ".nc", ".h5", ".hdf5" }) {
+        const std::size_t n = std::strlen(ext);
+        if (path.size() > n && path.compare(path.size() - n, n, ext) == 0)
+            return true;
+    }
+    return false;
+}
+const char* const PLANE_NAMES[5] = { "hice", "cice", "hsnow", "sst", "sss" }; // core/src/DevGridIO.cpp:35-40
+} // namespace
+
 void RectGrid::dump(const std::string& filePath) const
 {
+    // tice is (x, y, nLayers) in the file, layer-major planes in memory
+    std::vector<double> t(m_store.tice.size());
+    for (std::size_t e = 0; e < m_store.n; ++e)
+        for (int l = 0; l < m_store.nLayers; ++l)
+            t[e * m_store.nLayers + l] = m_store.tice[(std::size_t)l * m_store.n + e];
+    if (wantsHdf5(filePath)) { // groups, names and dimensions of core/src/DevGridIO.cpp:150-201
+        Hdf5Writer w;
+        w.group("/" + metadataNodeName());
+        w.stringAttribute("/" + metadataNodeName(), typeNodeName(), structureType());
+        w.group("/" + dataNodeName());
+        const std::vector<double>* planes[5] = { &m_store.hice, &m_store.cice, &m_store.hsnow, &m_store.sst, &m_store.sss };
+        for (int k = 0; k < 5; ++k)
+            w.dataset("/" + dataNodeName() + "/" + PLANE_NAMES[k], { (std::uint64_t)m_nx, (std::uint64_t)m_ny }, *planes[k]);
+        w.dataset("/" + dataNodeName() + "/tice", { (std::uint64_t)m_nx, (std::uint64_t)m_ny, (std::uint64_t)m_store.nLayers }, t);
+        w.write(filePath);
+        return;
+    }
     std::ofstream f(filePath, std::ios::binary);
     if (!f)
         throw std::runtime_error("cannot write restart file " + filePath);
@@ -134,11 +173,6 @@ void RectGrid::dump(const std::string& filePath) const
       << "variables=hice,cice,hsnow,sst,sss,tice\nEND-HEADER\n";
     for (const auto* v : { &m_store.hice, &m_store.cice, &m_store.hsnow, &m_store.sst, &m_store.sss })
         f.write(reinterpret_cast<const char*>(v->data()), (std::streamsize)(v->size() * sizeof(double)));
-    // tice is (x, y, nLayers) in the file, layer-major planes in memory
-    std::vector<double> t(m_store.tice.size());
-    for (std::size_t e = 0; e < m_store.n; ++e)
-        for (int l = 0; l < m_store.nLayers; ++l)
-            t[e * m_store.nLayers + l] = m_store.tice[(std::size_t)l * m_store.n + e];
     f.write(reinterpret_cast<const char*>(t.data()), (std::streamsize)(t.size() * sizeof(double)));
 }
 
@@ -152,6 +186,32 @@ void RectGrid::init(const std::string& filePath)
         const double sss = C::getConfiguration("init.sss", 32.0), tice = C::getConfiguration("init.tice", -1.0);
         for (cursor = 0; cursor; ++cursor)
             *cursor = PrognosticGenerator().hice(hice).cice(cice).hsnow(hsnow).sst(sst).sss(sss).tice({ tice });
+        return;
+    }
+    if (Hdf5File::isHdf5(filePath)) {
+        // NetCDF-4 restart file of the reference (core/src/DevGridIO.cpp:93-147): group "data", variables
+        // hice, cice, hsnow, sst, sss (x, y) and tice (x, y, nLayers); the number of layers is taken from
+        // the third dimension of tice (DevGridIO.cpp:97-99), element (i, j) has the linear index i*ny + j
+        const Hdf5File h(filePath);
+        const std::string g = "/" + dataNodeName() + "/";
+        const std::vector<std::uint64_t> d = h.dims(g + "tice");
+        if (d.size() != 3)
+            throw std::runtime_error("restart file " + filePath + ": tice must have the dimensions (x, y, nLayers)");
+        if (structureType() == "devgrid" && (d[0] != 10 || d[1] != 10))
+            throw std::runtime_error("devgrid restart files must be 10x10");
+        resize((int)d[0], (int)d[1], (int)d[2]);
+        std::vector<double>* planes[5] = { &m_store.hice, &m_store.cice, &m_store.hsnow, &m_store.sst, &m_store.sss };
+        for (int k = 0; k < 5; ++k) {
+            std::vector<double> v = h.readDoubles(g + PLANE_NAMES[k]);
+            if (v.size() != m_store.n)
+                throw std::runtime_error("restart file " + filePath + ": " + PLANE_NAMES[k] + " does not have x*y elements");
+            planes[k]->swap(v);
+        }
+        const std::vector<double> t = h.readDoubles(g + "tice");
+        for (std::size_t e = 0; e < m_store.n; ++e)
+            for (int l = 0; l < m_store.nLayers; ++l)
+                m_store.tice[(std::size_t)l * m_store.n + e] = t[e * m_store.nLayers + l];
+        resetCursor();
         return;
     }
     std::ifstream f(filePath, std::ios::binary);

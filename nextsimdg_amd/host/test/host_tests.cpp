@@ -4,6 +4,9 @@
 // known answers.  Tiny self-contained harness: CHECK() records failures, exit code = #failures.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
 #include <cstring>
 #include <functional>
 #include <iostream>
@@ -12,6 +15,7 @@
 
 #include "Configurator.hpp"
 #include "DynamicsStep.hpp"
+#include "Hdf5Subset.hpp"
 #include "Model.hpp"
 #include "ModuleLoader.hpp"
 #include "PhysicsModules.hpp"
@@ -392,11 +396,101 @@ static void test_hipstep_melting()
     ModuleLoader::getLoader().setAllDefaults();
 }
 
+static std::string goldenDir()
+{
+    const char* d = std::getenv("NSDG_GOLDEN_DIR");
+    return d ? std::string(d) : std::string("tests/golden");
+}
+
+static void test_restart_hdf5()
+{ // the reference's NetCDF-4 restart format (core/src/DevGridIO.cpp:65-210)
+    const std::string ref = goldenDir() + "/dev1.res.nc"; // the reference's run/dev1.res.nc (written by run/dev_res.py)
+    CHECK(Hdf5File::isHdf5(ref));
+    CHECK(!Hdf5File::isHdf5("/nonexistent/file.nc"));
+    // lookup3 known answers (the superblock / object header checksums of the file are verified while parsing)
+    CHECK(hdf5Checksum(reinterpret_cast<const unsigned char*>(""), 0) == 0xdeadbeefu);
+    CHECK(hdf5Checksum(reinterpret_cast<const unsigned char*>("Four score and seven years ago"), 30) == 0x17770551u);
+    {
+        const Hdf5File f(ref);
+        const std::vector<std::string> root = f.listGroup("/");
+        CHECK(root.size() == 2 && root[0] == "data" && root[1] == "structure");
+        CHECK(f.stringAttribute("/structure", "type") == "devgrid"); // run/dev_res.py:4
+        CHECK(f.hasAttribute("/", "_NCProperties") && !f.hasAttribute("/structure", "nope"));
+        CHECK(f.listGroup("/data").size() == 9); // 6 variables + the dimension scales x, y, nLayers (dense link storage)
+        CHECK((f.dims("/data/hice") == std::vector<std::uint64_t> { 10, 10 }));
+        CHECK((f.dims("/data/tice") == std::vector<std::uint64_t> { 10, 10, 1 }));
+        const std::pair<const char*, double> expect[] = { { "cice", 0.5 }, { "hice", 0.1 }, { "hsnow", 0.0 }, { "sss", 32. }, { "sst", -1. },
+            { "tice", -1. } }; // run/dev_res.py:10-20
+        for (const auto& e : expect) {
+            const std::vector<double> v = f.readDoubles(std::string("/data/") + e.first);
+            bool all = v.size() == 100;
+            for (double x : v)
+                all = all && x == e.second;
+            CHECK(all);
+        }
+        CHECK_THROWS_AS(f.readDoubles("/data/x"), Hdf5Error); // a dimension without coordinate values has no storage
+        CHECK_THROWS_AS(f.readDoubles("/data/nothere"), Hdf5Error);
+        CHECK(f.exists("/data/sst") && !f.exists("/data/nothere"));
+    }
+    // the structure factory and DevGrid::init read the reference's file directly
+    CHECK(RectGrid::typeInFile(ref) == "devgrid");
+    auto grid = StructureFactory::generateFromFile(ref);
+    CHECK(grid->structureType() == "devgrid");
+    grid->init(ref);
+    CHECK(grid->nx() == 10 && grid->ny() == 10 && grid->nIceLayers() == 1);
+    int n = 0;
+    bool same = true;
+    for (grid->cursor = 0; grid->cursor; ++grid->cursor, ++n)
+        same = same && grid->cursor->iceThickness() == 0.1 && grid->cursor->iceConcentration() == 0.5 && grid->cursor->snowThickness() == 0.
+            && grid->cursor->seaSurfaceTemperature() == -1. && grid->cursor->seaSurfaceSalinity() == 32. && grid->cursor->iceTemperature(0) == -1.;
+    CHECK(n == 100 && same);
+    // write -> read round trip in the same format, the index pattern of core/test/DevGrid_test.cpp:36-96
+    addConfig("[rectgrid]\nnx = 6\nny = 9\nnLayers = 2\n");
+    auto rect = StructureFactory::generate("rectgrid");
+    rect->init("");
+    CHECK(rect->nx() == 6 && rect->ny() == 9 && rect->nIceLayers() == 2);
+    int count = 0;
+    for (rect->cursor = 0; rect->cursor; ++rect->cursor, ++count) {
+        const double fr = (count / 9) * 0.01 + (count % 9) * 0.0001;
+        *rect->cursor = PrognosticGenerator().hice(1 + fr).cice(2 + fr).sst(3 + fr).sss(4 + fr).hsnow(5 + fr).tice({ -(1. + fr), -(2. + fr) });
+    }
+    const std::string path = "/tmp/nsdg_host_test_restart.nc";
+    rect->dump(path);
+    CHECK(Hdf5File::isHdf5(path) && RectGrid::typeInFile(path) == "rectgrid");
+    {
+        const Hdf5File f(path);
+        CHECK((f.dims("/data/tice") == std::vector<std::uint64_t> { 6, 9, 2 }));
+        CHECK(f.readDoubles("/data/hice")[4 * 9 + 3] == 1.0403); // element (i, j) at i*ny + j (core/src/DevGridIO.cpp:107-109)
+        CHECK(f.readDoubles("/data/tice")[(4 * 9 + 3) * 2 + 1] == -(2. + (4 * 0.01 + 3 * 0.0001))); // (x, y, nLayers), layers fastest
+    }
+    auto again = StructureFactory::generateFromFile(path);
+    again->init(path);
+    CHECK(again->nx() == 6 && again->ny() == 9 && again->nIceLayers() == 2);
+    CHECK(again->fields().hice == rect->fields().hice && again->fields().sss == rect->fields().sss && again->fields().tice == rect->fields().tice);
+    // damaged files are rejected, not misread
+    {
+        std::ifstream in(path, std::ios::binary);
+        std::vector<char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        std::vector<char> cut(bytes.begin(), bytes.begin() + 200);
+        std::ofstream("/tmp/nsdg_host_test_cut.nc", std::ios::binary).write(cut.data(), (std::streamsize)cut.size());
+        CHECK_THROWS_AS(Hdf5File("/tmp/nsdg_host_test_cut.nc").listGroup("/data"), Hdf5Error);
+        bytes[60] ^= 0x40; // inside the root object header: the checksum no longer matches
+        std::ofstream("/tmp/nsdg_host_test_bad.nc", std::ios::binary).write(bytes.data(), (std::streamsize)bytes.size());
+        CHECK_THROWS_AS(Hdf5File("/tmp/nsdg_host_test_bad.nc").listGroup("/"), Hdf5Error);
+    }
+    std::remove(path.c_str());
+    std::remove("/tmp/nsdg_host_test_cut.nc");
+    std::remove("/tmp/nsdg_host_test_bad.nc");
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+}
+
 static void test_model_dev1()
 { // BASELINE config 1: run/dev1.cfg (start 0, stop 1, time_step 1) on the 10x10 devgrid, Dummy forcing
     Configurator::clear();
     ModuleLoader::getLoader().setAllDefaults();
-    addConfig("[model]\ninit_file = dev1.res.nc\nstart = 0\nstop = 1\ntime_step = 1\nfinal_file = /tmp/nsdg_dev1_restart.nsdg\n");
+    // init_file = the reference's own NetCDF-4 restart file (run/dev1.res.nc), final_file in the same format
+    addConfig("[model]\ninit_file = " + goldenDir() + "/dev1.res.nc\nstart = 0\nstop = 1\ntime_step = 1\nfinal_file = /tmp/nsdg_dev1_restart.nc\n");
     ConfiguredModule::parseConfigurator();
     {
         Model model;
@@ -412,11 +506,11 @@ static void test_model_dev1()
             CHECK(f.sst[e] == -1.0);
         }
     } // ~Model writes the restart file
-    CHECK(RectGrid::typeInFile("/tmp/nsdg_dev1_restart.nsdg") == "devgrid");
-    auto again = StructureFactory::generateFromFile("/tmp/nsdg_dev1_restart.nsdg");
-    again->init("/tmp/nsdg_dev1_restart.nsdg");
+    CHECK(Hdf5File::isHdf5("/tmp/nsdg_dev1_restart.nc") && RectGrid::typeInFile("/tmp/nsdg_dev1_restart.nc") == "devgrid");
+    auto again = StructureFactory::generateFromFile("/tmp/nsdg_dev1_restart.nc");
+    again->init("/tmp/nsdg_dev1_restart.nc");
     CHECK(approx(again->fields().cice[99], 0.36670813101696548, 1e-12));
-    std::remove("/tmp/nsdg_dev1_restart.nsdg");
+    std::remove("/tmp/nsdg_dev1_restart.nc");
     Configurator::clear();
 }
 
@@ -464,6 +558,7 @@ int main(int argc, char** argv)
             test_timer();
             test_physics_config();
             test_structure();
+            test_restart_hdf5();
         } else {
             test_hipstep_melting();
             test_model_dev1();

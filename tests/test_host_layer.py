@@ -20,8 +20,12 @@ def host_build():
     return os.path.join(HOST, "build")
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
 def run(cmd, cwd=None):
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=cwd, timeout=300)
+    env = dict(os.environ, NSDG_GOLDEN_DIR=GOLDEN)  # where host_tests finds the reference's run/dev1.res.nc
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=cwd, timeout=300, env=env)
     return p.returncode, p.stdout.decode()
 
 
@@ -69,6 +73,17 @@ def test_dev1_cfg_end_to_end(host_build, gpu, tmp_path):
     for g, w in zip(got, want):
         assert abs(g - w) <= 1e-12 * abs(w), (got, want)
     assert os.path.exists(os.path.join(str(tmp_path), "restart.nsdg"))
+    assert "constant initial state" in out  # dev1.res.nc is not in the working directory: [init] constants were used
+    # the same run started from the reference's own NetCDF-4 restart file (tests/golden/dev1.res.nc is a copy of
+    # run/dev1.res.nc; `init_file = dev1.res.nc` is relative to the working directory as in run/dev1.sh) and
+    # writing its restart file in the same format
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"),
+                   "--model.final_file=%s" % os.path.join(str(tmp_path), "restart.nc")], cwd=GOLDEN)
+    assert rc == 0 and "Initial state read from dev1.res.nc (structure devgrid, 10 x 10)" in out, out
+    m2 = re.search(r"elements=(\d+) launches=(\d+) hice=(\S+) cice=(\S+) hsnow=(\S+) tice0=(\S+) sst=(\S+)", out)
+    assert m2 and [float(m2.group(i)) for i in range(3, 8)] == got, out
+    with open(os.path.join(str(tmp_path), "restart.nc"), "rb") as f:
+        assert f.read(8) == b"\x89HDF\r\n\x1a\n"
     # command-line override of a config value (first-wins precedence): 3 steps instead of 1
     rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"),
                    "--model.stop=3", "--model.final_file=%s" % os.path.join(str(tmp_path), "r2.nsdg")], cwd=str(tmp_path))
