@@ -35,6 +35,32 @@ def test_host_cpu_cases(host_build):
     assert re.search(r"host CPU tests: \d+ checks, 0 failures", out), out
 
 
+def test_written_restart_file_is_read_by_the_hdf5_library(host_build, tmp_path):
+    """the HDF5 file written by RectGrid::dump is handed to the HDF5 library's own `h5dump` (present in this
+    image under /opt/conda/bin; skipped where it is not): structure, dimensions, datatype and values must
+    come back as written (6 x 9 grid, 2 ice layers, index pattern of core/test/DevGrid_test.cpp:36-96)"""
+    import shutil
+
+    h5dump = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    if not os.path.exists(h5dump):
+        pytest.skip("no h5dump in this image")
+    path = os.path.join(str(tmp_path), "kept.nc")
+    env = dict(os.environ, NSDG_GOLDEN_DIR=GOLDEN, NSDG_KEEP_RESTART=path)
+    p = subprocess.run([os.path.join(host_build, "host_tests")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=300)
+    assert p.returncode == 0 and os.path.exists(path), p.stdout.decode()
+    rc, head = run([h5dump, "-H", path])
+    assert rc == 0, head
+    for needle in ('GROUP "structure"', 'ATTRIBUTE "type"', 'GROUP "data"', 'DATASET "hice"', 'DATASET "tice"', "H5T_IEEE_F64LE",
+                   "( 6, 9 ) / ( 6, 9 )", "( 6, 9, 2 ) / ( 6, 9, 2 )"):
+        assert needle in head, (needle, head)
+    rc, attr = run([h5dump, "-a", "/structure/type", path])
+    assert rc == 0 and '"rectgrid"' in attr, attr
+    rc, data = run([h5dump, "-d", "/data/hice", "-w", "400", path])
+    assert rc == 0, data
+    row4 = [ln for ln in data.splitlines() if ln.strip().startswith("(4,0):")]
+    assert row4 and "1.0403" in row4[0], data  # element (4, 3) of the pattern 1 + 0.01 i + 0.0001 j
+
+
 def test_help_lists_the_reference_options(host_build):
     rc, out = run([os.path.join(host_build, "nextsim_amd"), "--help"])
     assert rc == 0
