@@ -288,7 +288,7 @@ def main():
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
     # ghost element rows below / above: (2k, 2k-1) for k two-iteration passes between two exchanges
     kpass = max(1, min(args.passes_per_exchange, (ny // world) // 16)) if world > 1 else 1
-    depth = (2 * kpass, 2 * kpass - 1) if ctx.mevp_variant == 2 else (1, 1)
+    depth = (2 * kpass, 2 * kpass - 1) if ctx.mevp_variant >= 2 else (1, 1)
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
     coupled = args.workload == "coupled"
     core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device)
@@ -333,6 +333,9 @@ def main():
     if not finite or umax == 0.0:
         raise SystemExit("bench produced non-finite or trivial fields: invalid run")
 
+    # sub-iterations per launch of the dominant kernel
+    per_launch = 3 if getattr(core, "three_per_pass", False) and nsub >= 3 else (2 if core.two_per_pass else 1)
+    fused_kernel = {3: "mevp_fused3_kernel", 2: "mevp_fused2_kernel", 1: "mevp_fused_kernel"}[per_launch]
     if rank == 0:
         n_elem = nx * ny
         value = n_elem * args.steps / elapsed
@@ -346,16 +349,17 @@ def main():
                                    "512 km box test, dt=120 s, alpha=beta=%.0f (stability bound of the mesh)" % (nx, ny, nsub, alpha),
                        "decomposition": "%d row block(s), ghost-row send/recv" % world + (
                            ", ghost depth %d/%d rows, one exchange per %d mEVP passes" % (depth[0], depth[1], core.group_passes) if world > 1 else ""),
-                       "mevp_passes": "two sub-iterations per kernel pass" if core.two_per_pass else "one sub-iteration per kernel pass",
+                       "mevp_passes": "%s sub-iteration%s per kernel pass" % ({3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
                        "mevp_variant": args.variant if args.variant is not None else "default"},
             "roofline": {"bound": "hbm", "kernel": "mEVP sub-iteration", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(nx, ny, "mevp_fused2_kernel" if core.two_per_pass else "mevp_fused_kernel") if world == 1 else None,
-                         "algorithmic_bytes_per_launch": own_elems * BYTES_PER_ELEM_SUBITER * (2 if core.two_per_pass else 1),
-                         "avg_launch_ms": sub_ms * (2 if core.two_per_pass else 1),
-                         "note": ("achieved = 896 B (SURVEY section 8d, per element-sub-iteration) x elements x 2 sub-iterations / launch time; "
-                                  "the kernel fuses two sub-iterations per pass and keeps the intermediate stress/velocity in registers, "
-                                  "so it moves about half of that figure through HBM (see traffic) -- frac > 1 is possible by design")
-                         if core.two_per_pass else None},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(nx, ny, fused_kernel) if world == 1 else None,
+                         "algorithmic_bytes_per_launch": own_elems * BYTES_PER_ELEM_SUBITER * per_launch,
+                         "avg_launch_ms": sub_ms * per_launch,
+                         "note": ("achieved = 896 B (SURVEY section 8d, per element-sub-iteration) x elements x %d sub-iterations / launch time; "
+                                  "the kernel fuses %d sub-iterations per pass and keeps the intermediate stress/velocity on chip, "
+                                  "so it moves 1/%d of that figure through HBM (see traffic) -- frac > 1 is possible by design"
+                                  % (per_launch, per_launch, per_launch))
+                         if per_launch > 1 else None},
             "mevp_element_subiters_per_s": own_elems / (sub_ms * 1e-3),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -134,8 +134,9 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
 /* kernel variant of the mEVP sub-cycle: 0 = two kernels per sub-iteration (element-wise stress,
  * node-gather velocity), 1 = fused marching kernel (one launch per sub-iteration), 2 = fused marching
  * kernel that performs two sub-iterations per pass (nsdg_mevp_iterate2 / nsdg_mevp_subcycle on a whole
- * local array; single sub-iterations and row-range calls use the variant-1 kernel).  Variants 1 and 2
- * agree bit for bit, variant 0 to fp64 round-off. */
+ * local array; single sub-iterations and row-range calls use the variant-1 kernel), 3 = three
+ * sub-iterations per pass (nsdg_mevp_iterate3 / nsdg_mevp_subcycle; remainders of 2 or 1 sub-iterations use
+ * the kernels of variants 2 and 1).  Variants 1, 2 and 3 agree bit for bit, variant 0 to fp64 round-off. */
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
 
 /* CG2 velocity -> DG(order) velocity and edge-normal velocities used by the transport */
@@ -213,6 +214,13 @@ int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const d
  * boundary) or j0 >= 2 (two ghost rows below); above, one ghost row or the physical boundary (j1 == ny).
  * A multi-rank driver refreshes the ghost rows of S_out and u_new after every pass.  Requires variant 2. */
 int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
+    const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
+    double* u_new, double* v_new, const double* packed, const double* pg);
+
+/* THREE complete sub-iterations in one pass on the owned element rows [j0, j1): reads S_in, u_old on rows
+ * j0-3 .. j1+1 and writes S_out = S^{p+3} on rows [j0, j1) and u_new = u^{p+3} on the nodes they own.  j0 == 0
+ * or j0 >= 3 (three ghost rows below); j1 == ny or j1 + 2 <= ny (two ghost rows above).  Requires variant 3. */
+int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
     const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
     double* u_new, double* v_new, const double* packed, const double* pg);
 

@@ -40,6 +40,8 @@ class NsdgError(RuntimeError):
 # name -> (restype, argtypes); kept in one table so tests can check every declared symbol exists
 VP = C.c_void_p
 I32, I64, D = C.c_int32, C.c_int64, C.c_double
+DEFAULT_MEVP_VARIANT = 3  # nsdg_ctx_create's default: three sub-iterations per kernel pass (csrc/mevp_fused3.hip)
+
 SYMBOLS = {
     "nsdg_abi_version": (C.c_int, []),
     "nsdg_last_error": (C.c_char_p, []),
@@ -68,6 +70,7 @@ SYMBOLS = {
     "nsdg_mevp_velocity": (C.c_int, [VP, I32, I32] + [VP] * 8),
     "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate2": (C.c_int, [VP, I32, I32] + [VP] * 12),
+    "nsdg_mevp_iterate3": (C.c_int, [VP, I32, I32] + [VP] * 12),
     "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_occupancy_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
@@ -158,7 +161,7 @@ class Context:
         self._call(self.lib.nsdg_ctx_create(self.device.index or 0, VP(self.stream.cuda_stream), C.byref(h)))
         self.h = h
         self.nx = self.ny = 0
-        self.mevp_variant = 2  # the library default (two sub-iterations per pass)
+        self.mevp_variant = DEFAULT_MEVP_VARIANT  # the library default (three sub-iterations per pass)
 
     def _call(self, rc):
         if rc != 0:
@@ -310,10 +313,17 @@ class Context:
         """two sub-iterations in one pass on the owned rows [j0, j1) (variant 2)"""
         self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg)()
 
-    def bind_mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+    def mevp_iterate3(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        """three sub-iterations in one pass on the owned rows [j0, j1) (variant 3)"""
+        self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=3)()
+
+    def bind_mevp_iterate3(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        return self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=3)
+
+    def bind_mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=2):
         ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
         _check_f64(*ts)
-        fn = self.lib.nsdg_mevp_iterate2
+        fn = self.lib.nsdg_mevp_iterate3 if passes == 3 else self.lib.nsdg_mevp_iterate2
         args = (self.h, I32(j0), I32(j1)) + tuple(_ptr(t) for t in ts)
         keep = ts
 

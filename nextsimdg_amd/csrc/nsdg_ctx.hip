@@ -76,7 +76,7 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     nsdg_mevp_default_params(&c->mevp);
     c->nx = c->ny = 0;
     c->hx = c->hy = 0.;
-    c->mevp_variant = 2;
+    c->mevp_variant = 3;
     c->strip_rows = 0;
     {
         hipDeviceProp_t prop;
@@ -155,7 +155,7 @@ int nsdg_mevp_occupancy_set(nsdg_ctx* ctx, int32_t waves_per_simd)
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
-    NSDG_CHECK_ARG(variant >= 0 && variant <= 2, "variant must be 0, 1 or 2");
+    NSDG_CHECK_ARG(variant >= 0 && variant <= 3, "variant must be 0, 1, 2 or 3");
     ctx->mevp_variant = variant;
     return NSDG_OK;
 }

@@ -203,7 +203,11 @@ class DynamicsCore:
         self._calls = {}
         # two sub-iterations per pass need a (2k, 2k-1) ghost depth; a single domain has no ghosts at all
         deep = blk.depth_below >= 2 and blk.depth_below % 2 == 0 and blk.depth_above == blk.depth_below - 1
-        self.two_per_pass = getattr(ops, "mevp_variant", None) == 2 and (blk.world == 1 or deep)
+        variant = getattr(ops, "mevp_variant", None)
+        self.two_per_pass = variant in (2, 3) and (blk.world == 1 or deep)
+        # three sub-iterations per pass: single domain only (row blocks use the two-iteration kernel, whose
+        # results are bit-identical)
+        self.three_per_pass = variant == 3 and blk.world == 1
         self.group_passes = blk.depth_below // 2 if (self.two_per_pass and blk.world > 1) else 1  # passes between two exchanges
         self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
         nx, ny = blk.nx, blk.ny
@@ -246,6 +250,18 @@ class DynamicsCore:
         # the start of the step is read from the current iterate (it is only needed inside the packing)
         ops.mevp_prepare(self.dt, self.H, self.A, (self.ua, self.va), (self.uo, self.vo), (self.u, self.v), self.packed)
         it = 0
+        if self.three_per_pass:
+            while self.nsub - it >= 3:
+                key = (self.u.data_ptr(), self.s[0].data_ptr(), 3)
+                call = self._calls.get(key)
+                if call is None:
+                    call = self._calls[key] = ops.bind_mevp_iterate3(0, b.ny, self.s, self.sb, (self.u, self.v), (self.ub, self.vb),
+                                                                      self.packed, self.pg)
+                call()
+                self.u, self.ub = self.ub, self.u
+                self.v, self.vb = self.vb, self.v
+                self.s, self.sb = self.sb, self.s
+                it += 3
         if self.two_per_pass:
             # two sub-iterations per pass (intermediate stress / velocity stay in registers).  With several ranks
             # the passes run in groups of k = group_passes: pass i of a group of m covers the owned rows plus

@@ -33,7 +33,7 @@ def test_bad_grid_and_params(ctx):
     with pytest.raises(abi.NsdgError, match="alpha and beta"):
         ctx.set_mevp_params(ctx.mevp_default_params(alpha=0.0))
     with pytest.raises(abi.NsdgError):
-        ctx.set_mevp_variant(3)
+        ctx.set_mevp_variant(4)
     with pytest.raises(abi.NsdgError):
         ctx.set_mevp_occupancy(4)
 
@@ -67,7 +67,14 @@ def test_row_ranges_aliasing_and_sequence(ctx):
     ctx.set_mevp_variant(1)
     with pytest.raises(abi.NsdgError, match="variant 2"):
         ctx.mevp_iterate2(0, ny, s, so, (u, v), (un, vn), packed, pg)
-    ctx.set_mevp_variant(2)
+    with pytest.raises(abi.NsdgError, match="variant 3"):
+        ctx.mevp_iterate3(0, ny, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_mevp_variant(3)
+    with pytest.raises(abi.NsdgError, match="three ghost rows"):
+        ctx.mevp_iterate3(2, ny, s, so, (u, v), (un, vn), packed, pg)
+    with pytest.raises(abi.NsdgError, match="two ghost rows above"):
+        ctx.mevp_iterate3(0, ny - 1, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     with pytest.raises(abi.NsdgError, match="order must be"):
         ctx.prepare_advection(3, u, v, z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
     with pytest.raises(abi.NsdgError, match="ncoef"):

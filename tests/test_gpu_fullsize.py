@@ -89,7 +89,7 @@ def test_config4_2048_dynamics_step_properties(ctx):
     box, finite fields, agreement of the fused and the two-kernel mEVP variants at full size"""
     n = 2048
     results = {}
-    for variant in (2, 1, 0):
+    for variant in (3, 2, 1, 0):
         ctx.set_mevp_variant(variant)
         core = box_core(ctx, n, nsub=12)
         mH, mA = float(core.H[0].sum()), float(core.A[0].sum())
@@ -103,13 +103,14 @@ def test_config4_2048_dynamics_step_properties(ctx):
         assert abs(float(core.A[0].sum()) - mA) <= 1e-12 * abs(mA)
         results[variant] = (core.u.clone(), core.v.clone(), core.s[0].clone(), core.H.clone())
         del core
-    ctx.set_mevp_variant(2)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     ctx.set_mevp_params(ctx.mevp_default_params())
     for a, b in zip(results[0], results[1]):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 1e-10 * scale
-    for a, b in zip(results[1][:2] + results[1][3:], results[2][:2] + results[2][3:]):
-        assert torch.equal(a, b)  # one and two sub-iterations per pass: bit-identical velocities and thickness
+    for other in (2, 3):  # one, two and three sub-iterations per pass: bit-identical velocities and thickness
+        for a, b in zip(results[1][:2] + results[1][3:], results[other][:2] + results[other][3:]):
+            assert torch.equal(a, b), other
 
 
 def test_config3_1024_point_symmetry(ctx):

@@ -271,7 +271,7 @@ def test_mevp_single_iteration_matches_oracle(ctx, variant):
         assert_close(thost(d, nx), o, 1e-12, 1e-12 * np.max(np.abs(o)), name)
     assert_close(host(dun), un, 1e-11, 1e-13 * np.max(np.abs(un)), "u_new")
     assert_close(host(dvn), vn, 1e-11, 1e-13 * np.max(np.abs(vn)), "v_new")
-    ctx.set_mevp_variant(2)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -300,7 +300,7 @@ def test_mevp_subcycle_matches_oracle(ctx, variant):
     # Dirichlet rows/columns are exactly zero
     g = host(du)
     assert np.all(g[0] == 0) and np.all(g[-1] == 0) and np.all(g[:, 0] == 0) and np.all(g[:, -1] == 0)
-    ctx.set_mevp_variant(2)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
 
 
 def test_mevp_row_block_equals_full_domain_bitwise(ctx):
@@ -334,7 +334,7 @@ def test_mevp_row_block_equals_full_domain_bitwise(ctx):
             assert torch.equal(f[lo:], p)  # tiled arrays: element rows are the leading dimension
         assert torch.equal(un[2 * r0:], pun[2:])
         assert torch.equal(vn[2 * r0:], pvn[2:])
-    ctx.set_mevp_variant(2)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
 
 
 def test_mevp_fused_strip_size_does_not_change_results(ctx):
@@ -361,7 +361,7 @@ def test_mevp_fused_strip_size_does_not_change_results(ctx):
             assert torch.equal(a, c)
     for a, c in zip(results[0], results[1]):
         assert_close(host(c), host(a), 1e-12, 1e-13 * float(a.abs().max()), "fused vs two-kernel")
-    ctx.set_mevp_variant(2)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     ctx.set_mevp_strip_rows(0)
 
 
@@ -456,8 +456,75 @@ def test_mevp_two_iterations_per_pass_equals_two_single_passes_bitwise(ctx):
         O.mevp_subcycle(nx, ny, b.bt.hx, b.bt.hy, 120.0, 2, b.po, so, uo_, vo_, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga, pg_o)
         assert_close(host(ref[3]), uo_, 1e-10, 1e-12 * np.max(np.abs(uo_)), "u after two sub-iterations")
         assert_close(thost(ref[0], nx), so[0], 1e-10, 1e-12 * np.max(np.abs(so[0])), "s11 after two sub-iterations")
-    ctx.set_mevp_variant(2)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     ctx.set_mevp_strip_rows(0)
+
+
+def test_mevp_three_iterations_per_pass_equals_three_single_passes_bitwise(ctx):
+    """variant 3 pipelines three sub-iterations per pass (A -> B in registers, B -> C through LDS); it must
+    reproduce three launches of the single-iteration fused kernel bit for bit, for any strip height, for
+    widths around the 59 owned columns of a wave, for sub-ranges of rows, and inside nsdg_mevp_subcycle
+    (remainders of 2 and 1 sub-iterations through the kernels of variants 2 and 1)"""
+    for (nx, ny) in ((130, 45), (59, 9), (60, 11), (200, 3), (58, 1), (7, 5)):
+        b = Box(ctx, nx, ny)
+        rng = np.random.default_rng(53)
+        u, v, s = mevp_state(b, rng)
+        pg_o = O.ice_strength(nx, ny, b.po, b.H, b.A)
+        cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+        tax, tay = O.wind_stress(b.po, b.ua, b.va)
+        packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
+        pg = tdev(pg_o)
+        s_in = [tdev(x) for x in s]
+        ctx.set_mevp_variant(1)
+        ctx.set_mevp_strip_rows(0)
+        cur = s_in + [dev(u), dev(v)]
+        for _ in range(3):
+            nxt = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+            ctx.mevp_iterate(0, 0, ny, cur[:3], nxt[:3], (cur[3], cur[4]), (nxt[3], nxt[4]), packed, pg)
+            cur = nxt
+        ref = cur
+        ctx.set_mevp_variant(3)
+        for rows in (1, 2, 5, 16, 64, 0):
+            ctx.set_mevp_strip_rows(rows)
+            out = [torch.zeros_like(x) for x in s_in] + [torch.full_like(dev(u), 7.0), torch.full_like(dev(v), 7.0)]
+            ctx.mevp_iterate3(0, ny, s_in, out[:3], (dev(u), dev(v)), (out[3], out[4]), packed, pg)
+            for k, (a, c) in enumerate(zip(ref, out)):
+                assert torch.equal(a, c), (nx, ny, rows, k, float((a - c).abs().max()))
+        if ny >= 11:  # a sub-range with ghost rows on both sides: rows [3, ny - 2)
+            ctx.set_mevp_strip_rows(0)
+            out = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+            ctx.mevp_iterate3(3, ny - 2, s_in, out[:3], (dev(u), dev(v)), (out[3], out[4]), packed, pg)
+            assert torch.equal(abi.untile(out[0], nx)[:, 3:ny - 2], abi.untile(ref[0], nx)[:, 3:ny - 2])
+            assert torch.equal(out[3][6:2 * (ny - 2)], ref[3][6:2 * (ny - 2)])
+        # against the oracle
+        so = [x.copy() for x in s]
+        uo_, vo_ = u.copy(), v.copy()
+        O.mevp_subcycle(nx, ny, b.bt.hx, b.bt.hy, 120.0, 3, b.po, so, uo_, vo_, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga, pg_o)
+        assert_close(host(ref[3]), uo_, 1e-10, 1e-12 * np.max(np.abs(uo_)), "u after three sub-iterations")
+        assert_close(thost(ref[0], nx), so[0], 1e-10, 1e-12 * np.max(np.abs(so[0])), "s11 after three sub-iterations")
+    # whole sub-cycle: 3-passes + remainder 2 (nsub = 8) and remainder 1 (nsub = 7) against variant 1
+    b = Box(ctx, 70, 33, alpha=300.0, beta=300.0)
+    nx, ny = b.nx, b.ny
+    pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
+    cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+    tax, tay = O.wind_stress(b.po, b.ua, b.va)
+    shape = (2 * ny + 1, 2 * nx + 1)
+    for nsub in (8, 7, 9):
+        res = {}
+        for variant in (1, 3):
+            ctx.set_mevp_variant(variant)
+            du, dv = dev(np.zeros(shape)), dev(np.zeros(shape))
+            ds = [tdev(np.zeros((8, ny, nx))) for _ in range(3)]
+            scratch = torch.zeros(10 * du.numel() + 3 * ds[0].numel(), dtype=torch.float64, device="cuda")
+            ctx.mevp_subcycle(120.0, nsub, ds, du, dv, du.clone(), dv.clone(), dev(tax), dev(tay), dev(b.uo), dev(b.vo), dev(cgh), dev(cga),
+                              tdev(pg), scratch)
+            res[variant] = (du, dv, ds)
+        assert torch.equal(res[1][0], res[3][0]) and torch.equal(res[1][1], res[3][1]), nsub
+        assert all(torch.equal(a, c) for a, c in zip(res[1][2], res[3][2])), nsub
+        assert float(res[3][0].abs().max()) > 0
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
+    ctx.set_mevp_strip_rows(0)
+    ctx.set_mevp_params(ctx.mevp_default_params())
 
 
 def test_mevp_subcycle_variant2_matches_oracle(ctx):
@@ -478,7 +545,7 @@ def test_mevp_subcycle_variant2_matches_oracle(ctx):
     O.mevp_subcycle(nx, ny, b.bt.hx, b.bt.hy, 120.0, nsub, b.po, s, u, v, u.copy(), v.copy(), tax, tay, b.uo, b.vo, cgh, cga, pg)
     assert_close(host(du), u, 1e-9, 1e-11 * np.max(np.abs(u)), "u after subcycle (variant 2)")
     assert_close(thost(ds[0], nx), s[0], 1e-9, 1e-10 * np.max(np.abs(s[0])), "s11 after subcycle (variant 2)")
-    ctx.set_mevp_variant(2)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
 
 
 def test_mevp_two_per_pass_row_block_equals_full_domain_bitwise(ctx):
