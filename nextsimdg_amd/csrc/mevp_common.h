@@ -5,6 +5,25 @@
 #include "dg_tables.h"
 #include "nsdg_internal.h"
 
+#ifdef NSDG_STAMPS
+// Diagnostic build only (tools/ab_build.sh stamps -DNSDG_STAMPS): per-phase shader-cycle totals of one march,
+// s_memtime stamps fenced by scheduling barriers.  Never defined in the product build.
+#define NSDG_STAMP(k)                                            \
+    do {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+        stamp_acc[k] += now_ - stamp_last;                       \
+        stamp_last = now_;                                       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    } while (0)
+#define NSDG_STAMP_ARGS , unsigned (&stamp_acc)[12], unsigned& stamp_last
+#define NSDG_STAMP_PASS , stamp_acc, stamp_last
+#else
+#define NSDG_STAMP(k)
+#define NSDG_STAMP_ARGS
+#define NSDG_STAMP_PASS
+#endif
+
 namespace nsdg_mevp_detail {
 
 using namespace nsdg_tab;

@@ -27,23 +27,7 @@
 #include "mevp_common.h"
 
 #ifdef NSDG_STAMPS
-// Diagnostic build only (tools/ab_build.sh stamps -DNSDG_STAMPS): per-phase shader-cycle totals of one march,
-// s_memtime stamps fenced by scheduling barriers.  Never defined in the product build.
 __device__ unsigned nsdg_stamp_acc[64 * 16];
-#define NSDG_STAMP(k)                                            \
-    do {                                                         \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
-        stamp_acc[k] += now_ - stamp_last;                       \
-        stamp_last = now_;                                       \
-        __builtin_amdgcn_sched_barrier(0);                       \
-    } while (0)
-#define NSDG_STAMP_ARGS , unsigned (&stamp_acc)[10], unsigned& stamp_last
-#define NSDG_STAMP_PASS , stamp_acc, stamp_last
-#else
-#define NSDG_STAMP(k)
-#define NSDG_STAMP_ARGS
-#define NSDG_STAMP_PASS
 #endif
 
 namespace nsdg_mevp_detail {
@@ -252,7 +236,7 @@ __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx,
         Y.u[k] = Y.v[k] = 0.;
     TopCarry ca, cb; // sub-iteration p (row t-1) and p+1 (row t-2)
 #ifdef NSDG_STAMPS
-    unsigned stamp_acc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned stamp_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned stamp_last = (unsigned)__builtin_amdgcn_s_memtime();
     const unsigned stamp_t0 = stamp_last, stamp_rt0 = (unsigned)__builtin_amdgcn_s_memrealtime(); // 100 MHz reference
 #endif

@@ -23,6 +23,10 @@
 // them.  Where those rows do not exist the edge of the local array is the physical boundary.
 #include "mevp_common.h"
 
+#ifdef NSDG_STAMPS
+__device__ unsigned nsdg_stamp_acc3[64 * 16];
+#endif
+
 namespace nsdg_mevp_detail {
 
 struct StressPtrs3 {
@@ -33,7 +37,6 @@ struct StressPtrs3 {
 // everything of one element row that sub-iteration p+1 needs from sub-iteration p (registers)
 struct RowCarry3 {
     double s11[8], s12[8], s22[8]; // S^p of the row (relaxed in place to S^{p+1} by B)
-    double P[9]; // ice strength at the Gauss points
     double c[4][6]; // packed momentum coefficients of the 4 owned nodes (V, EX, EY, C)
     double u[4], v[4]; // u^p, v^p at those nodes
 };
@@ -96,9 +99,10 @@ __device__ __forceinline__ void gather_nodes(const MarchConst3& M, const double 
 // One march step: A(t) into `cur`; B(t) on row t-1 from `prev` (parked in LDS afterwards); C(t) on row t-2 from LDS.
 __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarry3& cur, RowCarry3& prev, TopCarry3& ca, TopCarry3& cb,
     TopCarry3& cc, double* __restrict__ park, const StressPtrs3& S, const double* __restrict__ u_old, const double* __restrict__ v_old,
-    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new NSDG_STAMP_ARGS)
 {
     const int nn = M.nn, ix = M.ix;
+    NSDG_STAMP(0);
     // ---------------------------------------------------------------------- A(t): sub-iteration p on row t
     if (t <= M.tendA) {
         const long ts = tile_off(ix, t, M.ntx, 8), tp = tile_off(ix, t, M.ntx, 9);
@@ -110,9 +114,10 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
             ul[a] = u_old[n];
             vl[a] = v_old[n];
         }
+        double PA[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q)
-            cur.P[q] = pg[tp + q * 64];
+            PA[q] = pg[tp + q * 64];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             cur.s11[i] = S.i11[ts + i * 64];
@@ -123,7 +128,9 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         load_nodal(packed, nV + 1, cur.c[1]);
         load_nodal(packed, nV + nn, cur.c[2]);
         load_nodal(packed, nV + nn + 1, cur.c[3]);
-        stress_update(ul, vl, cur.P, M.ihx, M.ihy, M.ialpha, M.dmin2, cur.s11, cur.s12, cur.s22);
+        NSDG_STAMP(1);
+        stress_update(ul, vl, PA, M.ihx, M.ihy, M.ialpha, M.dmin2, cur.s11, cur.s12, cur.s22);
+        NSDG_STAMP(2);
         double cx[9], cy[9];
         node_contrib_all(cur.s11, cur.s12, cur.s22, M.hx, M.hy, cx, cy);
         const double uu[4] = { ul[0], ul[1], ul[3], ul[4] }, vv[4] = { vl[0], vl[1], vl[3], vl[4] };
@@ -135,14 +142,26 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
             cur.u[k] = cur.v[k] = 0.; // node row 2*ny is the top boundary
     }
 
+    NSDG_STAMP(3);
     // ---------------------------------------------------------------------- B(t): sub-iteration p+1 on row r = t-1
     const int r = t - 1;
     double bu[4] = { 0., 0., 0., 0. }, bv[4] = { 0., 0., 0., 0. }; // u^{p+1} at the owned nodes of row r (zero above the top boundary)
     if (r >= M.tbeg && r >= M.y0 - 2 && r <= M.tendB) { // wave-uniform
+        // the ice strength of the row is read again (an L2 hit: A streamed it in one step ago) rather than
+        // carried: 18 registers per set that would push the kernel over the 512-register file
+        double PB[9];
+        {
+            const long tpb = tile_off(ix, r, M.ntx, 9);
+#pragma unroll
+            for (int g = 0; g < 9; ++g)
+                PB[g] = pg[tpb + g * 64];
+        }
         double ul[9], vl[9];
         gather_nodes(M, prev.u, cur.u[0], cur.u[1], ul);
         gather_nodes(M, prev.v, cur.v[0], cur.v[1], vl);
-        stress_update(ul, vl, prev.P, M.ihx, M.ihy, M.ialpha, M.dmin2, prev.s11, prev.s12, prev.s22);
+        NSDG_STAMP(4);
+        stress_update(ul, vl, PB, M.ihx, M.ihy, M.ialpha, M.dmin2, prev.s11, prev.s12, prev.s22);
+        NSDG_STAMP(5);
         double cx[9], cy[9];
         node_contrib_all(prev.s11, prev.s12, prev.s22, M.hx, M.hy, cx, cy);
         if (r >= M.y0 - 1) // wave-uniform: the row below only feeds the carried contributions
@@ -163,6 +182,7 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         }
     }
 
+    NSDG_STAMP(6);
     // ---------------------------------------------------------------------- C(t): sub-iteration p+2 on row q = t-2
     const int q = t - 2;
     if (q >= M.tbeg && q >= M.y0 - 1 && q < M.y1) { // wave-uniform
@@ -192,7 +212,9 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         double ul[9], vl[9];
         gather_nodes(M, qu, bu[0], bu[1], ul);
         gather_nodes(M, qv, bv[0], bv[1], vl);
+        NSDG_STAMP(7);
         stress_update(ul, vl, P, M.ihx, M.ihy, M.ialpha, M.dmin2, s11, s12, s22);
+        NSDG_STAMP(8);
         const bool store = M.own && q >= M.y0;
         if (store) {
             const long ts = tile_off(ix, q, M.ntx, 8);
@@ -204,6 +226,7 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
             }
         }
         double cx[9], cy[9];
+        NSDG_STAMP(9);
         node_contrib_all(s11, s12, s22, M.hx, M.hy, cx, cy);
         if (q >= M.y0) { // wave-uniform
             double un[4], vn[4];
@@ -227,6 +250,7 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         }
         carry_top(cc, cx, cy);
     }
+    NSDG_STAMP(10);
 }
 
 __global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int R, int ncw, double hx, double hy,
@@ -262,16 +286,37 @@ __global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, 
         Y.u[k] = Y.v[k] = 0.;
     TopCarry3 ca, cb, cc; // sub-iterations p (row t-1), p+1 (row t-2), p+2 (row t-3)
     const int tlast = M.y1 + 1; // C(tlast) finishes row y1 - 1
+#ifdef NSDG_STAMPS
+    unsigned stamp_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned stamp_last = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned stamp_t0 = stamp_last, stamp_rt0 = (unsigned)__builtin_amdgcn_s_memrealtime(); // 100 MHz reference
+#endif
     for (int t = M.tbeg; t <= tlast; t += 2) {
-        march_step3(M, t, X, Y, ca, cb, cc, park, S, u_old, v_old, packed, pg, u_new, v_new);
+        march_step3(M, t, X, Y, ca, cb, cc, park, S, u_old, v_old, packed, pg, u_new, v_new NSDG_STAMP_PASS);
         if (t + 1 <= tlast)
-            march_step3(M, t + 1, Y, X, ca, cb, cc, park, S, u_old, v_old, packed, pg, u_new, v_new);
+            march_step3(M, t + 1, Y, X, ca, cb, cc, park, S, u_old, v_old, packed, pg, u_new, v_new NSDG_STAMP_PASS);
     }
+#ifdef NSDG_STAMPS
+    if (lane == 0 && (wave & 63) == 0 && wave / 64 < 64) {
+        for (int k = 0; k < 11; ++k)
+            nsdg_stamp_acc3[(wave / 64) * 16 + k] = stamp_acc[k];
+        nsdg_stamp_acc3[(wave / 64) * 16 + 11] = tlast + 1 - M.tbeg; // march steps
+        nsdg_stamp_acc3[(wave / 64) * 16 + 12] = (unsigned)__builtin_amdgcn_s_memtime() - stamp_t0;
+        nsdg_stamp_acc3[(wave / 64) * 16 + 13] = (unsigned)__builtin_amdgcn_s_memrealtime() - stamp_rt0;
+    }
+#endif
 }
 
 } // namespace nsdg_mevp_detail
 
 using namespace nsdg_mevp_detail;
+
+#ifdef NSDG_STAMPS
+extern "C" int nsdg_debug_read_stamps3(unsigned* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nsdg_stamp_acc3), sizeof(unsigned) * 64 * 16);
+}
+#endif
 
 // three sub-iterations on the owned rows [j0, j1) of the local array
 int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,

@@ -7,19 +7,22 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 os.environ["NSDG_LIB"] = os.path.join(root, "nextsimdg_amd", "lib", "alt", sys.argv[1] if len(sys.argv) > 1 else "stamps", "libnsdg.so")
+VARIANT = int(sys.argv[2]) if len(sys.argv) > 2 else None  # default: the library default
 import numpy as np
 import torch
 
 from nextsimdg_amd import abi, rowblock, synthetic
 
 nx = ny = 2048
-L, dt, nsub = 512e3, 120.0, 8
+L, dt, nsub = 512e3, 120.0, 12
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
+if VARIANT is not None:
+    ctx.set_mevp_variant(VARIANT)
 bt = synthetic.BoxTest(nx, ny, L)
 alpha = bt.stable_alpha(dt)
 ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
-blk = rowblock.RowBlock(nx, ny, 0, 1, 2, 1)
+blk = rowblock.RowBlock(nx, ny, 0, 1)
 core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev)
 H, A = bt.dg_fields()
 uo, vo = bt.ocean()
@@ -30,18 +33,26 @@ for _ in range(2):
 torch.cuda.synchronize()
 lib = abi.load_library()
 out = (ctypes.c_uint * (64 * 16))()
-rc = lib.nsdg_debug_read_stamps(out)
+if ctx.mevp_variant == 3:
+    rc = lib.nsdg_debug_read_stamps3(out)
+    nph, isteps, icyc, irt = 11, 11, 12, 13
+    names = ["loop overhead", "A: loads issued (addressing)", "A: stress update", "A: nodal contributions + node updates + carries",
+             "B: P loads issued, node gather", "B: stress update", "B: contributions, node updates, parking in LDS",
+             "C: LDS reads, P/coefficient loads issued, node gather", "C: stress update", "C: stress stores", "C: contributions, node updates, stores"]
+else:
+    rc = lib.nsdg_debug_read_stamps(out)
+    nph, isteps, icyc, irt = 9, 9, 10, 11
+    names = ["step start -> A loads issued (B tail of previous step included)", "A: loads issued (addressing)", "A: stress update", "A: nodal contributions",
+             "A: node updates + carries", "B: stress update", "B: stress stores", "B: nodal contributions", "B: node updates + stores"]
 a = np.array(out[:], dtype=np.float64).reshape(64, 16)
-a = a[a[:, 9] > 0]
-steps = a[:, 9:10]
-per = a[:, :9] / steps
-names = ["step start -> A loads issued (B tail of previous step included)", "A: loads issued (addressing)", "A: stress update", "A: nodal contributions",
-         "A: node updates + carries", "B: stress update", "B: stress stores", "B: nodal contributions", "B: node updates + stores"]
-print("waves sampled %d, march steps per wave %s" % (len(a), sorted(set(a[:, 9].astype(int)))))
+a = a[a[:, isteps] > 0]
+steps = a[:, isteps:isteps + 1]
+per = a[:, :nph] / steps
+print("variant %d: waves sampled %d, march steps per wave %s" % (ctx.mevp_variant, len(a), sorted(set(a[:, isteps].astype(int)))))
 med = np.median(per, axis=0)
-for k in range(9):
+for k in range(nph):
     print("%-70s %8.0f cycles/step  (min %6.0f max %6.0f)" % (names[k], med[k], per[:, k].min(), per[:, k].max()))
 print("%-70s %8.0f" % ("sum", med.sum()))
-clk = a[:, 10] / (a[:, 11] * 10e-9) / 1e9
+clk = a[:, icyc] / (a[:, irt] * 10e-9) / 1e9
 print("in-kernel shader clock (s_memtime / s_memrealtime): median %.2f GHz (min %.2f, max %.2f); march of one wave %.3f ms"
-      % (np.median(clk), clk.min(), clk.max(), np.median(a[:, 11]) * 10e-6))
+      % (np.median(clk), clk.min(), clk.max(), np.median(a[:, irt]) * 10e-6))
