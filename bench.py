@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
     ap.add_argument("--passes-per-exchange", type=int, default=4,
-                    help="N > 1: two-iteration mEVP passes between two ghost-row exchanges (ghost depth 2k / 2k-1 rows)")
+                    help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -286,9 +286,10 @@ def main():
     bt = synthetic.BoxTest(nx, ny, L)
     alpha = bt.stable_alpha(dt)  # alpha = beta from the linear-stability bound of the sub-cycle on this mesh
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
-    # ghost element rows below / above: (2k, 2k-1) for k two-iteration passes between two exchanges
+    # ghost element rows below / above: (v k, v k - 1) for k passes of v sub-iterations between two exchanges
     kpass = max(1, min(args.passes_per_exchange, (ny // world) // 16)) if world > 1 else 1
-    depth = (2 * kpass, 2 * kpass - 1) if ctx.mevp_variant >= 2 else (1, 1)
+    vpass = min(ctx.mevp_variant, 3)
+    depth = (vpass * kpass, vpass * kpass - 1) if vpass >= 2 else (1, 1)
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
     coupled = args.workload == "coupled"
     core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device)

@@ -10,11 +10,12 @@ send/recv of ghost rows through torch.distributed (backend "nccl" = RCCL over xG
   per mEVP sub-iteration : velocity node rows   up: 2 rows x (u,v) x (2nx+1)     down: 1 row x (u,v)
    (single-iteration       (the stress of the ghost row below is NOT exchanged: it is updated
     kernel)                 redundantly by the rank itself, bit-identically to its owner)
-  per GROUP of k passes  : two-iterations-per-pass kernel with ghost depth (2k, 2k-1): 2k stress rows + 4k node
-   (2k sub-iterations)     rows travel up, 2k-1 stress rows + 4k-1 node rows down.  Between two exchanges a
-                           rank runs k passes on a row range that shrinks by 2 rows on each side per pass --
-                           the ghost rows are advanced redundantly, bit-identically to their owners -- so the
-                           number of messages per step drops by k (latency-avoiding halo)
+  per GROUP of k passes  : kernels with v = 2 or 3 sub-iterations per pass and ghost depth (d, d-1), d = v k:
+   (v k sub-iterations)    d stress rows + 2d node rows travel up, d-1 stress rows + 2d-1 node rows down.
+                           Between two exchanges a rank runs k passes on a row range that shrinks by v rows
+                           on each side per pass -- the ghost rows are advanced redundantly, bit-identically
+                           to their owners -- so the number of messages per step drops by v k
+                           (latency-avoiding halo)
   per RK stage           : the ghost element rows of each advected field in both directions (ghost depth
                            >= 3: once per step, the first two stages advance ghost rows redundantly)
 
@@ -35,11 +36,11 @@ def split_rows(ny, world, rank):
 
 class RowBlock:
     """index bookkeeping of one rank's local array.  `depth_below` / `depth_above` are the numbers of ghost
-    element rows kept on the interior sides: (1, 1) for one mEVP sub-iteration per pass, (2k, 2k-1) for the
-    two-sub-iterations-per-pass kernel with k passes between two ghost-row exchanges.  That kernel reads the
-    stress of two element rows below and one above the rows it updates and the velocity up to the bottom node
-    row of the second element row above (owned by that row), so complete rows shrink by 2 per pass on both
-    sides; k = 1 gives the (2, 1) of an exchange after every pass."""
+    element rows kept on the interior sides: (1, 1) for one mEVP sub-iteration per pass, (v k, v k - 1) for the
+    kernels with v = 2 or 3 sub-iterations per pass and k passes between two ghost-row exchanges.  Such a
+    kernel reads the stress of v element rows below and v - 1 above the rows it updates and the velocity up to
+    the bottom node row of the v-th element row above (owned by that row), so complete rows shrink by v per
+    pass on both sides; k = 1 gives the (2, 1) / (3, 2) of an exchange after every pass."""
 
     def __init__(self, nx, ny, rank=0, world=1, depth_below=1, depth_above=1):
         if ny < world * max(depth_below, depth_above, 1) * 2:
@@ -201,14 +202,19 @@ class DynamicsCore:
         self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
         self.overlap = overlap
         self._calls = {}
-        # two sub-iterations per pass need a (2k, 2k-1) ghost depth; a single domain has no ghosts at all
-        deep = blk.depth_below >= 2 and blk.depth_below % 2 == 0 and blk.depth_above == blk.depth_below - 1
+        # v sub-iterations per kernel pass (v = 3: variant 3, v = 2: variant 2) need a (v k, v k - 1) ghost depth
+        # for k passes between two exchanges; a single domain has no ghosts at all.  All variants produce
+        # bit-identical results, so a variant-3 context on a (2k, 2k-1) block simply uses the two-iteration kernel.
         variant = getattr(ops, "mevp_variant", None)
-        self.two_per_pass = variant in (2, 3) and (blk.world == 1 or deep)
-        # three sub-iterations per pass: single domain only (row blocks use the two-iteration kernel, whose
-        # results are bit-identical)
-        self.three_per_pass = variant == 3 and blk.world == 1
-        self.group_passes = blk.depth_below // 2 if (self.two_per_pass and blk.world > 1) else 1  # passes between two exchanges
+        self.per_pass = 1
+        for v in (3, 2):
+            deep = blk.depth_below >= v and blk.depth_below % v == 0 and blk.depth_above == blk.depth_below - 1
+            if variant is not None and variant >= v and (blk.world == 1 or deep):
+                self.per_pass = v
+                break
+        self.two_per_pass = self.per_pass >= 2  # the ghost zones hold stress rows as well as velocity rows
+        self.three_per_pass = self.per_pass == 3
+        self.group_passes = blk.depth_below // self.per_pass if (self.per_pass >= 2 and blk.world > 1) else 1  # passes between two exchanges
         self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
         nx, ny = blk.nx, blk.ny
         z = lambda *s: torch.zeros(*s, dtype=torch.float64, device=device)
@@ -250,42 +256,32 @@ class DynamicsCore:
         # the start of the step is read from the current iterate (it is only needed inside the packing)
         ops.mevp_prepare(self.dt, self.H, self.A, (self.ua, self.va), (self.uo, self.vo), (self.u, self.v), self.packed)
         it = 0
-        if self.three_per_pass:
-            while self.nsub - it >= 3:
-                key = (self.u.data_ptr(), self.s[0].data_ptr(), 3)
-                call = self._calls.get(key)
-                if call is None:
-                    call = self._calls[key] = ops.bind_mevp_iterate3(0, b.ny, self.s, self.sb, (self.u, self.v), (self.ub, self.vb),
-                                                                      self.packed, self.pg)
-                call()
-                self.u, self.ub = self.ub, self.u
-                self.v, self.vb = self.vb, self.v
-                self.s, self.sb = self.sb, self.s
-                it += 3
-        if self.two_per_pass:
-            # two sub-iterations per pass (intermediate stress / velocity stay in registers).  With several ranks
-            # the passes run in groups of k = group_passes: pass i of a group of m covers the owned rows plus
-            # 2(m-i) ghost rows on each side (what the remaining passes of the group will read), and only
-            # after the last pass the ghost rows of the new stress and velocity are exchanged.
+        if self.per_pass >= 2:
+            # v sub-iterations per pass (the intermediate stress / velocity stay on chip).  With several ranks the
+            # passes run in groups of k = group_passes: pass i of a group of m covers the owned rows plus
+            # v(m-i) ghost rows on each side (what the remaining passes of the group will read), and only
+            # after the last pass the ghost rows of the new stress and velocity are exchanged.  What is left
+            # of nsub after the v-passes is done by a two-iteration pass and / or single sub-iterations.
             k = self.group_passes
-            split2 = self.overlap and b.world > 1 and (b.j1 - b.j0) >= b.depth_below + b.depth_above + 5
-            while it + 1 < self.nsub:
-                m = min(k, (self.nsub - it) // 2)
-                for i in range(1, m + 1):
-                    last = i == m
-                    calls = self._iterate2_calls(split2 and last, m - i)
-                    for c in calls[:-1]:
-                        c()
-                    pending = self._ghost_exchange_start() if (split2 and last) else None
-                    calls[-1]()
-                    if last:
-                        if pending is None:
-                            pending = self._ghost_exchange_start()
-                        self._ghost_exchange_finish(pending)
-                    self.u, self.ub = self.ub, self.u
-                    self.v, self.vb = self.vb, self.v
-                    self.s, self.sb = self.sb, self.s
-                    it += 2
+            split_ok = self.overlap and b.world > 1 and (b.j1 - b.j0) >= b.depth_below + b.depth_above + 5
+            for v in ((self.per_pass, 2) if self.per_pass == 3 else (2,)):
+                while self.nsub - it >= v:
+                    m = min(k, (self.nsub - it) // v)
+                    for i in range(1, m + 1):
+                        last = i == m
+                        calls = self._pass_calls(v, split_ok and last, m - i)
+                        for c in calls[:-1]:
+                            c()
+                        pending = self._ghost_exchange_start() if (split_ok and last) else None
+                        calls[-1]()
+                        if last:
+                            if pending is None:
+                                pending = self._ghost_exchange_start()
+                            self._ghost_exchange_finish(pending)
+                        self.u, self.ub = self.ub, self.u
+                        self.v, self.vb = self.vb, self.v
+                        self.s, self.sb = self.sb, self.s
+                        it += v
         split = self.overlap and b.world > 1 and (b.j1 - b.j0) >= 4 and not self.two_per_pass
         for _ in range(self.nsub - it):
             uvn = (self.ub, self.vb)
@@ -310,8 +306,8 @@ class DynamicsCore:
             self.s, self.sb = self.sb, self.s
 
     def _ghost_exchange_start(self):
-        """two-iterations-per-pass ghost zones of depth (2k, 2k-1): velocity node rows (4k up, 4k-1 down) and
-        stress rows (2k up, 2k-1 down) in one batch"""
+        """ghost zones of the multi-iteration passes, depth (d, d-1) with d = v k: velocity node rows (2d up, 2d-1
+        down) and stress rows (d up, d-1 down) in one batch"""
         if self.blk.world == 1:
             return None
         return self.halo.rows_exchange_start(self.sb, self.ops.private_rows, nodal_fields=(self.ub, self.vb),
@@ -321,21 +317,22 @@ class DynamicsCore:
         if pending is not None:
             self.halo.rows_exchange_finish(*pending)
 
-    def _iterate2_calls(self, split, ext=0):
-        """launches of one two-iteration pass for the current ping-pong parity (bound once, cached).
-        ext > 0: a pass inside a group, one launch over the owned rows extended by 2*ext ghost rows on each
+    def _pass_calls(self, v, split, ext=0):
+        """launches of one pass of v (2 or 3) sub-iterations for the current ping-pong parity (bound once, cached).
+        ext > 0: a pass inside a group, one launch over the owned rows extended by v*ext ghost rows on each
         side.  ext == 0 and split: the rows whose results travel to the neighbours first, the interior last"""
-        key = (self.u.data_ptr(), self.s[0].data_ptr(), split, 2, ext)
+        key = (self.u.data_ptr(), self.s[0].data_ptr(), split, v, ext)
         calls = self._calls.get(key)
         if calls is not None:
             return calls
         ops, b = self.ops, self.blk
         uv, uvn = (self.u, self.v), (self.ub, self.vb)
-        bind = getattr(ops, "bind_mevp_iterate2", None)
-        if bind is None:
-            bind = lambda *a: (lambda: ops.mevp_iterate2(*a))
+        name = "mevp_iterate%d" % v
+        bind = getattr(ops, "bind_" + name, None)
+        if bind is None:  # ops without a binding fast path (the CPU test stand-in)
+            bind = lambda *a: (lambda: getattr(ops, name)(*a))
         rng = []
-        lo, hi = max(b.j0 - 2 * ext, 0), min(b.j1 + 2 * ext, b.ny)
+        lo, hi = max(b.j0 - v * ext, 0), min(b.j1 + v * ext, b.ny)
         if split and ext == 0:
             if b.above is not None:  # top owned element rows: depth_below stress rows + 2*depth_below node rows go up
                 rng.append((b.j1 - b.depth_below, b.j1))

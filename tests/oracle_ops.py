@@ -83,6 +83,26 @@ class OracleOps:
         O.mevp_velocity(self.nx, ny, j0, j1, self.hx, self.hy, dt, self.p, sp, up, [_np(x) for x in uv_new], u0v0, tau, ocean,
                         cgh, cga)
 
+    def mevp_iterate3(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        """three sub-iterations on the owned rows [j0, j1), reading three rows below / two above, exactly the
+        dependency region of the three-iterations-per-pass kernel (csrc/mevp_fused3.hip)"""
+        dt, u0v0, tau, ocean, cgh, cga = self.nodal
+        ny = self.ny
+        top = lambda r: min(r, ny - 1) + 1  # exclusive end of a row range clipped to the array
+        sp = [_np(x).copy() for x in s_in]
+        uo = [_np(x) for x in uv_old]
+        args = (self.nx, ny)
+        O.mevp_stress(*args, max(j0 - 3, 0), top(j1 + 1), self.hx, self.hy, self.p, uo[0], uo[1], _np(pg), *sp)
+        up = [x.copy() for x in uo]
+        O.mevp_velocity(*args, max(j0 - 2, 0), top(j1 + 1), self.hx, self.hy, dt, self.p, sp, uo, up, u0v0, tau, ocean, cgh, cga)
+        O.mevp_stress(*args, max(j0 - 2, 0), top(j1), self.hx, self.hy, self.p, up[0], up[1], _np(pg), *sp)
+        up2 = [x.copy() for x in up]
+        O.mevp_velocity(*args, max(j0 - 1, 0), top(j1), self.hx, self.hy, dt, self.p, sp, up, up2, u0v0, tau, ocean, cgh, cga)
+        O.mevp_stress(*args, max(j0 - 1, 0), j1, self.hx, self.hy, self.p, up2[0], up2[1], _np(pg), *sp)
+        for a, b in zip(sp, s_out):
+            _np(b)[:, j0:j1] = a[:, j0:j1]
+        O.mevp_velocity(*args, j0, j1, self.hx, self.hy, dt, self.p, sp, up2, [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga)
+
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):
         res = O.prepare_advection(self.nx, self.ny, order, _np(u), _np(v))
         for dst, src in zip((vx, vy, unx, uny), res):

@@ -123,7 +123,7 @@ def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, 
         ctx.set_mevp_variant(variant)
         ctx.set_mevp_params(ctx.mevp_default_params(alpha=300.0, beta=300.0))
         bt, H, A, uo, vo, ua, va = fields(nx, ny)
-        depth = (2 * group, 2 * group - 1) if variant == 2 else (1, 1)  # `group` passes between two exchanges
+        depth = (variant * group, variant * group - 1) if variant >= 2 else (1, 1)  # `group` passes of `variant` sub-iterations between two exchanges
         blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
         cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
         core = cls(ctx, blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cuda"), exchanger=ThreadExchanger(blk, mailbox),
@@ -172,15 +172,16 @@ def test_row_blocks_on_one_gpu_equal_single_domain_bitwise(gpu, world, variant, 
         assert torch.equal(got, ref[key]), (key, world, variant)
 
 
-@pytest.mark.parametrize("world,group,nsub,coupled", [(2, 2, 9, False), (3, 4, 19, False), (4, 3, 13, True)])
-def test_grouped_passes_with_deep_ghost_zones_bitwise(gpu, world, group, nsub, coupled):
-    """latency-avoiding halo on the real kernels: `group` two-iteration passes between two ghost exchanges on
-    ghost zones of depth (2*group, 2*group - 1), ghost rows advanced redundantly; odd nsub and a shorter last
-    group.  Bit-identical to the single-domain run."""
+@pytest.mark.parametrize("world,group,nsub,coupled,variant", [(2, 2, 9, False, 2), (3, 4, 19, False, 2), (4, 3, 13, True, 2),
+                                                              (2, 1, 8, False, 3), (3, 2, 20, False, 3), (4, 4, 41, True, 3)])
+def test_grouped_passes_with_deep_ghost_zones_bitwise(gpu, world, group, nsub, coupled, variant):
+    """latency-avoiding halo on the real kernels: `group` passes of `variant` sub-iterations between two ghost
+    exchanges on ghost zones of depth (variant*group, variant*group - 1), ghost rows advanced redundantly; nsub
+    with a remainder and a shorter last group.  Bit-identical to the single-domain run."""
     nx, ny, nsteps = 150, 128, 2
-    ref = run_world(1, 2, coupled, nx, ny, nsub, nsteps)[0]
+    ref = run_world(1, variant, coupled, nx, ny, nsub, nsteps)[0]
     assert float(ref["u"].abs().max()) > 1e-5
-    parts = run_world(world, 2, coupled, nx, ny, nsub, nsteps, group=group)
+    parts = run_world(world, variant, coupled, nx, ny, nsub, nsteps, group=group)
     for key, dim in (("H", 1), ("A", 1), ("u", 0), ("v", 0), ("s11", 0)):
         got = torch.cat([parts[r][key] for r in range(world)], dim=dim)
         assert torch.equal(got, ref[key]), (key, world, group)

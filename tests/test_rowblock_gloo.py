@@ -48,7 +48,7 @@ def run_core(rank, world, overlap=True, coupled=False, variant=1, group=1, nsub=
     H[1:3] += 0.02 * rng.standard_normal((2, NY, NX))
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
-    depth = (2 * group, 2 * group - 1) if variant == 2 else (1, 1)  # `group` passes between two ghost exchanges
+    depth = (variant * group, variant * group - 1) if variant >= 2 else (1, 1)  # `group` passes of `variant` sub-iterations between two ghost exchanges
     blk = rowblock.RowBlock(NX, NY, rank, world, *depth)
     cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
     core = cls(OracleOps(mevp_variant=variant, alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cpu"),
@@ -67,8 +67,8 @@ def worker(rank, world, port, outdir, overlap=True, coupled=False, variant=1, gr
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         core = run_core(rank, world, overlap, coupled, variant, group, nsub)
-        if variant == 2 and world > 1:
-            assert core.two_per_pass and core.group_passes == group
+        if variant >= 2 and world > 1:
+            assert core.per_pass == variant and core.group_passes == group
         out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
         out["s11"] = core.owned(core.s[0]).clone()
         if coupled:
@@ -118,15 +118,20 @@ def test_row_block_run_equals_single_domain_bitwise(world, overlap, variant, tmp
         assert torch.equal(got, full), key
 
 
-@pytest.mark.parametrize("world,overlap,group,nsub", [(2, True, 2, 9), (3, True, 2, 9), (2, False, 3, 15), (2, True, 3, 7)])
-def test_grouped_passes_with_deep_ghost_zones_bitwise(world, overlap, group, nsub, tmp_path):
-    """latency-avoiding halo: `group` two-iteration passes between two exchanges on ghost zones of depth
-    (2*group, 2*group - 1); the ghost rows are advanced redundantly.  nsub is odd (a trailing single
-    sub-iteration) and not a multiple of the group (a shorter last group).  Must equal the 1-rank run."""
-    ref = run_core(0, 1, variant=2, nsub=nsub)
+@pytest.mark.parametrize("world,overlap,group,nsub,variant", [(2, True, 2, 9, 2), (3, True, 2, 9, 2), (2, False, 3, 15, 2), (2, True, 3, 7, 2),
+                                                              (2, True, 1, 8, 3), (2, True, 2, 14, 3), (3, False, 1, 7, 3)])
+def test_grouped_passes_with_deep_ghost_zones_bitwise(world, overlap, group, nsub, variant, tmp_path):
+    """latency-avoiding halo: `group` passes of `variant` (2 or 3) sub-iterations between two exchanges on ghost
+    zones of depth (variant*group, variant*group - 1); the ghost rows are advanced redundantly.  nsub leaves a
+    remainder (a trailing two-iteration pass and / or single sub-iteration) and is not a multiple of the
+    group (a shorter last group).  Must equal the 1-rank run."""
+    ref = run_core(0, 1, variant=variant, nsub=nsub)
     assert float(ref.u.abs().max()) > 1e-5
+    if variant == 3:
+        one = run_core(0, 1, variant=1, nsub=nsub)  # pass structure does not change the arithmetic
+        assert torch.equal(one.u, ref.u) and torch.equal(one.s[0], ref.s[0]) and torch.equal(one.H, ref.H)
     port = free_port()
-    mp.spawn(worker, args=(world, port, str(tmp_path), overlap, False, 2, group, nsub), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, port, str(tmp_path), overlap, False, variant, group, nsub), nprocs=world, join=True)
     parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
     for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
         assert torch.equal(torch.cat([p[key] for p in parts], dim=1), full), key

@@ -32,7 +32,8 @@ def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3):
     alpha = bt.stable_alpha(dt)
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
     rank = world // 2
-    depth = (2 * kpass, 2 * kpass - 1)
+    v = min(ctx.mevp_variant, 3)  # sub-iterations per kernel pass
+    depth = (v * kpass, v * kpass - 1)
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
     core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=NullExchanger(blk) if world > 1 else None)
     H, A = bt.dg_fields()
