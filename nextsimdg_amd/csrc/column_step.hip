@@ -36,6 +36,32 @@ constexpr double WATER_TF = 273.15;
 
 __device__ __forceinline__ double kelvin(double c) { return c + WATER_TF; } // constants.hpp:128
 
+// Divisions.  The kernel is bound by fp64 issue, not by HBM, as long as its ~35 divisions per element go through
+// the IEEE sequence (v_div_scale x2, v_rcp, 6 fma, v_div_fmas, v_div_fixup = 13 instructions each, more than half
+// of the instruction stream).  They are replaced by
+//   qdiv(a, b)      hardware reciprocal seed + two Newton steps + one residual correction of the quotient (8 instr.)
+//   rdiv(a, b, 1/b) the same correction with a reciprocal that is known already: b is a compile-time constant or
+//                   a launch parameter such as dt (3 instructions)
+// Both return the quotient to within one ulp (the residual step makes it the correctly rounded one in all but
+// a few per mille of the cases), far inside the 1e-13 parity tolerance.  What they drop is the range scaling and
+// the special-case fix-up: every denominator of the column physics is finite and non-zero for physical input
+// (the reference guards the only data-dependent zero, conc == 0, itself); a zero or non-finite denominator
+// yields NaN here where IEEE division yields Inf or 0.
+__device__ __forceinline__ double qdiv(double a, double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double rdiv(double a, double b, double rb)
+{
+    const double q = a * rb;
+    return __builtin_fma(__builtin_fma(-b, q, a), rb, q);
+}
+#define CDIV(a, c) rdiv((a), (c), 1.0 / (c)) /* c is a compile-time constant: 1/c is folded */
+
 // NextsimPhysics::SpecificHumidity parameter sets, NextsimPhysics.cpp:310,346,324-325
 struct SpHum {
     double a, b, c, d, A, B, C;
@@ -51,11 +77,11 @@ __device__ __forceinline__ double sh_f(const SpHum& s, double t, double pPa) // 
 }
 __device__ __forceinline__ double sh_est(const SpHum& s, double t, double sal) // :377-381
 {
-    return s.a * exp((s.b - t / s.d) * t / (t + s.c)) * (1 - 5.37e-4 * sal);
+    return s.a * exp(qdiv((s.b - CDIV(t, s.d)) * t, t + s.c)) * (1 - 5.37e-4 * sal);
 }
 __device__ __forceinline__ double sh_q(double est, double f, double p) // :335-343
 {
-    return SH_ALPHA * f * est / (p - SH_BETA * f * est);
+    return qdiv(SH_ALPHA * f * est, p - SH_BETA * f * est);
 }
 
 __device__ __forceinline__ double freezing_point(int kind, double sss)
@@ -72,12 +98,12 @@ __device__ __forceinline__ double ice_albedo(const nsdg_column_params& P, double
     if (P.albedo_kind == NSDG_ALBEDO_CCSM) { // physics/src/modules/CCSMIceAlbedo.cpp:28-36
         const double iceAlbedoT = P.ccsm_ice_albedo - fmax(0., 0.075 * (temperature + 1.));
         const double snowAlbedoT = P.ccsm_snow_albedo - fmax(0., 0.124 * (temperature + 1.));
-        const double f = hs / (hs + 0.02);
+        const double f = qdiv(hs, hs + 0.02);
         return f * snowAlbedoT + (1 - f) * iceAlbedoT;
     }
     const double bare = ICE_ALBEDO + 0.4 * (1 - ICE_ALBEDO) * P.i0;
     if (P.albedo_kind == NSDG_ALBEDO_SMU2) // SMU2IceAlbedo.cpp:21-29
-        return (hs > 0.) ? fmin(SNOW_ALBEDO, ICE_ALBEDO + (SNOW_ALBEDO - ICE_ALBEDO) * hs / 0.2) : bare;
+        return (hs > 0.) ? fmin(SNOW_ALBEDO, ICE_ALBEDO + CDIV((SNOW_ALBEDO - ICE_ALBEDO) * hs, 0.2)) : bare;
     return (hs > 0.) ? SNOW_ALBEDO : bare; // SMUIceAlbedo.cpp:19-26
 }
 
@@ -98,8 +124,10 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     double newice = in.newice;
 
     // PrognosticData.hpp:56,75,78; ExternalData.hpp:60
-    const double h_true = (conc != 0) ? thick / conc : 0;
-    const double hs_true = (conc != 0) ? snow / conc : 0;
+    const double rconc = qdiv(1.0, conc); // NaN for conc == 0, never used then
+    const double h_true = (conc != 0) ? rdiv(thick, conc, rconc) : 0;
+    const double hs_true = (conc != 0) ? rdiv(snow, conc, rconc) : 0;
+    const double idt = 1.0 / dt; // launch parameter: one IEEE division per lane
     const double tf = freezing_point(P.freezing_kind, sss);
     const double mlbhc = mld * WATER_RHOOCEAN * WATER_CP;
 
@@ -109,8 +137,8 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     const double est_i = sh_est(SH_ICE, tice, 0.);
     const double f_i = sh_f(SH_ICE, tice, slp);
     const double q_i = sh_q(est_i, f_i, slp);
-    const double Ra_wet = AIR_RA / (1 - q_a * (1 - VAP_RA / AIR_RA));
-    const double rho = slp / (Ra_wet * kelvin(tair));
+    const double Ra_wet = qdiv(AIR_RA, 1 - q_a * (1 - VAP_RA / AIR_RA));
+    const double rho = qdiv(slp, Ra_wet * kelvin(tair));
     const double cspec = AIR_CP + q_a * VAP_CP;
     double hs = hs_true;
     double hi = h_true;
@@ -134,23 +162,23 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     { // SpecificHumidityIce::dq_dT :356-368 (df_dT written exactly as in the reference)
         const double df_dT = 2 * SH_ICE.C * SH_ICE.B * tice;
         const double ct = SH_ICE.c + tice;
-        const double dest_dT = (SH_ICE.b * SH_ICE.c * SH_ICE.d - tice * (2 * SH_ICE.c + tice)) / (SH_ICE.d * (ct * ct)) * est_i;
+        const double dest_dT = qdiv(SH_ICE.b * SH_ICE.c * SH_ICE.d - tice * (2 * SH_ICE.c + tice), SH_ICE.d * (ct * ct)) * est_i;
         const double den = slp - SH_BETA * est_i * f_i;
-        dq_dT = SH_ALPHA * slp * (f_i * dest_dT + est_i * df_dT) / (den * den);
+        dq_dT = qdiv(SH_ALPHA * slp * (f_i * dest_dT + est_i * df_dT), den * den);
     }
     const double dQlh_dT = Li * (P.drag_ice_t * rho * wind * dq_dT);
     const double Qshi = P.drag_ice_t * rho * cspec * wind * (tice - tair);
     const double dQsh_dT = P.drag_ice_t * rho * cspec * wind;
-    const double albedoValue = ice_albedo(P, tice, (conc > 0) ? (snow / conc) : 0.);
+    const double albedoValue = ice_albedo(P, tice, (conc > 0) ? rdiv(snow, conc, rconc) : 0.);
     const double Qswi = -qsw * (1. - P.i0) * (1 - albedoValue);
     const double ticeK = kelvin(tice), ticeK2 = ticeK * ticeK;
     const double sb_i = ICE_EPSILON * SIGMA * (ticeK2 * ticeK2);
     const double Qlwi = sb_i - qlw;
-    const double dQlw_dT = 4 / ticeK * sb_i;
+    const double dQlw_dT = qdiv(4, ticeK) * sb_i;
     const double Qia = Qlhi + Qshi + Qlwi + Qswi;
     const double dQ_dT = dQlh_dT + dQsh_dT + dQlw_dT;
     // ice-ocean :222-226 -> BasicIceOceanHeatFlux.cpp:16-25
-    double Qio = (sst - tf) * mlbhc / dt;
+    double Qio = rdiv((sst - tf) * mlbhc, dt, idt);
 
     // ---- massFluxIceOcean :200-220
     double hifroms = 0;
@@ -164,29 +192,29 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
             hs = 0;
             Tnew = freezingPointIce;
         } else {
-            const double k_lSlab = P.ks * ICE_KAPPA / (P.ks * h_true + ICE_KAPPA * hs_true); // :58-59
+            const double k_lSlab = qdiv(P.ks * ICE_KAPPA, P.ks * h_true + ICE_KAPPA * hs_true); // :58-59
             const double QIceConduction = k_lSlab * (tf - tice); // :60
             const double remainingFlux = QIceConduction - Qia; // :61
-            Tnew = tice + remainingFlux / (k_lSlab + dQ_dT); // :62-63
+            Tnew = tice + qdiv(remainingFlux, k_lSlab + dQ_dT); // :62-63
             Tnew = fmin((hs_true > 0.) ? 0. : freezingPointIce, Tnew); // :66-68
-            const double snowMeltRate = fmin(-remainingFlux, 0.) / bulkLHFusionSnow; // :71
-            const double snowSublRate = subl / ICE_RHOSNOW; // :72
+            const double snowMeltRate = CDIV(fmin(-remainingFlux, 0.), bulkLHFusionSnow); // :71
+            const double snowSublRate = CDIV(subl, ICE_RHOSNOW); // :72
             hs += (snowMeltRate - snowSublRate) * dt; // :74
-            const double excessIceMelt = fmin(hs, 0.) * bulkLHFusionSnow / bulkLHFusionIce; // :76-77
+            const double excessIceMelt = CDIV(fmin(hs, 0.) * bulkLHFusionSnow, bulkLHFusionIce); // :76-77
             hs = fmax(hs, 0.); // :79
-            hs += snowfall * dt / ICE_RHOSNOW; // :81
-            const double iceBottomChange = (QIceConduction - Qio) * dt / bulkLHFusionIce; // :84-85
+            hs += CDIV(snowfall * dt, ICE_RHOSNOW); // :81
+            const double iceBottomChange = CDIV((QIceConduction - Qio) * dt, bulkLHFusionIce); // :84-85
             hi += excessIceMelt + iceBottomChange; // :87-88
-            const double iceDraught = (hi * ICE_RHO + hs * ICE_RHOSNOW) / WATER_RHOOCEAN; // :95-97
+            const double iceDraught = CDIV(hi * ICE_RHO + hs * ICE_RHOSNOW, WATER_RHOOCEAN); // :95-97
             if (P.flooding && iceDraught > hi) { // :98-106
                 const double newIce = iceDraught - hi;
                 hifroms += newIce;
                 hi = iceDraught;
-                hs -= newIce * ICE_RHO / ICE_RHOSNOW;
+                hs -= CDIV(newIce * ICE_RHO, ICE_RHOSNOW);
             }
             if (hi < P.min_thick) { // :108-132
                 hifroms = 0;
-                Qio += hi * bulkLHFusionIce / dt + hs * bulkLHFusionSnow / dt;
+                Qio += rdiv(hi * bulkLHFusionIce, dt, idt) + rdiv(hs * bulkLHFusionSnow, dt, idt);
                 hi = 0;
                 hs = 0;
                 Tnew = freezingPointIce;
@@ -195,31 +223,32 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     }
     { // newIceFormation :228-254; newice keeps its old value when the branch is not taken (A.7 quirk 1)
         const double coolingFlux = Qow;
-        const double deltaTml = -coolingFlux / mlbhc * dt;
+        const double deltaTml = qdiv(-coolingFlux, mlbhc) * dt;
         const double t1 = sst + deltaTml;
         if (t1 < tf) {
-            const double sensibleFlux = (tf - sst) / deltaTml * coolingFlux;
+            const double sensibleFlux = qdiv(tf - sst, deltaTml) * coolingFlux;
             const double latentFlux = coolingFlux - sensibleFlux;
             Qow = sensibleFlux;
-            newice = latentFlux * dt * (1 - conc) / (ICE_LF * ICE_RHO);
+            newice = CDIV(latentFlux * dt * (1 - conc), ICE_LF * ICE_RHO);
         }
     }
     double c_new;
     { // lateralGrowth :262-289 with HiblerConcentration.cpp:32-47
         double del_c = newice * (1. / P.h0);
         if (hi < h_true && !(conc >= 1))
-            del_c += (hi - h_true) * conc * P.phi_m / h_true;
+            del_c += qdiv((hi - h_true) * conc * P.phi_m, h_true);
         c_new = conc + del_c;
         if (c_new >= P.min_conc) {
-            hi += (newice - hi * del_c) / (conc + del_c); // updateThickness :257-260
+            const double rc = qdiv(1.0, conc + del_c);
+            hi += rdiv(newice - hi * del_c, conc + del_c, rc); // updateThickness :257-260
             if (del_c < 0)
-                Qow -= del_c * hs * ICE_LF * ICE_RHOSNOW / dt;
+                Qow -= rdiv(del_c * hs * ICE_LF * ICE_RHOSNOW, dt, idt);
             else
-                hs += (0. - hs * del_c) / (conc + del_c);
+                hs += rdiv(0. - hs * del_c, conc + del_c, rc);
         }
     }
     if (c_new < P.min_conc || hi < P.min_thick) { // :211-219
-        Qow += c_new * ICE_LF * (hi * ICE_RHO + hs * ICE_RHOSNOW) / dt;
+        Qow += rdiv(c_new * ICE_LF * (hi * ICE_RHO + hs * ICE_RHOSNOW), dt, idt);
         c_new = 0;
         hi = 0;
         hs = 0;
@@ -277,7 +306,10 @@ __global__ __launch_bounds__(256) void column_step_kernel(nsdg_column_params P, 
 
 // Production kernel: two adjacent elements per lane, every plane access a 16-byte load/store (the
 // widest coalesced access; 8-byte accesses reach a lower fraction of the HBM rate).
-__global__ __launch_bounds__(256) void column_step_kernel_x2(nsdg_column_params P, long npairs, double dt,
+#ifndef NSDG_COL_WAVES
+#define NSDG_COL_WAVES 1
+#endif
+__global__ __launch_bounds__(256, NSDG_COL_WAVES) void column_step_kernel_x2(nsdg_column_params P, long npairs, double dt,
     double2* __restrict__ hice, double2* __restrict__ cice, double2* __restrict__ hsnow, double2* __restrict__ tice0,
     const double2* __restrict__ sst_, const double2* __restrict__ sss_, const double2* __restrict__ tair_,
     const double2* __restrict__ tdew_, const double2* __restrict__ slp_, const double2* __restrict__ qsw_,
