@@ -330,7 +330,7 @@ int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, c
         const long slots = 1L * 4 * ctx->num_cus;
         double best = 1e30;
         R = 16;
-        for (int r = 4; r <= 256; ++r) {
+        for (int r = 1; r <= 256; ++r) {
             const long waves = (long)nsdg_div_up(j1 - j0, r) * ncw;
             const long rounds = (waves + slots - 1) / slots;
             const double cost = rounds * (r + 5.0) + (rounds == 1 ? 2.0 : 0.0);

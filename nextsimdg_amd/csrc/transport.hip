@@ -126,7 +126,10 @@ __device__ __forceinline__ void transport_rhs(const double (&c)[DG<ORDER>::NC], 
 // neighbours hit L2: the time does not depend on the workgroup height).  The fields advected by the same
 // velocity are processed by the same lane, so the DG velocity and the edge velocities are loaded once.
 template <int ORDER>
-__global__ __launch_bounds__(256) void transport_stage_kernel(int nx, int ny, int j0, int j1, int nfields, double ihx, double ihy,
+#ifndef NSDG_TR_WAVES
+#define NSDG_TR_WAVES 1
+#endif
+__global__ __launch_bounds__(256, NSDG_TR_WAVES) void transport_stage_kernel(int nx, int ny, int j0, int j1, int nfields, double ihx, double ihy,
     double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
     const double* __restrict__ un_x, const double* __restrict__ un_y)
 {

@@ -24,7 +24,7 @@ class NullExchanger(rowblock.HaloExchanger):
         return
 
 
-def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3):
+def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3, overlap=True):
     dev = torch.device("cuda:0")
     ctx = abi.Context(dev)
     L, dt = 512e3, 120.0
@@ -35,7 +35,7 @@ def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3):
     v = min(ctx.mevp_variant, 3)  # sub-iterations per kernel pass
     depth = (v * kpass, v * kpass - 1)
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
-    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=NullExchanger(blk) if world > 1 else None)
+    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=NullExchanger(blk) if world > 1 else None, overlap=overlap)
     H, A = bt.dg_fields()
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
@@ -51,11 +51,20 @@ def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3):
 
 
 if __name__ == "__main__":
-    worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    ks = (1, 4)
+    args = sys.argv[1:]
+    overlap = True
+    if args and args[0] == "--no-overlap":  # one launch per pass, the exchange would follow it un-overlapped
+        overlap = False
+        args = args[1:]
+    if args and args[0] == "--k":
+        ks = tuple(int(x) for x in args[1].split(","))
+        args = args[2:]
+    worlds = [int(a) for a in args] or [1, 2, 4, 8]
     base = None
     for w in worlds:
-        for k in ((1,) if w == 1 else (1, 4)):
-            ms, host_ms, rows = run(w, k)
+        for k in ((1,) if w == 1 else ks):
+            ms, host_ms, rows = run(w, k, overlap=overlap)
             base = ms if w == 1 else base
-            print("world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
+            print(("" if overlap else "no-overlap  ") + "world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
                   % (w, k, rows, ms, host_ms, "%.2f" % (base / ms) if base else "-"), flush=True)
