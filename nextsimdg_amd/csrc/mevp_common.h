@@ -18,6 +18,11 @@
     } while (0)
 #define NSDG_STAMP_ARGS , unsigned (&stamp_acc)[12], unsigned& stamp_last
 #define NSDG_STAMP_PASS , stamp_acc, stamp_last
+#elif defined(NSDG_PHASE_FENCE)
+// scheduling fences at the phase boundaries only (experiment: keeps the compiler from interleaving phases)
+#define NSDG_STAMP(k) __builtin_amdgcn_sched_barrier(0)
+#define NSDG_STAMP_ARGS
+#define NSDG_STAMP_PASS
 #else
 #define NSDG_STAMP(k)
 #define NSDG_STAMP_ARGS
