@@ -29,9 +29,13 @@
  *        un_y[g*nx*(ny+1) + ey*nx + ix]       (horizontal edges, normal = +y)
  *  - arrays private to the mEVP sub-cycle -- the stress coefficients s11/s12/s22 (nc = 8) and the ice
  *    strength at the 3x3 Gauss points pg (nc = 9, q = 3*qy + qx) -- use a TILED layout: tiles of 64
- *    consecutive elements of a row with all coefficients of the tile together,
- *        a[((iy*ntx + ix/64)*nc + c)*64 + ix%64],  ntx = ceil(nx/64),  nsdg_tiled_len(nx, ny, nc) doubles.
- *    Element rows stay contiguous, so row ranges / ghost rows work as for the plane layout.
+ *    consecutive elements of a row with all coefficients of the tile together, the coefficients in pairs
+ *    interleaved by element (so that two coefficients travel in one 16-byte access): with the tile base
+ *    T = ((iy*ntx + ix/64)*nc)*64, ntx = ceil(nx/64), and l = ix%64,
+ *        coefficient c < 2*(nc/2):  a[T + (c/2)*128 + 2*l + c%2]
+ *        odd last coefficient (nc = 9, c = 8):  a[T + (nc/2)*128 + l]
+ *    nsdg_tiled_len(nx, ny, nc) doubles, 16-byte aligned.  Element rows stay contiguous, so row ranges / ghost
+ *    rows work as for the plane layout.  (nextsimdg_amd/abi.py: tile() / untile() convert from / to planes.)
  *  - Row ranges [j0, j1) are ELEMENT rows of the local array; the edges of the local array are the
  *    physical boundary (zero inflow for transport, v = 0 for momentum).  A rank of a row-block
  *    decomposition passes arrays that include its ghost rows and the range of rows it owns.

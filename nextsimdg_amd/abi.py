@@ -105,20 +105,34 @@ TILE = 64
 
 
 def tile(a):
-    """[nc, ny, nx] coefficient planes -> the tiled layout [ny, ceil(nx/64), nc, 64] of include/nsdg.h
-    (stress coefficients and Gauss-point ice strength); padding elements are zero"""
+    """[nc, ny, nx] coefficient planes -> the tiled layout of include/nsdg.h (stress coefficients and Gauss-point
+    ice strength), returned as [ny, ceil(nx/64), nc*64]: per tile of 64 elements the coefficients in pairs
+    interleaved by element, (c/2)*128 + 2*l + c%2, an odd last coefficient at (nc/2)*128 + l; padding elements
+    are zero"""
     import torch
 
     nc, ny, nx = a.shape
     ntx = (nx + TILE - 1) // TILE
-    b = torch.nn.functional.pad(a, (0, ntx * TILE - nx))
-    return b.reshape(nc, ny, ntx, TILE).permute(1, 2, 0, 3).contiguous()
+    b = torch.nn.functional.pad(a, (0, ntx * TILE - nx)).reshape(nc, ny, ntx, TILE)
+    npair = nc // 2
+    parts = [b[:2 * npair].reshape(npair, 2, ny, ntx, TILE).permute(2, 3, 0, 4, 1).reshape(ny, ntx, npair * 2 * TILE)]
+    if nc % 2:
+        parts.append(b[nc - 1].reshape(ny, ntx, TILE))
+    return torch.cat(parts, dim=2).contiguous()
 
 
 def untile(t, nx):
-    """inverse of tile(): [ny, ntx, nc, 64] -> [nc, ny, nx]"""
-    ny, ntx, nc, _ = t.shape
-    return t.permute(2, 0, 1, 3).reshape(nc, ny, ntx * TILE)[:, :, :nx].contiguous()
+    """inverse of tile(): [ny, ntx, nc*64] -> [nc, ny, nx]"""
+    import torch
+
+    ny, ntx, w = t.shape
+    nc = w // TILE
+    npair = nc // 2
+    pairs = t[:, :, :npair * 2 * TILE].reshape(ny, ntx, npair, TILE, 2).permute(2, 4, 0, 1, 3).reshape(2 * npair, ny, ntx * TILE)
+    planes = [pairs]
+    if nc % 2:
+        planes.append(t[:, :, npair * 2 * TILE:].reshape(1, ny, ntx * TILE))
+    return torch.cat(planes, dim=0)[:, :, :nx].contiguous()
 
 
 def _ptr(t):
@@ -185,7 +199,7 @@ class Context:
     def private_zeros(self, nc, ny, nx, device):
         import torch
 
-        return torch.zeros(ny, (nx + TILE - 1) // TILE, nc, TILE, dtype=torch.float64, device=device)
+        return torch.zeros(ny, (nx + TILE - 1) // TILE, nc * TILE, dtype=torch.float64, device=device)
 
     @staticmethod
     def private_rows(f, j0, j1):

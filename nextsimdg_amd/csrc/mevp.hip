@@ -14,6 +14,8 @@
 //                        deterministic and independent of the decomposition -- and applies the
 //                        momentum update.
 // Variant 1 ("fused march") lives in mevp_fused.hip.
+#include <initializer_list>
+
 #include "mevp_common.h"
 
 namespace nsdg_mevp_detail {
@@ -38,33 +40,22 @@ __global__ __launch_bounds__(256) void mevp_stress_kernel(int nx, int ny, int k0
         ul[a] = u[n];
         vl[a] = v[n];
     }
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-        P[q] = pg[tp + q * 64];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        s11[i] = S11i[ts + i * 64];
-        s12[i] = S12i[ts + i * 64];
-        s22[i] = S22i[ts + i * 64];
-    }
+    tile_load9(pg, tp, ix & 63, P);
+    tile_load8(S11i, ts, s11);
+    tile_load8(S12i, ts, s12);
+    tile_load8(S22i, ts, s22);
     stress_update(ul, vl, P, ihx, ihy, ialpha, dmin2, s11, s12, s22);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        S11[ts + i * 64] = s11[i];
-        S12[ts + i * 64] = s12[i];
-        S22[ts + i * 64] = s22[i];
-    }
+    tile_store8(S11, ts, s11);
+    tile_store8(S12, ts, s12);
+    tile_store8(S22, ts, s22);
 }
 
 __device__ __forceinline__ void load_stress(const double* __restrict__ S11, const double* __restrict__ S12,
     const double* __restrict__ S22, long ts, double (&s11)[8], double (&s12)[8], double (&s22)[8])
 {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        s11[i] = S11[ts + i * 64];
-        s12[i] = S12[ts + i * 64];
-        s22[i] = S22[ts + i * 64];
-    }
+    tile_load8(S11, ts, s11);
+    tile_load8(S12, ts, s12);
+    tile_load8(S22, ts, s22);
 }
 
 __global__ __launch_bounds__(256) void mevp_velocity_kernel(NodalConsts K, int nx, int ny, int j0, int j1, double hx, double hy,
@@ -263,6 +254,7 @@ __global__ __launch_bounds__(256) void ice_strength_kernel(int nx, int ny, int j
         hc[c] = H[c * N + e];
         ac[c] = A[c * N + e];
     }
+    double pq[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         double h = 0., a = 0.;
@@ -273,8 +265,9 @@ __global__ __launch_bounds__(256) void ice_strength_kernel(int nx, int ny, int j
         }
         h = fmax(h, 0.);
         a = fmin(fmax(a, 0.), 1.);
-        pg[tp + q * 64] = pstar * h * exp(-compaction * (1. - a));
+        pq[q] = pstar * h * exp(-compaction * (1. - a));
     }
+    tile_store9(pg, tp, ix & 63, pq);
 }
 
 __global__ __launch_bounds__(256) void wind_stress_kernel(long n, double f_atm, const double* __restrict__ ua,
@@ -324,6 +317,16 @@ int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, const double* 
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
     const double* packed, const double* pg);
 
+// the tiled arrays are accessed 16 bytes at a time
+static inline bool aligned16(std::initializer_list<const void*> ptrs)
+{
+    for (const void* p : ptrs)
+        if ((uintptr_t)p & 15)
+            return false;
+    return true;
+}
+#define NSDG_CHECK_TILED(...) NSDG_CHECK_ARG(aligned16({ __VA_ARGS__ }), "tiled arrays (stress, ice strength) must be 16-byte aligned")
+
 // defined in mevp_fused3.hip
 int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
     double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
@@ -358,6 +361,7 @@ int nsdg_ice_strength(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* H, co
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
     NSDG_CHECK_ARG(H && A && pg, "null field pointer");
+    NSDG_CHECK_TILED(pg);
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
@@ -412,6 +416,7 @@ int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, con
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(0 <= k0 && k0 <= k1 && k1 <= ctx->ny, "row range outside the local array");
     NSDG_CHECK_ARG(u && v && pg && s11 && s12 && s22, "null field pointer");
+    NSDG_CHECK_TILED(pg, s11, s12, s22);
     if (k0 == k1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
@@ -456,6 +461,7 @@ int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11,
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
     NSDG_CHECK_ARG(s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed, "null field pointer");
+    NSDG_CHECK_TILED(s11, s12, s22);
     NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
     if (j0 == j1)
         return NSDG_OK;
@@ -480,6 +486,7 @@ int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const d
     NSDG_CHECK_ARG(k0 == j0 - 1 || (k0 == 0 && j0 == 0), "need k0 == j0 - 1 (one ghost row below) or k0 == j0 == 0");
     NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed && pg,
         "null field pointer");
+    NSDG_CHECK_TILED(s11i, s12i, s22i, s11, s12, s22, pg);
     NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
     NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
     if (k0 == j1)
@@ -506,6 +513,7 @@ int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     NSDG_CHECK_ARG(j0 == 0 || j0 >= 2, "need two ghost rows below the owned rows (or j0 == 0 at the physical boundary)");
     NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed && pg,
         "null field pointer");
+    NSDG_CHECK_TILED(s11i, s12i, s22i, s11, s12, s22, pg);
     NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
     NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
     if (!(ctx->pack_dt > 0)) {
@@ -531,6 +539,7 @@ int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     NSDG_CHECK_ARG(j1 == ctx->ny || j1 + 2 <= ctx->ny, "need two ghost rows above the owned rows (or j1 == ny at the physical boundary)");
     NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed && pg,
         "null field pointer");
+    NSDG_CHECK_TILED(s11i, s12i, s22i, s11, s12, s22, pg);
     NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
     NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
     if (!(ctx->pack_dt > 0)) {

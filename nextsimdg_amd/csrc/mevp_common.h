@@ -35,15 +35,51 @@ using namespace nsdg_tab;
 
 // Tiled layout of the element-wise arrays that only the mEVP kernels touch (stress coefficients,
 // Gauss-point ice strength): tiles of 64 consecutive elements of a row, all nc coefficients of a tile
-// stored together,
-//     a[((iy*ntx + ix/64)*nc + c)*64 + ix%64],   ntx = ceil(nx/64)   (rows padded to whole tiles).
-// A lane then reaches every coefficient of its element from ONE base address plus a compile-time
-// immediate (c*512 B <= 4 KB), instead of one 64-bit address per coefficient plane, and a wave streams
-// 4 KB of contiguous HBM per array and element row instead of 8 separate 512 B pieces 32 MB apart.
+// stored together, and inside a tile the coefficients in PAIRS interleaved by element,
+//     tile (iy, tx = ix/64) at ((iy*ntx + tx) * nc) * 64,   ntx = ceil(nx/64)   (rows padded to whole tiles)
+//     coefficient c < 2*(nc/2) of element l = ix%64 at  (c/2)*128 + 2*l + c%2
+//     the odd last coefficient (nc = 9: c = 8) at        (nc/2)*128 + l
+// A lane then reaches every coefficient of its element from ONE base address plus compile-time immediates,
+// a wave streams 4 KB of contiguous HBM per array and element row, and every access is a 16-byte
+// global_load_dwordx4 / global_store_dwordx4 of two coefficients: vector-memory instructions cost the issuing
+// wave the same whether they move 8 or 16 bytes per lane (profiles/r01_vmem_issue_microbench.txt), so pairing
+// halves the issue cost of the stress and ice-strength traffic.  Arrays must be 16-byte aligned.
 __host__ __device__ __forceinline__ int tiles_per_row(int nx) { return (nx + 63) >> 6; }
 __device__ __forceinline__ long tile_off(int ix, int iy, int ntx, int nc)
 {
-    return ((long)iy * ntx + (ix >> 6)) * (nc * 64) + (ix & 63);
+    return ((long)iy * ntx + (ix >> 6)) * (nc * 64) + 2 * (ix & 63); // address of coefficient 0; the pair (2k, 2k+1) is at + 128 k
+}
+// 8 stress coefficients of one element: four 16-byte accesses
+__device__ __forceinline__ void tile_load8(const double* __restrict__ a, long t, double (&c)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double2 v = *reinterpret_cast<const double2*>(a + t + 128 * k);
+        c[2 * k] = v.x, c[2 * k + 1] = v.y;
+    }
+}
+__device__ __forceinline__ void tile_store8(double* __restrict__ a, long t, const double (&c)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<double2*>(a + t + 128 * k) = make_double2(c[2 * k], c[2 * k + 1]);
+}
+// 9 Gauss-point values of one element: four 16-byte accesses and one 8-byte access (t = tile_off(ix, .., 9), l = ix % 64)
+__device__ __forceinline__ void tile_load9(const double* __restrict__ a, long t, int l, double (&c)[9])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double2 v = *reinterpret_cast<const double2*>(a + t + 128 * k);
+        c[2 * k] = v.x, c[2 * k + 1] = v.y;
+    }
+    c[8] = a[t + 512 - l];
+}
+__device__ __forceinline__ void tile_store9(double* __restrict__ a, long t, int l, const double (&c)[9])
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<double2*>(a + t + 128 * k) = make_double2(c[2 * k], c[2 * k + 1]);
+    a[t + 512 - l] = c[8];
 }
 
 #define FMA_TAB(acc, tab, val)   \

@@ -24,15 +24,6 @@
 // wave is independent and runs to completion.
 #include "mevp_common.h"
 
-// streamed-once data (stress in/out, Gauss-point strength): non-temporal policy keeps the velocity rows,
-// which ARE re-read by the next row of the march, in cache
-#ifdef NSDG_FUSED_NT
-#define NSDG_LD(p) __builtin_nontemporal_load(p)
-#define NSDG_ST(v, p) __builtin_nontemporal_store(v, p)
-#else
-#define NSDG_LD(p) (*(p))
-#define NSDG_ST(v, p) (*(p) = (v))
-#endif
 
 namespace nsdg_mevp_detail {
 
@@ -83,38 +74,27 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
             ul[a] = u_old[n];
             vl[a] = v_old[n];
         }
-#pragma unroll
-        for (int q = 0; q < 9; ++q)
-            Pq[q] = NSDG_LD(&pg[tp + q * 64]);
+        tile_load9(pg, tp, ix & 63, Pq);
         if constexpr (MINW >= 2) {
             // 2 waves/SIMD build: stage the loads so that the live set stays under 256 registers -- the old
             // stress is fetched only after the projected stress is formed, the partner wave covers the latency
             double r11[8], r12[8], r22[8];
             stress_projected(ul, vl, Pq, ihx, ihy, dmin2, r11, r12, r22);
             asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s11[i] = NSDG_LD(&S.i11[ts + i * 64]);
-                s12[i] = NSDG_LD(&S.i12[ts + i * 64]);
-                s22[i] = NSDG_LD(&S.i22[ts + i * 64]);
-            }
+            tile_load8(S.i11, ts, s11);
+            tile_load8(S.i12, ts, s12);
+            tile_load8(S.i22, ts, s22);
             stress_relax(ialpha, r11, r12, r22, s11, s12, s22);
         } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s11[i] = NSDG_LD(&S.i11[ts + i * 64]);
-                s12[i] = NSDG_LD(&S.i12[ts + i * 64]);
-                s22[i] = NSDG_LD(&S.i22[ts + i * 64]);
-            }
+            tile_load8(S.i11, ts, s11);
+            tile_load8(S.i12, ts, s12);
+            tile_load8(S.i22, ts, s22);
             stress_update(ul, vl, Pq, ihx, ihy, ialpha, dmin2, s11, s12, s22);
         }
         if (!prologue && own) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                NSDG_ST(s11[i], &S.o11[ts + i * 64]);
-                NSDG_ST(s12[i], &S.o12[ts + i * 64]);
-                NSDG_ST(s22[i], &S.o22[ts + i * 64]);
-            }
+            tile_store8(S.o11, ts, s11);
+            tile_store8(S.o12, ts, s12);
+            tile_store8(S.o22, ts, s22);
         }
         double cx[9], cy[9];
         node_contrib_all(s11, s12, s22, hx, hy, cx, cy);

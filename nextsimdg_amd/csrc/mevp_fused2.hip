@@ -80,15 +80,10 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
             ul[a] = u_old[n];
             vl[a] = v_old[n];
         }
-#pragma unroll
-        for (int q = 0; q < 9; ++q)
-            cur.P[q] = pg[tp + q * 64];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            cur.s11[i] = S.i11[ts + i * 64];
-            cur.s12[i] = S.i12[ts + i * 64];
-            cur.s22[i] = S.i22[ts + i * 64];
-        }
+        tile_load9(pg, tp, ix & 63, cur.P);
+        tile_load8(S.i11, ts, cur.s11);
+        tile_load8(S.i12, ts, cur.s12);
+        tile_load8(S.i22, ts, cur.s22);
         load_nodal(packed, nV, cur.c[0]);
         load_nodal(packed, nV + 1, cur.c[1]);
         load_nodal(packed, nV + nn, cur.c[2]);
@@ -148,12 +143,9 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
         const bool store = M.own && r >= M.y0;
         if (store) {
             const long ts = tile_off(ix, r, M.ntx, 8);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                S.o11[ts + i * 64] = prev.s11[i];
-                S.o12[ts + i * 64] = prev.s12[i];
-                S.o22[ts + i * 64] = prev.s22[i];
-            }
+            tile_store8(S.o11, ts, prev.s11);
+            tile_store8(S.o12, ts, prev.s12);
+            tile_store8(S.o22, ts, prev.s22);
         }
         double cx[9], cy[9];
         NSDG_STAMP(6);

@@ -115,15 +115,10 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
             vl[a] = v_old[n];
         }
         double PA[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q)
-            PA[q] = pg[tp + q * 64];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            cur.s11[i] = S.i11[ts + i * 64];
-            cur.s12[i] = S.i12[ts + i * 64];
-            cur.s22[i] = S.i22[ts + i * 64];
-        }
+        tile_load9(pg, tp, ix & 63, PA);
+        tile_load8(S.i11, ts, cur.s11);
+        tile_load8(S.i12, ts, cur.s12);
+        tile_load8(S.i22, ts, cur.s22);
         load_nodal(packed, nV, cur.c[0]);
         load_nodal(packed, nV + 1, cur.c[1]);
         load_nodal(packed, nV + nn, cur.c[2]);
@@ -150,12 +145,7 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         // the ice strength of the row is read again (an L2 hit: A streamed it in one step ago) rather than
         // carried: 18 registers per set that would push the kernel over the 512-register file
         double PB[9];
-        {
-            const long tpb = tile_off(ix, r, M.ntx, 9);
-#pragma unroll
-            for (int g = 0; g < 9; ++g)
-                PB[g] = pg[tpb + g * 64];
-        }
+        tile_load9(pg, tile_off(ix, r, M.ntx, 9), ix & 63, PB);
         double ul[9], vl[9];
         gather_nodes(M, prev.u, cur.u[0], cur.u[1], ul);
         gather_nodes(M, prev.v, cur.v[0], cur.v[1], vl);
@@ -202,9 +192,7 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         const long tp = tile_off(ix, q, M.ntx, 9);
         const long nV = (long)(2 * q) * nn + 2 * ix;
         double P[9], c[4][6];
-#pragma unroll
-        for (int g = 0; g < 9; ++g)
-            P[g] = pg[tp + g * 64];
+        tile_load9(pg, tp, ix & 63, P);
         load_nodal(packed, nV, c[0]);
         load_nodal(packed, nV + 1, c[1]);
         load_nodal(packed, nV + nn, c[2]);
@@ -218,12 +206,9 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         const bool store = M.own && q >= M.y0;
         if (store) {
             const long ts = tile_off(ix, q, M.ntx, 8);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                S.o11[ts + i * 64] = s11[i];
-                S.o12[ts + i * 64] = s12[i];
-                S.o22[ts + i * 64] = s22[i];
-            }
+            tile_store8(S.o11, ts, s11);
+            tile_store8(S.o12, ts, s12);
+            tile_store8(S.o22, ts, s22);
         }
         double cx[9], cy[9];
         NSDG_STAMP(9);
