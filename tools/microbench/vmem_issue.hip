@@ -45,6 +45,31 @@ __global__ __launch_bounds__(256) void k_load(const double* __restrict__ src, do
         cyc[wave] = t1 - t0;
 }
 
+// 16-byte loads with a 48-byte lane stride (the packed nodal coefficients: 6 doubles per node, node-major)
+__global__ __launch_bounds__(256) void k_load_strided(const double* __restrict__ src, double* out, long long* cyc, long stride_batch)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double* p = src + wave * (long)BATCH * NL * 64;
+    double acc = 0.;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int b = 0; b < BATCH; ++b) {
+        const double* q = p + (long)b * stride_batch;
+        double2 v[NL / 2];
+#pragma unroll
+        for (int i = 0; i < NL / 2; ++i) // 12 loads = 4 nodes x 3 pieces; lanes 48 B apart
+            v[i] = *reinterpret_cast<const double2*>(q + (i / 3) * 384 + lane * 6 + (i % 3) * 2);
+#pragma unroll
+        for (int i = 0; i < NL / 2; ++i)
+            acc += v[i].x + v[i].y;
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[(long)blockIdx.x * 256 + threadIdx.x] = acc;
+    if (lane == 0)
+        cyc[wave] = t1 - t0;
+}
+
 template <int WIDTH>
 __global__ __launch_bounds__(256) void k_store(double* dst, long long* cyc, long stride_batch)
 {
@@ -101,6 +126,8 @@ int main()
             report("global_load_dwordx2 (8 B/lane), 24 per batch", NL);
             hipLaunchKernelGGL(k_load<2>, dim3(blocks), dim3(256), 0, 0, src, out, cyc, st);
             report("global_load_dwordx4 (16 B/lane), 12 per batch", NL / 2);
+            hipLaunchKernelGGL(k_load_strided, dim3(blocks), dim3(256), 0, 0, src, out, cyc, st);
+            report("global_load_dwordx4, lanes 48 B apart, 12 per batch", NL / 2);
             hipLaunchKernelGGL(k_store<1>, dim3(blocks), dim3(256), 0, 0, src, cyc, st);
             report("global_store_dwordx2, 24 per batch", NL);
             hipLaunchKernelGGL(k_store<2>, dim3(blocks), dim3(256), 0, 0, src, cyc, st);
