@@ -257,8 +257,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the dynamics core has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("NSDG_FORCE_DIST"))  # NSDG_FORCE_DIST: rehearse the RCCL set-up with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nextsimdg_amd import build
@@ -305,7 +307,7 @@ def main():
     del H, A, uo, vo, ua, va
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -324,7 +326,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
     sub_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / nsub  # per sub-iteration, this rank
@@ -366,7 +368,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nsub)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

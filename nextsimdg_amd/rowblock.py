@@ -64,129 +64,134 @@ class RowBlock:
         return slice(2 * self.lo, 2 * self.hi + 1)
 
 
-class HaloExchanger:
-    """nearest-neighbour ghost-row exchange.  All slices are contiguous row blocks of their arrays (node
-    rows of [rows, cols] lattices, element rows of tiled [ny, ntx, nc, 64] arrays), so they are sent in
-    place; only coefficient-plane arrays [nc, ny, nx] need a pack/unpack copy."""
+class HaloPlan:
+    """what one ghost-row exchange moves: lists of tensor views (row blocks) per direction"""
 
-    def __init__(self, blk, group=None):
+    def __init__(self):
+        self.up_send, self.down_send, self.from_above, self.from_below = [], [], [], []
+        self.buffers = None  # transport-private (packed send / receive buffers)
+
+
+class HaloExchanger:
+    """nearest-neighbour ghost-row exchange.  Planning (which row blocks travel) is separate from transport:
+    subclasses that move the data differently (the in-process exchanger of tests/test_gpu_multiblock.py, the
+    no-op exchanger of tools/rank_share_timing.py) override _start / _finish only.
+
+    Transport: everything that travels to one neighbour is packed into ONE buffer (torch.cat) and sent with ONE
+    P2P op, so a batch has at most 2 sends + 2 receives whatever the number of fields -- the host cost of
+    torch.distributed P2P ops (about 13 us each on the GPU box; 20 ops per batch made the 8-block sub-cycle
+    host-bound) matters more than the extra device copy of a few MB."""
+
+    def __init__(self, blk, group=None, loopback=False):
         self.blk, self.group = blk, group
         self._cache = {}
+        # loopback (rehearsal on one GPU, tools/rank_share_timing.py --rccl-loopback): both neighbours are this
+        # rank itself, so a send upwards must meet the receive from below -- receives are posted in that order
+        self.loopback = loopback
 
-    @staticmethod
-    def finish(reqs):
-        for req in reqs:
-            req.wait()
+    # ------------------------------------------------------------------ planning
+    def _plan(self, key, build):
+        plan = self._cache.get(key)
+        if plan is None:
+            plan = self._cache[key] = HaloPlan()
+            if self.blk.world > 1:
+                build(plan)
+        return plan
 
-    def _post(self, key, build):
-        if self.blk.world == 1:
-            return []
-        ops = self._cache.get(key)
-        if ops is None:
-            ops = self._cache[key] = build()
-        return dist.batch_isend_irecv(ops) if ops else []
-
-    # -- CG2 nodal arrays [2ny+1, 2nx+1]
-    def _nodal_ops(self, fields, rows_down):
+    def _add_nodal(self, plan, fields, rows_down):
+        """CG2 nodal arrays [2ny+1, 2nx+1]: 2*depth_below node rows travel upwards, `rows_down` rows (1 for the
+        single-iteration kernel, 2*depth_above + 1 for the multi-iteration kernels) downwards"""
         b = self.blk
-        up = 2 * b.depth_below  # node rows the rank above keeps as ghosts below its first owned row
-        ops = []
+        up = 2 * b.depth_below
         for f in fields:
             if b.above is not None:
-                ops.append(dist.P2POp(dist.isend, f[2 * b.j1 - up:2 * b.j1], b.above, self.group))
-                ops.append(dist.P2POp(dist.irecv, f[2 * b.j1:2 * b.j1 + rows_down], b.above, self.group))
+                plan.up_send.append(f[2 * b.j1 - up:2 * b.j1])
+                plan.from_above.append(f[2 * b.j1:2 * b.j1 + rows_down])
             if b.below is not None:
-                ops.append(dist.P2POp(dist.isend, f[2 * b.j0:2 * b.j0 + rows_down], b.below, self.group))
-                ops.append(dist.P2POp(dist.irecv, f[2 * b.j0 - up:2 * b.j0], b.below, self.group))
-        return ops
+                plan.down_send.append(f[2 * b.j0:2 * b.j0 + rows_down])
+                plan.from_below.append(f[2 * b.j0 - up:2 * b.j0])
 
+    def _add_rows(self, plan, fields, rows_of):
+        """element-row arrays: depth_below rows travel upwards, depth_above rows downwards"""
+        b = self.blk
+        for f in fields:
+            if b.above is not None:
+                plan.up_send.append(rows_of(f, b.j1 - b.depth_below, b.j1))
+                if b.gt:
+                    plan.from_above.append(rows_of(f, b.j1, b.j1 + b.gt))
+            if b.below is not None:
+                if b.depth_above:
+                    plan.down_send.append(rows_of(f, b.j0, b.j0 + b.depth_above))
+                plan.from_below.append(rows_of(f, b.j0 - b.gb, b.j0))
+
+    # ------------------------------------------------------------------ transport
+    def _start(self, plan):
+        b = self.blk
+        if b.world == 1 or not (plan.up_send or plan.down_send or plan.from_above or plan.from_below):
+            return None
+        if plan.buffers is None:
+            size = lambda views: sum(v.numel() for v in views)
+            like = (plan.up_send or plan.down_send or plan.from_above or plan.from_below)[0]
+            new = lambda n: torch.empty(n, dtype=like.dtype, device=like.device) if n else None
+            plan.buffers = tuple(new(size(v)) for v in (plan.up_send, plan.down_send, plan.from_above, plan.from_below))
+        s_up, s_down, r_above, r_below = plan.buffers
+        ops = []
+        if s_up is not None:
+            torch.cat([v.reshape(-1) for v in plan.up_send], out=s_up)
+            ops.append(dist.P2POp(dist.isend, s_up, b.above, self.group))
+        if s_down is not None:
+            torch.cat([v.reshape(-1) for v in plan.down_send], out=s_down)
+            ops.append(dist.P2POp(dist.isend, s_down, b.below, self.group))
+        recv_above = dist.P2POp(dist.irecv, r_above, b.above, self.group) if r_above is not None else None
+        recv_below = dist.P2POp(dist.irecv, r_below, b.below, self.group) if r_below is not None else None
+        ops += [r for r in ((recv_below, recv_above) if self.loopback else (recv_above, recv_below)) if r is not None]
+        return dist.batch_isend_irecv(ops), plan
+
+    def _finish(self, handle):
+        if handle is None:
+            return
+        works, plan = handle
+        for w in works:
+            w.wait()
+        for views, buf in ((plan.from_above, plan.buffers[2]), (plan.from_below, plan.buffers[3])):
+            o = 0
+            for v in views:
+                n = v.numel()
+                v.copy_(buf[o:o + n].view(v.shape))
+                o += n
+
+    # ------------------------------------------------------------------ the exchanges of the driver
     def nodal_start(self, fields, rows_down=1):
-        """post the exchange of the ghost node rows: 2*depth_below rows travel upwards, `rows_down` rows
-        (1 for the single-iteration kernel, 2*depth_above + 1 for the two-iteration kernel) downwards"""
+        """post the exchange of the ghost node rows of `fields`"""
         key = ("n", rows_down) + tuple(f.data_ptr() for f in fields)
-        return self._post(key, lambda: self._nodal_ops(fields, rows_down))
+        return self._start(self._plan(key, lambda p: self._add_nodal(p, fields, rows_down)))
+
+    def finish(self, handle):
+        self._finish(handle)
 
     def nodal(self, fields, rows_down=1):
         self.finish(self.nodal_start(fields, rows_down))
 
-    # -- arrays private to the sub-cycle (stress): rows are taken with ops.private_rows(); for the tiled
-    #    device layout a row range is one contiguous block and travels in place
     def rows_exchange_start(self, fields, rows_of, nodal_fields=(), rows_down=1):
-        """post ONE batch with the ghost rows of the private arrays `fields` and (optionally) the ghost node
-        rows of `nodal_fields`: one RCCL group per pass instead of two"""
-        b = self.blk
-        if b.world == 1:
-            return [], []
+        """post ONE batch with the ghost rows of the private arrays `fields` (rows taken with ops.private_rows():
+        for the tiled device layout a row range is one contiguous block) and, optionally, the ghost node rows of
+        `nodal_fields`"""
         key = ("r", rows_down) + tuple(f.data_ptr() for f in fields) + tuple(f.data_ptr() for f in nodal_fields)
-        plan = self._cache.get(key)
-        if plan is None:
-            sends, recvs = [], []  # (view, peer)
-            for f in fields:
-                if b.above is not None:
-                    sends.append((rows_of(f, b.j1 - b.depth_below, b.j1), b.above))
-                    if b.gt:
-                        recvs.append((rows_of(f, b.j1, b.j1 + b.gt), b.above))
-                if b.below is not None:
-                    if b.depth_above:
-                        sends.append((rows_of(f, b.j0, b.j0 + b.depth_above), b.below))
-                    recvs.append((rows_of(f, b.j0 - b.gb, b.j0), b.below))
-            up = 2 * b.depth_below
-            for f in nodal_fields:
-                if b.above is not None:
-                    sends.append((f[2 * b.j1 - up:2 * b.j1], b.above))
-                    recvs.append((f[2 * b.j1:2 * b.j1 + rows_down], b.above))
-                if b.below is not None:
-                    sends.append((f[2 * b.j0:2 * b.j0 + rows_down], b.below))
-                    recvs.append((f[2 * b.j0 - up:2 * b.j0], b.below))
-            plan = self._cache[key] = (sends, recvs)
-        sends, recvs = plan
-        ops, unpack = [], []
-        for view, peer in sends:
-            ops.append(dist.P2POp(dist.isend, view if view.is_contiguous() else view.contiguous(), peer, self.group))
-        for view, peer in recvs:
-            if view.is_contiguous():
-                ops.append(dist.P2POp(dist.irecv, view, peer, self.group))
-            else:
-                buf = torch.empty(view.shape, dtype=view.dtype, device=view.device)
-                ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
-                unpack.append((view, buf))
-        # sends and recvs of a peer pair are matched in list order: fields in order, upward before downward,
-        # the same on both sides
-        return (dist.batch_isend_irecv(ops) if ops else []), unpack
 
-    @staticmethod
-    def rows_exchange_finish(reqs, unpack):
-        for req in reqs:
-            req.wait()
-        for view, buf in unpack:
-            view.copy_(buf)
+        def build(p):
+            self._add_rows(p, fields, rows_of)
+            self._add_nodal(p, nodal_fields, rows_down)
 
-    # -- coefficient planes [nc, ny, nx] (advected fields): pack, exchange, unpack
+        return self._start(self._plan(key, build)), ()
+
+    def rows_exchange_finish(self, handle, unused=()):
+        self._finish(handle)
+
     def element(self, fields):
         """refresh the ghost element rows of DG arrays [nc, ny, nx] (after a transport stage)"""
-        b = self.blk
-        if b.world == 1:
-            return
-        ops, unpack = [], []
-        for f in fields:
-            if b.above is not None:
-                sbuf = f[:, b.j1 - b.depth_below:b.j1, :].contiguous()
-                ops.append(dist.P2POp(dist.isend, sbuf, b.above, self.group))
-                if b.gt:
-                    rbuf = torch.empty_like(f[:, b.j1:b.j1 + b.gt, :].contiguous())
-                    ops.append(dist.P2POp(dist.irecv, rbuf, b.above, self.group))
-                    unpack.append((f, slice(b.j1, b.j1 + b.gt), rbuf))
-            if b.below is not None:
-                if b.depth_above:
-                    sbuf = f[:, b.j0:b.j0 + b.depth_above, :].contiguous()
-                    ops.append(dist.P2POp(dist.isend, sbuf, b.below, self.group))
-                rbuf = torch.empty_like(f[:, b.j0 - b.gb:b.j0, :].contiguous())
-                ops.append(dist.P2POp(dist.irecv, rbuf, b.below, self.group))
-                unpack.append((f, slice(b.j0 - b.gb, b.j0), rbuf))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        for f, rows, rbuf in unpack:
-            f[:, rows, :] = rbuf
+        key = ("e",) + tuple(f.data_ptr() for f in fields)
+        plan = self._plan(key, lambda p: self._add_rows(p, fields, lambda f, a, c: f[:, a:c, :]))
+        self._finish(self._start(plan))
 
 
 class DynamicsCore:

@@ -34,76 +34,29 @@ class Mailbox:
 
 
 class ThreadExchanger(rowblock.HaloExchanger):
-    """same slicing logic as HaloExchanger, transport = clone into a mailbox / copy out of it"""
+    """the planning of HaloExchanger (which row blocks travel) with an in-process transport: the views sent to
+    a neighbour are cloned into a mailbox, the receiver copies them out in the same order"""
 
     def __init__(self, blk, mailbox):
         super().__init__(blk)
         self.mb = mailbox
 
-    def _exchange(self, sends, recvs):
-        for view, peer in sends:
-            self.mb.put((self.blk.rank, peer), view.clone())
-        return recvs
-
-    def _complete(self, recvs):
-        for view, peer in recvs:
-            view.copy_(self.mb.get((peer, self.blk.rank)))
-
-    # nodal arrays
-    def nodal_start(self, fields, rows_down=1):
+    def _start(self, plan):
         b = self.blk
         if b.world == 1:
-            return []
-        up = 2 * b.depth_below
-        sends, recvs = [], []
-        for f in fields:
-            if b.above is not None:
-                sends.append((f[2 * b.j1 - up:2 * b.j1], b.above))
-                recvs.append((f[2 * b.j1:2 * b.j1 + rows_down], b.above))
-            if b.below is not None:
-                sends.append((f[2 * b.j0:2 * b.j0 + rows_down], b.below))
-                recvs.append((f[2 * b.j0 - up:2 * b.j0], b.below))
-        return [self._exchange(sends, recvs)]
+            return None
+        for views, peer in ((plan.up_send, b.above), (plan.down_send, b.below)):
+            for v in views:
+                self.mb.put((b.rank, peer), v.clone())
+        return plan
 
-    def finish(self, reqs):
-        for recvs in reqs:
-            self._complete(recvs)
-
-    def rows_exchange_start(self, fields, rows_of, nodal_fields=(), rows_down=1):
-        b = self.blk
-        if b.world == 1:
-            return [], []
-        sends, recvs = [], []
-        for f in fields:
-            if b.above is not None:
-                sends.append((rows_of(f, b.j1 - b.depth_below, b.j1), b.above))
-                if b.gt:
-                    recvs.append((rows_of(f, b.j1, b.j1 + b.gt), b.above))
-            if b.below is not None:
-                if b.depth_above:
-                    sends.append((rows_of(f, b.j0, b.j0 + b.depth_above), b.below))
-                recvs.append((rows_of(f, b.j0 - b.gb, b.j0), b.below))
-        pending = [self._exchange(sends, recvs)] + (self.nodal_start(nodal_fields, rows_down) if nodal_fields else [])
-        return pending, []
-
-    def rows_exchange_finish(self, reqs, unpack):
-        self.finish(reqs)
-
-    def element(self, fields):
-        b = self.blk
-        if b.world == 1:
+    def _finish(self, plan):
+        if plan is None:
             return
-        sends, recvs = [], []
-        for f in fields:
-            if b.above is not None:
-                sends.append((f[:, b.j1 - b.depth_below:b.j1, :], b.above))
-                if b.gt:
-                    recvs.append((f[:, b.j1:b.j1 + b.gt, :], b.above))
-            if b.below is not None:
-                if b.depth_above:
-                    sends.append((f[:, b.j0:b.j0 + b.depth_above, :], b.below))
-                recvs.append((f[:, b.j0 - b.gb:b.j0, :], b.below))
-        self._complete(self._exchange(sends, recvs))
+        b = self.blk
+        for views, peer in ((plan.from_above, b.above), (plan.from_below, b.below)):
+            for v in views:
+                v.copy_(self.mb.get((peer, b.rank)))
 
 
 def fields(nx, ny):

@@ -14,17 +14,14 @@ from nextsimdg_amd import abi, rowblock, synthetic
 
 
 class NullExchanger(rowblock.HaloExchanger):
-    def _post(self, key, build):
-        return []
+    def _start(self, plan):
+        return None
 
-    def rows_exchange_start(self, fields, rows_of, nodal_fields=(), rows_down=1):
-        return [], []
-
-    def element(self, fields):
+    def _finish(self, handle):
         return
 
 
-def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3, overlap=True):
+def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3, overlap=True, loopback=False):
     dev = torch.device("cuda:0")
     ctx = abi.Context(dev)
     L, dt = 512e3, 120.0
@@ -35,7 +32,15 @@ def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3, overlap=True):
     v = min(ctx.mevp_variant, 3)  # sub-iterations per kernel pass
     depth = (v * kpass, v * kpass - 1)
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
-    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=NullExchanger(blk) if world > 1 else None, overlap=overlap)
+    exchanger = None
+    if world > 1 and loopback:  # real RCCL send/recv, both neighbours = this rank (periodic wrap: values meaningless)
+        if blk.below is None or blk.above is None:
+            raise SystemExit("--rccl-loopback needs a block with two neighbours (world >= 3)")
+        blk.below = blk.above = 0
+        exchanger = rowblock.HaloExchanger(blk, loopback=True)
+    elif world > 1:
+        exchanger = NullExchanger(blk)
+    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=exchanger, overlap=overlap)
     H, A = bt.dg_fields()
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
@@ -53,7 +58,16 @@ def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3, overlap=True):
 if __name__ == "__main__":
     ks = (1, 4)
     args = sys.argv[1:]
-    overlap = True
+    overlap, loopback = True, False
+    if args and args[0] == "--rccl-loopback":  # exchanges are real RCCL send/recv to self (one rank on one GPU)
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29551")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        loopback = True
+        args = args[1:]
     if args and args[0] == "--no-overlap":  # one launch per pass, the exchange would follow it un-overlapped
         overlap = False
         args = args[1:]
@@ -64,7 +78,12 @@ if __name__ == "__main__":
     base = None
     for w in worlds:
         for k in ((1,) if w == 1 else ks):
-            ms, host_ms, rows = run(w, k, overlap=overlap)
+            ms, host_ms, rows = run(w, k, overlap=overlap, loopback=loopback)
             base = ms if w == 1 else base
-            print(("" if overlap else "no-overlap  ") + "world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
+            print(("RCCL loopback  " if loopback else "") + ("" if overlap else "no-overlap  ") + "world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
                   % (w, k, rows, ms, host_ms, "%.2f" % (base / ms) if base else "-"), flush=True)
+    if loopback:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
