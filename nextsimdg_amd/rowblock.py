@@ -20,8 +20,8 @@ send/recv of ghost rows through torch.distributed (backend "nccl" = RCCL over xG
                            >= 3: once per step, the first two stages advance ghost rows redundantly)
 
 Ownership of CG2 nodes is bottom-left: rank r owns node rows [2*r0, 2*r1); the global top node row is a
-Dirichlet boundary.  Node rows of a [rows, cols] array are contiguous, so velocity halos are sent
-straight out of / received straight into the field arrays without packing.
+Dirichlet boundary.  Everything that travels to one neighbour in one exchange (row blocks of several
+arrays) is packed into one buffer and sent with one P2P op (HaloExchanger).
 
 The numerical kernels are reached through an `ops` object with the method names of
 nextsimdg_amd.abi.Context (the C-ABI binding).  Nothing here computes on the host.
