@@ -154,11 +154,14 @@ class HaloExchanger:
         for w in works:
             w.wait()
         for views, buf in ((plan.from_above, plan.buffers[2]), (plan.from_below, plan.buffers[3])):
-            o = 0
-            for v in views:
-                n = v.numel()
-                v.copy_(buf[o:o + n].view(v.shape))
-                o += n
+            if not views:
+                continue
+            chunks = buf.split([v.numel() for v in views])
+            if all(v.is_contiguous() for v in views):  # one multi-tensor launch
+                torch._foreach_copy_([v.view(-1) for v in views], list(chunks))
+            else:
+                for v, c in zip(views, chunks):
+                    v.copy_(c.view(v.shape))
 
     # ------------------------------------------------------------------ the exchanges of the driver
     def nodal_start(self, fields, rows_down=1):
