@@ -34,13 +34,35 @@ BYTES_PER_ELEM_SUBITER = 896  # SURVEY.md section 8(d), mEVP sub-iteration
 BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
 
 
+def host_cores():
+    """usable host cores: the scheduler affinity, capped by the cgroup CPU quota of the box (a one-GPU box
+    shows all hardware threads but grants a share of them; oversubscribing that share with one OpenMP thread
+    per visible CPU made the all-cores baseline 3x instead of 10x the single-thread figure)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(nsub_full, budget_s=12.0):
     """Time the CPU oracle (tests' checker; here only as the reported baseline) on a bounded sample
     of the same workload: a 192 x 192 box test, a few mEVP sub-iterations and one transport step,
     single thread (the reference itself is single-threaded), then extrapolate
     per element: t_step = nsub * t_subiter + t_transport."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1))
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
     import oracle_lib as O
 
     n = 192
@@ -87,7 +109,7 @@ def cpu_baseline(nsub_full, budget_s=12.0):
             O.transport_step(n, n, bt.hx, bt.hy, 2, 120.0, f, adv, omp=omp)
         t_tr = (time.perf_counter() - t0) / (n * n)
         out[omp] = (1.0 / (nsub_full * t_sub + t_tr), 1.0 / t_sub, k)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = int(os.environ["OMP_NUM_THREADS"])
     res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port",
            "sample": "oracle/dyn_oracle.c on a 192x192 box test: %d mEVP sub-iterations + 1 DG2 RK3 transport step of H and A, "
                      "per-element costs extrapolated to %d sub-iterations/step; own CPU restatement -- the reference snapshot "
@@ -143,8 +165,8 @@ def column_bench(args, device):
         O.column_step(O.column_params(), 600.0, st, fo, ni)
         reps += 1
     cpu = reps * m / (time.perf_counter() - c0)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
+    cores = int(os.environ["OMP_NUM_THREADS"])
     big = 1 << 24  # large enough for every host core to have work
     st, fo, ni = synthetic.column_fields(big)
     O.column_step(O.column_params(), 600.0, st, fo, ni, omp=True)
