@@ -496,7 +496,7 @@ int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const d
         nsdg_set_error("nsdg_mevp_iterate: nsdg_mevp_pack_nodal was not called on this context");
         return NSDG_ERR_STATE;
     }
-    if (ctx->mevp_variant >= 1) // variant 2 falls back on the single-iteration fused kernel for one sub-iteration
+    if (ctx->mevp_variant >= 1) // variants 2 and 3 use the single-iteration fused kernel for one sub-iteration
         return nsdg_launch_mevp_fused(ctx, k0, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     int rc = launch_stress(ctx, k0, j1, u_old, v_old, pg, s11i, s12i, s22i, s11, s12, s22);
     if (rc)

@@ -296,7 +296,7 @@ class DynamicsCore:
             calls = self._iterate_calls(split)
             if not split:
                 calls[0]()
-                if self.two_per_pass:  # keep the deeper ghost zones of the two-iteration passes consistent
+                if self.two_per_pass:  # keep the deeper ghost zones (stress as well as velocity) of the multi-iteration passes consistent
                     self._ghost_exchange_finish(self._ghost_exchange_start())
                 else:
                     self.halo.nodal(uvn)
