@@ -317,11 +317,13 @@ def main():
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
     coupled = args.workload == "coupled"
     core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device)
-    if coupled:  # seeded thermodynamic forcing of SURVEY.md section 8(d), held constant in time; calm wind over most of the box
-        cs, cf, _ = synthetic.column_fields(nx * ny)
-        col = {k: v.reshape(ny, nx) for k, v in {**cs, **cf}.items() if k not in ("hice", "cice")}
-        core.load_column(col)
-        del cs, cf, col
+    if coupled:
+        # thermodynamic forcing held constant in time: smooth analytic fields in the ranges of SURVEY.md section 8(d)
+        # with the mixed layer at the freezing point (synthetic.column_fields_smooth explains why not the per-element
+        # random fields of the column-kernel bench: those blow the coupled model up within ~10 steps)
+        cs, cf = synthetic.column_fields_smooth(nx, ny, L)
+        core.load_column({**cs, **cf})
+        del cs, cf
     H, A = bt.dg_fields()
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)

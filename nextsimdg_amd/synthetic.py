@@ -26,6 +26,27 @@ def column_fields(n, seed=COLUMN_SEED):
     return state, forcing, np.zeros(n)
 
 
+def column_fields_smooth(nx, ny, L=512e3):
+    """Thermodynamic state (hsnow, tice0) and forcing for the COUPLED runs (BASELINE config 5): the same variables
+    and ranges as column_fields(), but smooth analytic functions of position instead of independent random numbers
+    per element -- element-wise noise in the forcing makes the thermodynamics write grid-scale noise into H and A,
+    which the dynamics then (rightly) cannot digest: the coupled model blows up within ~10 steps.  Winter
+    conditions: cold air, little short-wave.  Returns dicts of [ny, nx] arrays."""
+    x = (np.arange(nx) + 0.5)[None, :] / nx
+    y = (np.arange(ny) + 0.5)[:, None] / ny
+    s1, c1 = np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y), np.cos(2 * np.pi * x) * np.sin(np.pi * y)
+    one = np.ones((ny, nx))
+    tair = -15.0 + 8.0 * s1
+    state = dict(hsnow=0.05 * one + 0.03 * c1, tice0=-10.0 + 4.0 * s1)
+    sss = 32.0 + 1.5 * s1
+    # the mixed layer sits AT the freezing point (linear law, -0.055 S): the reference never updates sst
+    # (SURVEY App. A.7 quirk 4), so any excess over T_f is an inexhaustible heat source that melts ~2 cm per step
+    forcing = dict(sst=-0.055 * sss, sss=sss, tair=tair, tdew=tair - 2.0 - 1.0 * c1, slp=1.0e5 + 2.0e3 * c1,
+                   qsw=40.0 + 30.0 * s1, qlw=230.0 + 40.0 * c1, mld=25.0 + 10.0 * s1, snowfall=2.0e-5 * (1.0 + c1),
+                   wind=6.0 + 4.0 * s1)
+    return state, {k: np.ascontiguousarray(v * one) for k, v in forcing.items()}
+
+
 class BoxTest:
     """Square box of side L (default 512 km), closed boundaries (v = 0).  Fields follow the usual
     VP/mEVP benchmark set-up: H0 = 0.3 + 0.005 (sin(6e-5 x) + sin(3e-5 y)), A0 = 1, circular ocean

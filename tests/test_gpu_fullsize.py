@@ -151,3 +151,33 @@ def test_config2_convergence_rate_one_revolution(ctx):
     rates = [np.log2(errs[i] / errs[i + 1]) for i in range(2)]
     assert errs[2] < errs[1] < errs[0]
     assert rates[1] > 1.7, (errs, rates)
+
+
+def test_config5_coupled_run_stays_physical(ctx):
+    """BASELINE config 5 in small: column thermodynamics + dynamics for 240 model steps (8 hours) with the smooth
+    winter forcing of synthetic.column_fields_smooth.  The fields must stay finite and physical: drift of a few
+    cm/s, thickness and concentration inside their initial ranges plus slow thermodynamic growth.  (With the
+    per-element random forcing of the column-kernel tests, or with a mixed layer above freezing -- which the
+    reference never cools, SURVEY App. A.7 quirk 4 -- the same model melts / blows up within ~10 steps.)"""
+    nx = ny = 256
+    L, dt = 512e3, 120.0
+    bt = synthetic.BoxTest(nx, ny, L)
+    alpha = bt.stable_alpha(dt)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
+    ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+    core = rowblock.CoupledCore(ctx, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, 120, torch.device("cuda"))
+    cs, cf = synthetic.column_fields_smooth(nx, ny, L)
+    core.load_column({**cs, **cf})
+    H, A = bt.dg_fields()
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    core.load_global(H, A, uo, vo, ua, va)
+    for _ in range(240):
+        core.step()
+    for f in (core.u, core.v, core.H, core.A, core.col["tice0"], core.col["hsnow"]):
+        assert bool(torch.isfinite(f).all())
+    assert 1e-3 < float(core.u.abs().max()) < 0.5
+    assert 0.25 < float(core.H[0].min()) and float(core.H[0].max()) < 0.45
+    assert 0.9 < float(core.A[0].min()) and float(core.A[0].max()) < 1.01  # convergent drift piles concentration up slightly above 1
+    assert -40.0 < float(core.col["tice0"].min()) and float(core.col["tice0"].max()) <= 0.0
+    ctx.set_mevp_params(ctx.mevp_default_params())
