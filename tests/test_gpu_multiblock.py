@@ -146,3 +146,23 @@ def test_overlap_split_does_not_change_results(gpu):
     for r in range(3):
         for k in a[r]:
             assert torch.equal(a[r][k], b[r][k])
+
+
+def test_rccl_rehearsals_on_one_gpu(gpu):
+    """what can be exercised of the RCCL path with one device: batched ncclSend / ncclRecv to self of the row-block
+    views the driver exchanges (tools/rccl_p2p_selftest.py), and the whole multi-rank driver of an interior block
+    with both neighbours mapped to the rank itself, every exchange a real RCCL batch
+    (tools/rank_share_timing.py --rccl-loopback; timing only, the wrapped values are meaningless)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_p2p_selftest.py")], env=dict(env, MASTER_PORT="29561"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"row-block views: ok" in p.stdout, p.stdout.decode()[-2000:]
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rank_share_timing.py"), "--rccl-loopback", "--k", "2", "8"],
+                       env=dict(env, MASTER_PORT="29562", NSDG_SHARE_GRID="512", NSDG_SHARE_NSUB="12"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0 and b"RCCL loopback  world 8" in p.stdout, p.stdout.decode()[-2000:]

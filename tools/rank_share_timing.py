@@ -21,7 +21,11 @@ class NullExchanger(rowblock.HaloExchanger):
         return
 
 
-def run(world, kpass, nx=2048, ny=2048, nsub=120, steps=3, overlap=True, loopback=False):
+GRID = int(os.environ.get("NSDG_SHARE_GRID", "2048"))  # smaller grid / fewer sub-iterations for the smoke test
+NSUB = int(os.environ.get("NSDG_SHARE_NSUB", "120"))
+
+
+def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopback=False):
     dev = torch.device("cuda:0")
     ctx = abi.Context(dev)
     L, dt = 512e3, 120.0
