@@ -140,7 +140,8 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
  * kernel that performs two sub-iterations per pass (nsdg_mevp_iterate2 / nsdg_mevp_subcycle on a whole
  * local array; single sub-iterations and row-range calls use the variant-1 kernel), 3 = three
  * sub-iterations per pass (nsdg_mevp_iterate3 / nsdg_mevp_subcycle; remainders of 2 or 1 sub-iterations use
- * the kernels of variants 2 and 1).  Variants 1, 2 and 3 agree bit for bit, variant 0 to fp64 round-off. */
+ * the kernels of variants 2 and 1); 3 is the default of a new context.  Variants 1, 2 and 3 agree bit for bit,
+ * variant 0 to fp64 round-off. */
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
 
 /* CG2 velocity -> DG(order) velocity and edge-normal velocities used by the transport */
@@ -216,7 +217,8 @@ int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const d
  * j0-2 .. j1 (node rows 2(j0-2) .. 2*j1+2) and writes S_out = S^{p+2} on rows [j0, j1) and u_new = u^{p+2} on
  * the nodes they own; the intermediate stress and velocity never leave the registers.  j0 == 0 (physical
  * boundary) or j0 >= 2 (two ghost rows below); above, one ghost row or the physical boundary (j1 == ny).
- * A multi-rank driver refreshes the ghost rows of S_out and u_new after every pass.  Requires variant 2. */
+ * A multi-rank driver refreshes the ghost rows of S_out and u_new after every pass (or runs k passes on row ranges
+ * shrinking by 2 rows per side and pass on a (2k, 2k-1)-row ghost zone).  Requires variant 2 or 3. */
 int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
     const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
     double* u_new, double* v_new, const double* packed, const double* pg);
