@@ -208,20 +208,60 @@ __global__ __launch_bounds__(256) void mevp_pack_nodal_kernel(nsdg_mevp_params P
     pack_node(P, dt, u0[n], v0[n], tax[n], tay[n], uo[n], vo[n], cgh[n], cga[n], packed + n * NODAL_STRIDE);
 }
 
+// node_average() on a tile of DG coefficients staged in LDS: tile[c][iy - ey0][ix - ex0]; same loops, same order of
+// summation, so the result is bit-identical to the global-memory form
+constexpr int PREP_TW = 33, PREP_TH = 3; // element columns / rows under a 64 x 4 block of nodes
+__device__ __forceinline__ double node_average_tile(int nx, int ny, const double (*tile)[PREP_TH][PREP_TW], int ex0, int ey0, int gx, int gy)
+{
+    const int ix_hi = gx / 2, ix_lo = (gx % 2 == 0) ? gx / 2 - 1 : gx / 2;
+    const int iy_hi = gy / 2, iy_lo = (gy % 2 == 0) ? gy / 2 - 1 : gy / 2;
+    double s = 0.;
+    int cnt = 0;
+    for (int iy = iy_lo; iy <= iy_hi; ++iy)
+        for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+            if (ix < 0 || ix >= nx || iy < 0 || iy >= ny)
+                continue;
+            const double x = -0.5 + 0.5 * (gx - 2 * ix), y = -0.5 + 0.5 * (gy - 2 * iy);
+            double val = 0.;
+            for (int c = 0; c < 6; ++c)
+                val += tile[c][iy - ey0][ix - ex0] * psi_rt(c, x, y);
+            s += val;
+            ++cnt;
+        }
+    return s / cnt;
+}
+
 // All per-step nodal preparation of the momentum equation in one pass over the CG2 lattice: nodal means of
-// H and A (dg_to_cg), wind stress, coefficient packing -- without materialising cgH, cgA, tau_a.
+// H and A (dg_to_cg), wind stress, coefficient packing -- without materialising cgH, cgA, tau_a.  A workgroup
+// handles 64 x 4 nodes; the DG coefficients of the 33 x 3 elements under them are staged in LDS once (9.5 KB)
+// instead of being gathered by every node lane from memory (a vertex node reads 4 elements x 6 coefficients x 2
+// fields: the gather form issued ~57 loads per lane and was bound by vector-memory issue, 0.67 ms at 2048^2).
 __global__ __launch_bounds__(256) void mevp_prepare_kernel(nsdg_mevp_params P, int nx, int ny, double dt,
     const double* __restrict__ H, const double* __restrict__ A, const double* __restrict__ ua, const double* __restrict__ va,
     const double* __restrict__ uo, const double* __restrict__ vo, const double* __restrict__ u0, const double* __restrict__ v0,
     double* __restrict__ packed)
 {
-    const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int gy = blockIdx.y * 4 + threadIdx.y;
+    __shared__ double tile[2][6][PREP_TH][PREP_TW];
+    const int gx0 = blockIdx.x * 64, gy0 = blockIdx.y * 4;
+    const int ex0 = gx0 / 2 - 1, ey0 = gy0 / 2 - 1;
+    const long N = (long)nx * ny;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int k = tid; k < 2 * 6 * PREP_TH * PREP_TW; k += 256) {
+        const int col = k % PREP_TW, r = (k / PREP_TW) % PREP_TH, c = (k / (PREP_TW * PREP_TH)) % 6, fld = k / (PREP_TW * PREP_TH * 6);
+        const int ix = ex0 + col, iy = ey0 + r;
+        double val = 0.;
+        if (ix >= 0 && ix < nx && iy >= 0 && iy < ny)
+            val = (fld == 0 ? H : A)[c * N + (long)iy * nx + ix];
+        tile[fld][c][r][col] = val;
+    }
+    __syncthreads();
+    const int gx = gx0 + threadIdx.x;
+    const int gy = gy0 + threadIdx.y;
     const int nn = 2 * nx + 1, nm = 2 * ny + 1;
     if (gx >= nn || gy >= nm)
         return;
     const long n = (long)gy * nn + gx;
-    const double cgh = node_average(nx, ny, 6, H, gx, gy), cga = node_average(nx, ny, 6, A, gx, gy);
+    const double cgh = node_average_tile(nx, ny, tile[0], ex0, ey0, gx, gy), cga = node_average_tile(nx, ny, tile[1], ex0, ey0, gx, gy);
     double tax, tay;
     wind_tau(P.c_atm * P.rho_atm, ua[n], va[n], tax, tay);
     pack_node(P, dt, u0[n], v0[n], tax, tay, uo[n], vo[n], cgh, cga, packed + n * NODAL_STRIDE);
