@@ -82,6 +82,18 @@ __device__ __forceinline__ void tile_store9(double* __restrict__ a, long t, int 
     a[t + 512 - l] = c[8];
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs of the chip, each with its own L2.  The three-iteration kernel
+// gives every XCD a CONTIGUOUS range of (strip, column-wave) indices, so that the waves that share halo columns and
+// strip-boundary rows -- neighbours in that index -- read them through the same L2 (34.0-35.2 -> 33.0-33.3 ms per
+// model step, A/B on one box).  The same mapping is neutral for the two-iteration kernel and 3-6 % slower for
+// the single-iteration one, which streams at the HBM ceiling: those keep the round-robin order.  Bijective for
+// any grid size.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nblocks)
+{
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = b & 7;
+    return xcd * q + min(xcd, r) + (b >> 3);
+}
+
 #define FMA_TAB(acc, tab, val)   \
     do {                         \
         const double t_ = (tab); \

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, 
 {
     __shared__ double park[2 * PARK_SLOT]; // 32 KB: the B -> C hand-over of this wave
     const int lane = threadIdx.x;
-    const int wave = blockIdx.x;
+    const int wave = xcd_contiguous_block(blockIdx.x, gridDim.x); // one wave per workgroup
     const int strip = wave / ncw, cw = wave - strip * ncw;
     MarchConst3 M;
     M.y0 = j0 + strip * R;
