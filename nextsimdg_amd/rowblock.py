@@ -70,6 +70,7 @@ class HaloPlan:
     def __init__(self):
         self.up_send, self.down_send, self.from_above, self.from_below = [], [], [], []
         self.buffers = None  # transport-private (packed send / receive buffers)
+        self.ops = self.flat_up = self.flat_down = None  # transport-private (P2P ops and flattened views, built once)
 
 
 class HaloExchanger:
@@ -134,18 +135,25 @@ class HaloExchanger:
             like = (plan.up_send or plan.down_send or plan.from_above or plan.from_below)[0]
             new = lambda n: torch.empty(n, dtype=like.dtype, device=like.device) if n else None
             plan.buffers = tuple(new(size(v)) for v in (plan.up_send, plan.down_send, plan.from_above, plan.from_below))
-        s_up, s_down, r_above, r_below = plan.buffers
-        ops = []
+            # the P2P ops and the flattened source views are built once per plan
+            s_up, s_down, r_above, r_below = plan.buffers
+            ops = []
+            if s_up is not None:
+                ops.append(dist.P2POp(dist.isend, s_up, b.above, self.group))
+            if s_down is not None:
+                ops.append(dist.P2POp(dist.isend, s_down, b.below, self.group))
+            recv_above = dist.P2POp(dist.irecv, r_above, b.above, self.group) if r_above is not None else None
+            recv_below = dist.P2POp(dist.irecv, r_below, b.below, self.group) if r_below is not None else None
+            ops += [r for r in ((recv_below, recv_above) if self.loopback else (recv_above, recv_below)) if r is not None]
+            plan.ops = ops
+            plan.flat_up = [v.reshape(-1) for v in plan.up_send] if all(v.is_contiguous() for v in plan.up_send) else None
+            plan.flat_down = [v.reshape(-1) for v in plan.down_send] if all(v.is_contiguous() for v in plan.down_send) else None
+        s_up, s_down = plan.buffers[0], plan.buffers[1]
         if s_up is not None:
-            torch.cat([v.reshape(-1) for v in plan.up_send], out=s_up)
-            ops.append(dist.P2POp(dist.isend, s_up, b.above, self.group))
+            torch.cat(plan.flat_up if plan.flat_up is not None else [v.reshape(-1) for v in plan.up_send], out=s_up)
         if s_down is not None:
-            torch.cat([v.reshape(-1) for v in plan.down_send], out=s_down)
-            ops.append(dist.P2POp(dist.isend, s_down, b.below, self.group))
-        recv_above = dist.P2POp(dist.irecv, r_above, b.above, self.group) if r_above is not None else None
-        recv_below = dist.P2POp(dist.irecv, r_below, b.below, self.group) if r_below is not None else None
-        ops += [r for r in ((recv_below, recv_above) if self.loopback else (recv_above, recv_below)) if r is not None]
-        return dist.batch_isend_irecv(ops), plan
+            torch.cat(plan.flat_down if plan.flat_down is not None else [v.reshape(-1) for v in plan.down_send], out=s_down)
+        return dist.batch_isend_irecv(plan.ops), plan
 
     def _finish(self, handle):
         if handle is None:
