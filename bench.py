@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- element-steps/s of the dynamics core (mEVP sub-cycle + DG2 transport) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Either the caller starts them (`python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N`, RANK / LOCAL_RANK / WORLD_SIZE in the environment) or bench.py starts them itself: the
+plain command above, run without WORLD_SIZE, spawns torch.distributed.run as a child BEFORE anything touches a
+GPU, passes rank 0's JSON line through and exits with the children's status.
 
 Workload (BASELINE.json metric "element-steps/sec (dynamics+transport)"; the >=40 % HBM-roofline
 target is stated on the DG2 mEVP inner loop at 2048x2048): 2048 x 2048 elements, DG2 advected H and A,
@@ -10,9 +15,11 @@ step, fp64, synthetic 512 km box test.  One "step" = one model time step of the 
 "element-step" is everything done to one element in it.  With N GPUs the SAME grid
 is split into N row blocks (strong scaling) with ghost-row send/recv over RCCL.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel:
-the mEVP sub-iteration; algorithmic 896 B per element-sub-iteration, HIP-event timed in this run)
-and `cpu_baseline` (the CPU oracle = this repo's own restatement, "port", timed on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel: one pass
+of the fused mEVP kernel, HIP-event timed in this run; `frac` is bounded by 1: the kernel's own compulsory
+bytes per pass against 8 TB/s -- the unfused accounting of SURVEY.md section 8(d), 896 B per element and
+sub-iteration, is reported beside it as `survey_8d` and is NOT a roofline fraction) and `cpu_baseline` (the CPU
+oracle = this repo's own restatement, "port", timed on a bounded sample and extrapolated per element).
 """
 import argparse
 import json
@@ -30,7 +37,9 @@ sys.path.insert(0, ROOT)
 from nextsimdg_amd import abi, rowblock, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-BYTES_PER_ELEM_SUBITER = 896  # SURVEY.md section 8(d), mEVP sub-iteration
+BYTES_PER_ELEM_SUBITER = 896  # byte model of ONE mEVP sub-iteration per HBM round trip
+BYTES_COMPULSORY_PER_PASS = 776  # what a pass of a fused kernel must move per element whatever it computes on chip
+SHADER_CLOCK_PEAK_HZ = 2.4e9  # MI355X_MICROARCH.md: peak engine clock
 BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
 
 
@@ -110,24 +119,42 @@ def cpu_baseline(nsub_full, budget_s=12.0):
         t_tr = (time.perf_counter() - t0) / (n * n)
         out[omp] = (1.0 / (nsub_full * t_sub + t_tr), 1.0 / t_sub, k)
     cores = int(os.environ["OMP_NUM_THREADS"])
-    res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port",
-           "sample": "oracle/dyn_oracle.c on a 192x192 box test: %d mEVP sub-iterations + 1 DG2 RK3 transport step of H and A, "
-                     "per-element costs extrapolated to %d sub-iterations/step; own CPU restatement -- the reference snapshot "
-                     "has no dynamics code to time" % (out[False][2], nsub_full),
+    res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port", "extrapolated": True,
+           "sample": "EXTRAPOLATED, not the 2048x2048 workload itself: oracle/dyn_oracle.c on a 192x192 box test, %d mEVP sub-iterations + "
+                     "1 DG2 RK3 transport step of H and A, per-element costs scaled to %d sub-iterations/step; own CPU restatement -- "
+                     "the reference snapshot has no dynamics code to time" % (out[False][2], nsub_full),
            "subiters_per_s": out[False][1]}
     if True in out:
         res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1], "sample": "OpenMP build, 768x768 box test"}
     return res
 
 
-def measured_traffic(nx, ny, key="mevp_fused_kernel"):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/): bench.py
-    cannot run rocprofv3 on itself, so the figure is the one measured with the same command under the
-    profiler (FETCH_SIZE doubled as the gfx950 correction requires, WRITE_SIZE as is)."""
+KERNEL_SOURCES = ("mevp_fused3.hip", "mevp_fused2.hip", "mevp_fused.hip", "mevp_common.h", "transport.hip")
+
+
+def kernel_source_hash():
+    """identifies the kernel sources an offline profile belongs to"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "nextsimdg_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def offline_counters(nx, ny, kernel):
+    """Counter figures of the dominant kernel from the committed rocprofv3 --pmc passes (bench.py cannot run the
+    profiler on itself, so these are OFFLINE numbers of the same command, labelled as such): HBM-side bytes per
+    launch (FETCH_SIZE doubled as the gfx950 correction requires, WRITE_SIZE as is) and VALU wave-instructions
+    per launch.  `stale` tells whether the kernel sources changed since the profile was taken."""
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")))
-        if d.get("nx") == nx and d.get("ny") == ny:
-            return d["kernels"][key]["total_bytes"]
+        if d.get("nx") == nx and d.get("ny") == ny and kernel in d["kernels"]:
+            k = d["kernels"][kernel]
+            return {"traffic": k["total_bytes"], "valu_insts": k.get("valu_wave_insts"),
+                    "source": "profiles/%s (offline rocprofv3 --pmc passes of this command, %s)" % (
+                        d.get("file", "hbm_traffic_latest.json"), d.get("config", "")),
+                    "stale": d.get("kernel_source_hash") != kernel_source_hash()}
     except Exception:
         pass
     return None
@@ -266,15 +293,20 @@ def main():
     ap.add_argument("--passes-per-exchange", type=int, default=6,
                     help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--halo", choices=["native", "torch"], default="native",
+                    help="N > 1: ghost-row exchange through the C ABI (nsdg_halo_*, RCCL calls and pack kernels in libnsdg.so) or through torch.distributed P2P ops")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (gloo): launch, rendezvous, planning; no metric")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the dynamics core has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -310,13 +342,12 @@ def main():
     bt = synthetic.BoxTest(nx, ny, L)
     alpha = bt.stable_alpha(dt)  # alpha = beta from the linear-stability bound of the sub-cycle on this mesh
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
-    # ghost element rows below / above: (v k, v k - 1) for k passes of v sub-iterations between two exchanges
-    kpass = max(1, min(args.passes_per_exchange, (ny // world) // 16)) if world > 1 else 1
-    vpass = min(ctx.mevp_variant, 3)
-    depth = (vpass * kpass, vpass * kpass - 1) if vpass >= 2 else (1, 1)
-    blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
+    blk, depth = plan_blocks(ctx.mevp_variant, args.passes_per_exchange, nx, ny, rank, world)
     coupled = args.workload == "coupled"
-    core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device)
+    exchanger = None
+    if world > 1 or os.environ.get("NSDG_FORCE_DIST"):
+        exchanger = make_exchanger(args.halo, ctx, blk, device)
+    core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device, exchanger=exchanger)
     if coupled:
         # thermodynamic forcing held constant in time: smooth analytic fields in the ranges of SURVEY.md section 8(d)
         # with the mixed layer at the freezing point (synthetic.column_fields_smooth explains why not the per-element
@@ -338,13 +369,17 @@ def main():
     for _ in range(args.warmup):
         core.step()
     sync()
-    # dominant-kernel timing: HIP events on the context's stream around the sub-cycle of every timed step
+    # Timed region: EXACTLY what core.step() does (column thermodynamics when coupled, per-step preparation, the
+    # sub-cycle, transport), with HIP events on the context's stream around the sub-cycle for the dominant kernel
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         core._set_grid()
+        if coupled:
+            core.thermodynamics()
+        core.prepare()
         ev[k][0].record(ctx.stream)
-        core.momentum()
+        core.subcycle()
         ev[k][1].record(ctx.stream)
         core.transport()
     sync()
@@ -353,41 +388,69 @@ def main():
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
-    sub_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / nsub  # per sub-iteration, this rank
+    cycle_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # one sub-cycle (nsub sub-iterations), this rank
 
-    finite = bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())
-    umax = float(core.u.abs().max())
-    if not finite or umax == 0.0:
+    # ---- validity of the run: finite, non-trivial, and the fused pass still equals single sub-iterations bit for bit
+    ok = torch.tensor([float(bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())), float(core.u.abs().max())],
+                      dtype=torch.float64, device=device)
+    guard = fused_pass_guard(ctx, core)
+    ok = torch.cat([ok, torch.tensor([float(guard is not False)], dtype=torch.float64, device=device)])
+    if use_dist:
+        lo = ok.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(ok, op=dist.ReduceOp.MAX)
+        ok[0], ok[2] = lo[0], lo[2]
+    if ok[0] == 0.0 or ok[1] == 0.0:
         raise SystemExit("bench produced non-finite or trivial fields: invalid run")
+    if ok[2] == 0.0:
+        raise SystemExit("bench: one pass of the fused kernel differs from single sub-iterations on the live state: invalid run")
 
-    # sub-iterations per launch of the dominant kernel
-    per_launch = 3 if getattr(core, "three_per_pass", False) and nsub >= 3 else (2 if core.two_per_pass else 1)
+    full, twos, ones = core.passes_per_step()
+    per_launch = core.per_pass if full else (2 if twos else 1)
+    launches = full if full else (twos if twos else ones)  # launches of the dominant kernel per sub-cycle
     fused_kernel = {3: "mevp_fused3_kernel", 2: "mevp_fused2_kernel", 1: "mevp_fused_kernel"}[per_launch]
     if rank == 0:
         n_elem = nx * ny
         value = n_elem * args.steps / elapsed
         own_elems = (blk.r1 - blk.r0) * nx
-        achieved = own_elems * BYTES_PER_ELEM_SUBITER / (sub_ms * 1e-3) / 1e9
+        # every sub-iteration costs the same arithmetic whichever kernel runs it: a launch's share of the sub-cycle
+        # time is its share of the sub-iterations (remainder launches of 2 / 1 sub-iterations are the minority)
+        launch_ms = cycle_ms * per_launch / nsub
+        compulsory = own_elems * BYTES_COMPULSORY_PER_PASS
+        achieved = compulsory / (launch_ms * 1e-3) / 1e9
+        off = offline_counters(nx, ny, fused_kernel) if world == 1 else None
+        roof = {"bound": "hbm", "kernel": fused_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": off["traffic"] if off else None,
+                "traffic_source": (off["source"] + (" -- STALE: kernel sources changed since" if off["stale"] else "")) if off else None,
+                "algorithmic_bytes_per_launch": compulsory,
+                "compulsory_bytes_per_launch": compulsory,
+                "bytes_model": "%d B per element and launch: u,v of the 4 owned nodes 64 + ice strength 72 + stress in 192 + nodal coefficients 192 "
+                               "+ stress out 192 + u,v out 64; a launch performs %d sub-iterations on them" % (BYTES_COMPULSORY_PER_PASS, per_launch),
+                "avg_launch_ms": launch_ms, "launches_per_step": launches, "subiterations_per_launch": per_launch,
+                "hbm_physical_frac": (off["traffic"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if off else None,
+                "valu_issue_frac": valu_issue_frac(off["valu_insts"], launch_ms, ctx) if off and off.get("valu_insts") else None,
+                "survey_8d": {"bytes_per_element_subiteration": BYTES_PER_ELEM_SUBITER,
+                              "equivalent_GBs": own_elems * BYTES_PER_ELEM_SUBITER * per_launch / (launch_ms * 1e-3) / 1e9,
+                              "ratio_to_hbm_peak": own_elems * BYTES_PER_ELEM_SUBITER * per_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "one-pass-per-sub-iteration byte model of SURVEY.md 8(d); the fused kernel keeps the intermediate stress and "
+                                      "velocity of %d sub-iterations on chip, so this ratio is NOT a roofline fraction (it may exceed 1)" % per_launch}}
         line = {
             "metric": "element-steps/sec (dynamics+transport)", "value": value, "unit": "element-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("column thermodynamics + " if coupled else "") + "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
-                                   "512 km box test, dt=120 s, alpha=beta=%.0f (stability bound of the mesh)" % (nx, ny, nsub, alpha),
+                                   "512 km box test, dt=120 s, alpha=beta=%.0f (the linear-stability bound of the sub-cycle on this mesh; SURVEY 8(d) "
+                                   "names 1500, which is unstable here; with %d sub-iterations the stress is under-converged towards the VP state -- "
+                                   "flops and bytes do not depend on alpha)" % (nx, ny, nsub, alpha, nsub),
                        "decomposition": "%d row block(s), ghost-row send/recv" % world + (
-                           ", ghost depth %d/%d rows, one exchange per %d mEVP passes" % (depth[0], depth[1], core.group_passes) if world > 1 else ""),
+                           ", ghost depth %d/%d rows, one exchange per %d mEVP passes, halo=%s" % (depth[0], depth[1], core.group_passes, args.halo) if world > 1 else ""),
                        "mevp_passes": "%s sub-iteration%s per kernel pass" % ({3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
-                       "mevp_variant": args.variant if args.variant is not None else "default"},
-            "roofline": {"bound": "hbm", "kernel": "mEVP sub-iteration", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(nx, ny, fused_kernel) if world == 1 else None,
-                         "algorithmic_bytes_per_launch": own_elems * BYTES_PER_ELEM_SUBITER * per_launch,
-                         "avg_launch_ms": sub_ms * per_launch,
-                         "note": ("achieved = 896 B (SURVEY section 8d, per element-sub-iteration) x elements x %d sub-iterations / launch time; "
-                                  "the kernel fuses %d sub-iterations per pass and keeps the intermediate stress/velocity on chip, "
-                                  "so it moves 1/%d of that figure through HBM (see traffic) -- frac > 1 is possible by design"
-                                  % (per_launch, per_launch, per_launch))
-                         if per_launch > 1 else None},
-            "mevp_element_subiters_per_s": own_elems / (sub_ms * 1e-3),
+                       "mevp_variant": args.variant if args.variant is not None else "default",
+                       "parity": "dynamics parity unpinned (the reference snapshot has no DG/mEVP code); self-check of this run: "
+                                 + ("fused pass == single sub-iterations bitwise on the live state" if guard else "finite fields")},
+            "roofline": roof,
+            "mevp_element_subiters_per_s": own_elems * nsub / (cycle_ms * 1e-3),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nsub)
@@ -395,6 +458,88 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def plan_blocks(variant, passes_per_exchange, nx, ny, rank, world):
+    """row block of `rank`: ghost element rows below / above are (v k, v k - 1) for k passes of v sub-iterations
+    between two exchanges"""
+    kpass = max(1, min(passes_per_exchange, (ny // world) // 16)) if world > 1 else 1
+    vpass = min(variant, 3)
+    depth = (vpass * kpass, vpass * kpass - 1) if vpass >= 2 else (1, 1)
+    return rowblock.RowBlock(nx, ny, rank, world, *depth), depth
+
+
+def make_exchanger(kind, ctx, blk, device):
+    loop = bool(os.environ.get("NSDG_FORCE_DIST")) and blk.world == 1
+    if kind == "native":
+        return rowblock.NativeHaloExchanger(ctx, blk, device, loopback=loop)
+    return rowblock.HaloExchanger(blk, loopback=loop)
+
+
+def fused_pass_guard(ctx, core):
+    """In-bench correctness guard: on the LIVE state after the timed region, one pass of the multi-iteration kernel
+    must equal the same number of single sub-iterations bit for bit (stress and velocity), treating the rank's
+    local array as a domain of its own.  Returns True (checked, equal), False (differs) or None (the run uses
+    the single-iteration kernel only: nothing to compare)."""
+    v = core.per_pass
+    if v < 2 or core.nsub < v:
+        return None
+    ny = core.blk.ny
+    core._set_grid()
+    new = lambda: ([torch.empty_like(x) for x in core.s], (torch.zeros_like(core.u), torch.zeros_like(core.v)))
+    (sx, ux), (sy, uy) = new(), new()
+    getattr(ctx, "mevp_iterate%d" % v)(0, ny, core.s, core.sb, (core.u, core.v), (core.ub, core.vb), core.packed, core.pg)
+    src, usrc = core.s, (core.u, core.v)
+    for i in range(v):
+        dst, udst = (sx, ux) if i % 2 == 0 else (sy, uy)
+        ctx.mevp_iterate(0, 0, ny, src, dst, usrc, udst, core.packed, core.pg)
+        src, usrc = dst, udst
+    same = all(torch.equal(a, b) for a, b in zip(src, core.sb)) and torch.equal(usrc[0], core.ub) and torch.equal(usrc[1], core.vb)
+    return bool(same)
+
+
+def valu_issue_frac(valu_wave_insts, launch_ms, ctx):
+    """VALU wave-instructions of a launch (offline SQ_INSTS_VALU) x 4 cycles (a 64-wide fp64 instruction on a
+    16-lane SIMD) / (SIMDs x peak shader clock x launch time): the share of the chip's peak VALU issue slots the
+    kernel fills"""
+    simds = 4 * ctx.num_cus()
+    return valu_wave_insts * 4.0 / (simds * SHADER_CLOCK_PEAK_HZ * launch_ms * 1e-3)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never will), let the children's output through and exit with their status"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, rank, world):
+    """Plumbing check without a GPU (tests/test_bench_launch.py, gloo): the launch, the rendezvous, the row-block
+    planning and the max-over-ranks reduction of the real run -- no kernel runs, NO metric is reported."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blk, depth = plan_blocks(abi.DEFAULT_MEVP_VARIANT, args.passes_per_exchange, args.nx, args.ny, rank, world)
+    rows = torch.tensor([float(blk.r1 - blk.r0)], dtype=torch.float64)
+    dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+    dist.barrier()
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": None, "value": None, "n_gpus": world, "rows_total": int(rows[0]),
+                          "ghost_depth": list(depth), "max_rank_seen": int(t[0])}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

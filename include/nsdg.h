@@ -49,14 +49,15 @@
 extern "C" {
 #endif
 
-#define NSDG_ABI_VERSION 1
+#define NSDG_ABI_VERSION 2
 
 typedef enum {
     NSDG_OK = 0,
     NSDG_ERR_ARG = -1, /* bad argument (null pointer, bad size / order / range) */
     NSDG_ERR_HIP = -2, /* a HIP runtime call or kernel launch failed */
     NSDG_ERR_STATE = -3, /* call sequence error (e.g. grid not set) */
-    NSDG_ERR_NODEVICE = -4 /* no usable HIP device */
+    NSDG_ERR_NODEVICE = -4, /* no usable HIP device */
+    NSDG_ERR_COMM = -5 /* RCCL missing or an RCCL call failed; a rank of a local group failed */
 } nsdg_status;
 
 typedef struct nsdg_ctx nsdg_ctx;
@@ -242,6 +243,51 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
 int nsdg_mevp_strip_rows_set(nsdg_ctx* ctx, int32_t rows);
 /* register budget of the fused kernel: 1 or 2 resident waves per SIMD (performance knob) */
 int nsdg_mevp_occupancy_set(nsdg_ctx* ctx, int32_t waves_per_simd);
+
+/* ---- row-block decomposition: ghost-row exchange (SURVEY.md section 8(b) "nsdg_halo_exchange", 8(e)) ----------
+ * The reference is a single-process, single-thread program; these entry points have no
+ * counterpart in it.  They sit behind the same seam as everything else, the batched model step
+ * IModelStep::iterate (core/src/include/IModelStep.hpp:16-34): a multi-rank step owns one context per GPU and
+ * exchanges ghost rows with its <= 2 neighbours between kernel launches.  No collective is involved.
+ *
+ * Communicator: one per context.  nsdg_comm_init is the RCCL transport (one process per GPU; `id` is the
+ * NSDG_COMM_ID_BYTES-byte ncclUniqueId obtained by rank 0 from nsdg_comm_unique_id and distributed by the caller --
+ * torch.distributed in the Python driver, a TCP rendezvous in the C++ host); collective over the ranks.
+ * librccl.so.1 is loaded on first use.  nsdg_comm_init_local is the in-process transport: the ranks of `group`
+ * are contexts of ONE process driven by one host thread each (device-to-device copies, host hand-shake); used
+ * by the one-GPU tests of the multi-rank driver and usable as a single-process multi-GPU mode. */
+#define NSDG_COMM_ID_BYTES 128
+int nsdg_comm_unique_id(void* id);
+int nsdg_comm_init(nsdg_ctx* ctx, int32_t rank, int32_t world, const void* id);
+int nsdg_comm_init_local(nsdg_ctx* ctx, int64_t group, int32_t rank, int32_t world);
+int nsdg_comm_finalize(nsdg_ctx* ctx);
+int nsdg_comm_rank(nsdg_ctx* ctx, int32_t* rank, int32_t* world);
+
+/* A plan fixes what ONE kind of exchange moves: for each of the four directions a list of contiguous blocks of
+ * doubles in the caller's arrays (row blocks: ghost rows are contiguous in every layout of this ABI).  up_send
+ * travels to rank_above and is received there as from_below, down_send travels to rank_below and arrives as
+ * from_above; the packed sizes of matching directions must agree between neighbours.  rank_* = -1: physical
+ * boundary, no traffic.  rank_below == rank_above == own rank: loopback (what goes up arrives from below), the
+ * one-GPU rehearsal of an interior block.  Every rank of a communicator creates its plans in the same order. */
+typedef struct nsdg_halo nsdg_halo;
+typedef struct {
+    double* ptr;
+    int64_t count;
+} nsdg_halo_seg;
+int nsdg_halo_plan_create(nsdg_ctx* ctx, int32_t rank_below, int32_t rank_above, int32_t n_up, const nsdg_halo_seg* up_send,
+    int32_t n_down, const nsdg_halo_seg* down_send, int32_t n_above, const nsdg_halo_seg* from_above, int32_t n_below,
+    const nsdg_halo_seg* from_below, nsdg_halo** out);
+int nsdg_halo_plan_destroy(nsdg_halo* plan);
+/* packed doubles per direction (segments are padded to 16 bytes) */
+int nsdg_halo_counts(const nsdg_halo* plan, int64_t* up, int64_t* down, int64_t* above, int64_t* below);
+
+/* One exchange.  start: everything enqueued on the context's stream so far is visible to the exchange; the send
+ * blocks are packed (one launch) and the transport is posted on the context's communication stream.  finish: the
+ * received blocks are scattered into the ghost rows (one launch) and the context's stream waits for that.  Neither
+ * call blocks the host (the local transport blocks until the neighbour thread has posted).  Kernels launched between
+ * the two calls overlap with the exchange; they must not write the send blocks nor touch the receive blocks. */
+int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* plan);
+int nsdg_halo_finish(nsdg_ctx* ctx, nsdg_halo* plan);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,13 @@ class MevpParams(C.Structure):
         "alpha", "beta", "h_min")]
 
 
+class HaloSeg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("count", C.c_int64)]
+
+
+COMM_ID_BYTES = 128
+
+
 class NsdgError(RuntimeError):
     pass
 
@@ -74,6 +81,17 @@ SYMBOLS = {
     "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_occupancy_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
+    "nsdg_comm_unique_id": (C.c_int, [VP]),
+    "nsdg_comm_init": (C.c_int, [VP, I32, I32, VP]),
+    "nsdg_comm_init_local": (C.c_int, [VP, I64, I32, I32]),
+    "nsdg_comm_finalize": (C.c_int, [VP]),
+    "nsdg_comm_rank": (C.c_int, [VP, C.POINTER(I32), C.POINTER(I32)]),
+    "nsdg_halo_plan_create": (C.c_int, [VP, I32, I32, I32, C.POINTER(HaloSeg), I32, C.POINTER(HaloSeg), I32, C.POINTER(HaloSeg), I32,
+                                        C.POINTER(HaloSeg), C.POINTER(VP)]),
+    "nsdg_halo_plan_destroy": (C.c_int, [VP]),
+    "nsdg_halo_counts": (C.c_int, [VP] + [C.POINTER(I64)] * 4),
+    "nsdg_halo_start": (C.c_int, [VP, VP]),
+    "nsdg_halo_finish": (C.c_int, [VP, VP]),
 }
 
 _lib = None
@@ -158,6 +176,60 @@ def _ptr_array(tensors):
     return arr
 
 
+class HaloPlanHandle:
+    """an nsdg_halo plan; start() / finish() are pre-bound zero-argument calls"""
+
+    def __init__(self, ctx, below, above, up_send, down_send, from_above, from_below):
+        def pieces(v):  # a row block of a [nc, ny, nx] array is one contiguous block per coefficient plane
+            return [v] if v.is_contiguous() else [p for sub in v.unbind(0) for p in pieces(sub)]
+
+        lists = tuple([p for v in views for p in pieces(v)] for views in (up_send, down_send, from_above, from_below))
+        for views in lists:
+            _check_f64(*views)
+        self.keep = [list(v) for v in lists]  # the tensors must outlive the plan
+        arrs = []
+        for views in lists:
+            a = (HaloSeg * max(len(views), 1))()
+            for i, v in enumerate(views):
+                a[i].ptr, a[i].count = v.data_ptr(), v.numel()
+            arrs.append(a)
+        h = VP()
+        nb = lambda r: -1 if r is None else int(r)
+        ctx._call(ctx.lib.nsdg_halo_plan_create(ctx.h, nb(below), nb(above), len(lists[0]), arrs[0], len(lists[1]), arrs[1],
+                                                len(lists[2]), arrs[2], len(lists[3]), arrs[3], C.byref(h)))
+        self.ctx, self.h = ctx, h
+        lib, ch = ctx.lib, ctx.h
+
+        def start():
+            rc = lib.nsdg_halo_start(ch, h)
+            if rc != 0:
+                ctx._call(rc)
+
+        def finish():
+            rc = lib.nsdg_halo_finish(ch, h)
+            if rc != 0:
+                ctx._call(rc)
+
+        self.start, self.finish = start, finish
+
+    def counts(self):
+        c = [I64() for _ in range(4)]
+        self.ctx._call(self.ctx.lib.nsdg_halo_counts(self.h, *[C.byref(x) for x in c]))
+        return tuple(x.value for x in c)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.nsdg_halo_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:  # plans die with their context's communicator otherwise
+                self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One nsdg_ctx bound to a torch device and (by default) torch's current stream on it, so that
     torch.cuda.Event timing and torch.distributed collectives order correctly with the kernels."""
@@ -194,6 +266,37 @@ class Context:
 
     def synchronize(self):
         self._call(self.lib.nsdg_ctx_synchronize(self.h))
+
+    def num_cus(self):
+        import torch
+
+        return torch.cuda.get_device_properties(self.device).multi_processor_count
+
+    # ---- row-block communicator and ghost-row exchange plans (csrc/halo.hip)
+    def comm_init_rccl(self, rank, world, group=None):
+        """RCCL communicator of this context; the ncclUniqueId of rank 0 travels through torch.distributed
+        (any backend: it is 128 bytes, once)"""
+        import torch.distributed as dist
+
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        if rank == 0:
+            self._call(self.lib.nsdg_comm_unique_id(buf))
+        if world > 1:
+            box = [buf.raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            buf = C.create_string_buffer(box[0], COMM_ID_BYTES)
+        self._call(self.lib.nsdg_comm_init(self.h, rank, world, buf))
+
+    def comm_init_local(self, group_id, rank, world):
+        """in-process communicator: the ranks of `group_id` are contexts driven by one thread each"""
+        self._call(self.lib.nsdg_comm_init_local(self.h, int(group_id), rank, world))
+
+    def comm_finalize(self):
+        self._call(self.lib.nsdg_comm_finalize(self.h))
+
+    def halo_plan(self, below, above, up_send, down_send, from_above, from_below):
+        """plan of one kind of exchange; the arguments are lists of CONTIGUOUS tensor views (row blocks)"""
+        return HaloPlanHandle(self, below, above, up_send, down_send, from_above, from_below)
 
     # ---- arrays private to the mEVP sub-cycle (stress, ice strength) live in the tiled layout
     def private_zeros(self, nc, ny, nx, device):

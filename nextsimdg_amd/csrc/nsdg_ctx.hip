@@ -87,6 +87,8 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     c->transport_rows = 0;
     c->pack_dt = 0.;
     c->d_ptrs = nullptr;
+    c->comm = nullptr;
+    c->comm_group = 0;
     *out = c;
     return NSDG_OK;
 }
@@ -95,6 +97,7 @@ int nsdg_ctx_destroy(nsdg_ctx* ctx)
 {
     if (!ctx)
         return NSDG_OK;
+    nsdg_comm_finalize(ctx);
     delete ctx;
     return NSDG_OK;
 }
@@ -120,6 +123,7 @@ int nsdg_mevp_params_set(nsdg_ctx* ctx, const nsdg_mevp_params* p)
     NSDG_CHECK_ARG(ctx && p, "null argument");
     NSDG_CHECK_ARG(p->alpha > 0 && p->beta > 0, "alpha and beta must be positive");
     ctx->mevp = *p;
+    ctx->pack_dt = 0.; // the packed nodal coefficients were built from the old parameters: repack before iterating
     return NSDG_OK;
 }
 
@@ -129,6 +133,10 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy)
     NSDG_CHECK_ARG(nx > 0 && ny > 0, "nx and ny must be positive");
     NSDG_CHECK_ARG(hx > 0 && hy > 0, "cell sizes must be positive");
     NSDG_CHECK_ARG((long)(2 * (long)nx + 1) * (2 * (long)ny + 1) < (1L << 31), "grid too large for 32-bit node indices");
+    ctx->nx = nx;
+    ctx->ny = ny;
+    if (ctx->nx != nx || ctx->ny != ny || ctx->hx != hx || ctx->hy != hy)
+        ctx->pack_dt = 0.; // packed nodal coefficients belong to the old grid
     ctx->nx = nx;
     ctx->ny = ny;
     ctx->hx = hx;

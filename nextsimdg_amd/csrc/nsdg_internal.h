@@ -7,6 +7,8 @@
 
 #include "../../include/nsdg.h"
 
+struct nsdg_comm; // halo.hip
+
 struct nsdg_ctx {
     int device;
     hipStream_t stream;
@@ -22,6 +24,8 @@ struct nsdg_ctx {
     int fused_min_waves; // register budget of the fused kernel: 1 or 2 waves per SIMD
     // device scratch for small host->device tables (field pointer lists of the transport stage)
     double** d_ptrs;
+    nsdg_comm* comm; // row-block communicator (halo.hip), null until nsdg_comm_init*
+    int64_t comm_group; // id of the local group the communicator belongs to
 };
 
 void nsdg_set_error(const char* fmt, ...);

@@ -205,6 +205,53 @@ class HaloExchanger:
         self._finish(self._start(plan))
 
 
+class NativeHaloExchanger(HaloExchanger):
+    """the planning of HaloExchanger with the transport behind the C ABI (csrc/halo.hip): pack kernel, RCCL
+    send/recv group on the context's communication stream, unpack kernel -- three C calls and no torch op per
+    exchange.  `local_group`: in-process transport between thread-ranks instead of RCCL (one-GPU tests)."""
+
+    def __init__(self, ctx, blk, device=None, group=None, loopback=False, local_group=None):
+        super().__init__(blk, group, loopback)
+        self.ctx = ctx
+        if loopback:
+            # rehearsal of an interior block on one GPU: a communicator of ONE rank, both neighbours are that rank
+            # (what goes up arrives from below); the values wrap around, the calls and sizes are the real ones
+            if local_group is not None:
+                ctx.comm_init_local(local_group, 0, 1)
+            else:
+                ctx.comm_init_rccl(0, 1)
+            self.peer_below = 0 if blk.below is not None else None
+            self.peer_above = 0 if blk.above is not None else None
+        else:
+            if local_group is not None:
+                ctx.comm_init_local(local_group, blk.rank, blk.world)
+            else:
+                ctx.comm_init_rccl(blk.rank, blk.world, group)
+            self.peer_below, self.peer_above = blk.below, blk.above
+
+    def _plan(self, key, build):
+        plan = self._cache.get(key)
+        if plan is None:
+            plan = self._cache[key] = HaloPlan()
+            if self.blk.world > 1:
+                build(plan)
+                if plan.up_send or plan.down_send or plan.from_above or plan.from_below:
+                    plan.native = self.ctx.halo_plan(self.peer_below, self.peer_above, plan.up_send, plan.down_send,
+                                                     plan.from_above, plan.from_below)
+        return plan
+
+    def _start(self, plan):
+        native = getattr(plan, "native", None)
+        if native is None:
+            return None
+        native.start()
+        return native
+
+    def _finish(self, handle):
+        if handle is not None:
+            handle.finish()
+
+
 class DynamicsCore:
     """State and time step of the dynamics core on one rank's row block.
 
@@ -266,11 +313,29 @@ class DynamicsCore:
         self.ops.set_grid(self.blk.nx, self.blk.ny, self.hx, self.hy)
 
     def momentum(self):
+        self.prepare()
+        self.subcycle()
+
+    def prepare(self):
+        """once per model step: ice strength at the Gauss points, nodal means of H and A, wind stress and the packed
+        momentum coefficients (one launch); the velocity at the start of the step is read from the current iterate
+        (it is only needed inside the packing)"""
         ops, b = self.ops, self.blk
         ops.ice_strength(self.H, self.A, self.pg, 0, b.ny)
-        # nodal means of H and A, wind stress and the packed momentum coefficients in one launch; the velocity at
-        # the start of the step is read from the current iterate (it is only needed inside the packing)
         ops.mevp_prepare(self.dt, self.H, self.A, (self.ua, self.va), (self.uo, self.vo), (self.u, self.v), self.packed)
+
+    def passes_per_step(self):
+        """kernel launches of the dominant kernel per sub-cycle on an unsplit block: (launches with per_pass
+        sub-iterations, two-iteration remainders, single sub-iterations)"""
+        n, v = self.nsub, self.per_pass
+        if v == 1:
+            return 0, 0, n
+        full, rest = n // v, n % v
+        return full, (rest // 2 if v == 3 else 0), (rest % 2 if v == 3 else rest)
+
+    def subcycle(self):
+        """the nsub mEVP sub-iterations of one model step (ghost rows exchanged as the ghost depth requires)"""
+        ops, b = self.ops, self.blk
         it = 0
         if self.per_pass >= 2:
             # v sub-iterations per pass (the intermediate stress / velocity stay on chip).  With several ranks the

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_default_params(lib):
-    assert lib.nsdg_abi_version() == 1
+    assert lib.nsdg_abi_version() == 2  # 2: nsdg_comm_* / nsdg_halo_* (row-block ghost exchange)
     p = abi.ColumnParams()
     lib.nsdg_column_default_params(C.byref(p))
     # defaults of the reference: NextsimPhysics.cpp:76-82, ThermoIce0.cpp:30-31, HiblerConcentration.cpp:28-29
@@ -51,6 +51,15 @@ def test_param_struct_layout_matches_oracle():
     for a, b in ((abi.ColumnParams, O.ColumnParams), (abi.MevpParams, O.MevpParams)):
         assert [f[0] for f in a._fields_] == [f[0] for f in b._fields_]
         assert C.sizeof(a) == C.sizeof(b)
+
+
+def test_comm_entry_points_fail_cleanly_without_a_device(lib):
+    """the ghost-exchange entry points on a machine without a GPU: argument / state errors, never a crash"""
+    assert lib.nsdg_comm_init(None, 0, 1, None) == -1
+    assert lib.nsdg_comm_finalize(None) == -1
+    assert lib.nsdg_halo_plan_destroy(None) == 0
+    assert lib.nsdg_halo_start(None, None) == -1
+    assert lib.nsdg_halo_finish(None, None) == -1
 
 
 def test_no_silent_cpu_fallback(lib):
@@ -73,8 +82,6 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
-                if re.search(r"oracle_lib|liboracle|oracle/|_oracle\.", txt) and "oracle/dyn_oracle.c" not in txt and "oracle/" in txt and False:
-                    bad.append(f)
                 if re.search(r"import\s+oracle|from\s+oracle|liboracle|#include\s+\".*oracle", txt):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad

@@ -1,0 +1,103 @@
+"""BASELINE.json configs 3, 4 and 5 AS STATED, on one MI355X, through the C ABI.
+
+The CPU oracle cannot run these sizes in seconds, so the checks are the size-independent ones the discretisation
+offers: the kernel variants agree bit for bit (three sub-iterations per pass == three single passes), mass is
+conserved in the closed box, the Dirichlet rows stay zero, and a row-block decomposition reproduces the
+single-domain run bit for bit.  The multi-rank driver runs with one thread per rank on the one GPU of the test
+box (tests/thread_ranks.py): real kernels, real ghost-row layouts, in-process transport instead of RCCL.
+"""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from nextsimdg_amd import abi, rowblock, synthetic
+from thread_ranks import fields, gather, run_world
+
+pytestmark = pytest.mark.gpu
+
+
+def free():
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def check_physical(res, mass0, nx, ny):
+    u, v, H, A = res["u"], res["v"], res["H"], res["A"]
+    for f in (u, v, H, A):
+        assert bool(torch.isfinite(f).all())
+    for f in (u, v):  # closed box: v = 0 on all four walls
+        assert float(f[0].abs().max()) == 0 and float(f[-1].abs().max()) == 0
+        assert float(f[:, 0].abs().max()) == 0 and float(f[:, -1].abs().max()) == 0
+    assert 1e-6 < float(u.abs().max()) < 1.0
+    if mass0 is not None:  # transport alone conserves the cell means in the closed box
+        assert abs(float(H[0].sum()) - mass0[0]) <= 1e-12 * abs(mass0[0])
+        assert abs(float(A[0].sum()) - mass0[1]) <= 1e-12 * abs(mass0[1])
+
+
+def test_config3_1024_transport_and_mevp_120_subiterations(gpu):
+    """config 3: 1024x1024 DG2 transport (H, A; SSP-RK3) + mEVP with 120 sub-iterations, 3 model steps, default
+    kernel (three sub-iterations per pass) against one sub-iteration per pass: bit-identical; mass, walls"""
+    n, nsub, nsteps = 1024, 120, 3
+    data = fields(n, n, wind_scale=1.0)
+    alpha = data[0].stable_alpha(120.0)
+    mass0 = (float(np.sum(data[1][0])), float(np.sum(data[2][0])))
+    res = {}
+    for variant in (3, 1):
+        res[variant] = run_world(1, variant, False, n, n, nsub, nsteps, data=data, alpha=alpha)[0]
+        check_physical(res[variant], mass0, n, n)
+    for k in ("u", "v", "H", "A", "s11"):
+        assert torch.equal(res[3][k], res[1][k]), k
+    assert float((res[3]["H"][0] - torch.from_numpy(data[1][0]).cuda()).abs().max()) > 1e-9  # the ice did move
+    del res
+    free()
+
+
+def test_config4_2048_four_row_blocks_equal_single_domain_bitwise(gpu):
+    """config 4: 2048x2048 DG2 full dynamics, 4 row blocks of 512 rows, 120 sub-iterations, 6 passes of the
+    three-iteration kernel between two ghost-row exchanges (ghost depth 18 / 17), overlap split on, 2 model steps:
+    every owned row of every block equals the single-domain run bit for bit"""
+    n, nsub, nsteps, world, group = 2048, 120, 2, 4, 6
+    data = fields(n, n, wind_scale=1.0)
+    alpha = data[0].stable_alpha(120.0)
+    mass0 = (float(np.sum(data[1][0])), float(np.sum(data[2][0])))
+    ref = run_world(1, 3, False, n, n, nsub, nsteps, data=data, alpha=alpha)[0]
+    check_physical(ref, mass0, n, n)
+    parts = run_world(world, 3, False, n, n, nsub, nsteps, group=group, data=data, alpha=alpha)
+    for k in ("H", "A", "u", "v", "s11"):
+        got = gather(parts, world, k)
+        assert got.shape == ref[k].shape, k
+        assert torch.equal(got, ref[k]), k
+    del ref, parts
+    free()
+
+
+def test_config5_4096_coupled_eight_row_blocks_equal_single_domain_bitwise(gpu):
+    """config 5: 4096x4096 DG2 dynamics + column thermodynamics, 8 row blocks of 512 rows, 120 sub-iterations,
+    3 model steps with the smooth winter forcing of the coupled bench: bit-identical to the single domain, fields
+    in their physical ranges.  (The one-day run of this configuration is tools/soak_coupled.py; its record is in
+    profiles/.)"""
+    n, nsub, nsteps, world, group = 4096, 120, 3, 8, 6
+    bt = synthetic.BoxTest(n, n)
+    H, A = bt.dg_fields()
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    data = (bt, H, A, uo, vo, ua, va)
+    cs, cf = synthetic.column_fields_smooth(n, n)
+    column = {**cs, **cf}
+    alpha = bt.stable_alpha(120.0)
+    keep = ("H", "A", "u", "v")
+    ref = run_world(1, 3, True, n, n, nsub, nsteps, data=data, column=column, alpha=alpha, keep=keep)[0]
+    check_physical(ref, None, n, n)
+    assert 0.25 < float(ref["H"][0].min()) and float(ref["H"][0].max()) < 0.45
+    assert 0.9 < float(ref["A"][0].min()) and float(ref["A"][0].max()) < 1.01
+    assert -40.0 < float(ref["tice0"].min()) and float(ref["tice0"].max()) <= 0.0
+    assert float((ref["tice0"] - torch.from_numpy(column["tice0"]).cuda()).abs().max()) > 1e-3  # the column step ran
+    parts = run_world(world, 3, True, n, n, nsub, nsteps, group=group, data=data, column=column, alpha=alpha, keep=keep)
+    for k in keep + ("hsnow", "tice0"):
+        got = gather(parts, world, k)
+        assert got.shape == ref[k].shape, k
+        assert torch.equal(got, ref[k]), k
+    del ref, parts
+    free()

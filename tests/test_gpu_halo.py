@@ -1,0 +1,91 @@
+"""The ghost-row exchange behind the C ABI (csrc/halo.hip, nsdg_comm_* / nsdg_halo_*) on one GPU:
+plans and pack / unpack kernels on hand-made segments, the RCCL transport in loopback (a communicator of one rank
+whose neighbours are the rank itself: real ncclSend / ncclRecv groups), and the in-process transport under the
+whole multi-rank driver, bit for bit against the single-domain run."""
+import ctypes as C
+
+import pytest
+import torch
+
+from nextsimdg_amd import abi
+from thread_ranks import gather, run_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx(gpu):
+    c = abi.Context(gpu)
+    yield c
+    c.close()
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.rand(*shape, dtype=torch.float64, device="cuda", generator=g)
+
+
+@pytest.mark.parametrize("transport", ["rccl", "local"])
+def test_loopback_exchange_delivers_every_block_in_order(ctx, transport):
+    """several blocks per direction with odd lengths and odd (8-byte) alignments: what is sent upwards arrives as
+    'from below' block by block, what is sent downwards as 'from above'; untouched memory stays untouched"""
+    if transport == "rccl":
+        ctx.comm_init_rccl(0, 1)
+    else:
+        ctx.comm_init_local(77, 0, 1)
+    a, b, c = rnd(40, 257, seed=1), rnd(9, 3, 512, seed=2), rnd(1001, seed=3)
+    ra, rb, rc = torch.zeros_like(a), torch.zeros_like(b), torch.zeros_like(c)
+    up = [a[30:37], b[5:8], c[1:400]]  # c[1:] starts 8 bytes off a 16-byte boundary
+    down = [a[2:3], c[500:503]]
+    from_below = [ra[0:7], rb[0:3], rc[3:402]]
+    from_above = [ra[39:40], rc[900:903]]
+    plan = ctx.halo_plan(0, 0, up, down, from_above, from_below)
+    assert plan.counts()[0] >= sum(v.numel() for v in up)
+    for it in range(3):  # the plan is reusable; new data every time
+        a.add_(1.0), b.add_(1.0), c.add_(1.0)
+        plan.start()
+        plan.finish()
+        torch.cuda.synchronize()
+        for s, r in list(zip(up, from_below)) + list(zip(down, from_above)):
+            assert torch.equal(s, r)
+    assert float(ra[7:39].abs().max()) == 0 and float(rb[3:].abs().max()) == 0
+    assert float(rc[:3].abs().max()) == 0 and float(rc[402:900].abs().max()) == 0 and float(rc[903:].abs().max()) == 0
+    plan.close()
+    ctx.comm_finalize()
+
+
+def test_halo_call_sequence_errors(ctx):
+    """error behaviour of the boundary: negative status + nsdg_last_error, never an exception from the library"""
+    lib = ctx.lib
+    h = abi.VP()
+    seg = (abi.HaloSeg * 1)()
+    x = rnd(16)
+    seg[0].ptr, seg[0].count = x.data_ptr(), 16
+    # no communicator yet
+    assert lib.nsdg_halo_plan_create(ctx.h, 0, 0, 1, seg, 0, seg, 0, seg, 1, seg, C.byref(h)) == -3
+    ctx.comm_init_local(78, 0, 1)
+    assert lib.nsdg_comm_init_local(ctx.h, 78, 0, 1) == -3  # second communicator on the same context
+    assert lib.nsdg_halo_plan_create(ctx.h, 5, 0, 1, seg, 0, seg, 0, seg, 1, seg, C.byref(h)) == -1  # rank out of range
+    assert lib.nsdg_halo_plan_create(ctx.h, -1, 0, 1, seg, 1, seg, 0, seg, 0, seg, C.byref(h)) == -1  # segments towards a wall
+    plan = ctx.halo_plan(0, 0, [x[0:4]], [], [], [x[8:12]])
+    assert lib.nsdg_halo_finish(ctx.h, plan.h) == -3  # finish without start
+    plan.start()
+    assert lib.nsdg_halo_start(ctx.h, plan.h) == -3  # start twice
+    assert b"not finished" in lib.nsdg_last_error()
+    plan.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(x[8:12], x[0:4])
+    plan.close()
+
+
+@pytest.mark.parametrize("world,group,nsub,coupled,variant", [(3, 2, 20, False, 3), (4, 3, 13, True, 2), (2, 1, 7, False, 1)])
+def test_driver_on_native_halo_equals_single_domain_bitwise(gpu, world, group, nsub, coupled, variant):
+    """the whole multi-rank driver with the exchange of the product (nsdg_halo_*: pack kernel, transport, unpack
+    kernel on a communication stream, event-ordered against the compute stream), thread-ranks on the in-process
+    transport: bit-identical to the single-domain run"""
+    nx, ny, nsteps = 150, 128, 2
+    ref = run_world(1, variant, coupled, nx, ny, nsub, nsteps)[0]
+    assert float(ref["u"].abs().max()) > 1e-5
+    parts = run_world(world, variant, coupled, nx, ny, nsub, nsteps, group=group, transport="native")
+    for key in ("H", "A", "u", "v", "s11"):
+        assert torch.equal(gather(parts, world, key), ref[key]), (key, world, group)

@@ -1,7 +1,7 @@
 """Diagnostic: GPU time of ONE rank's share of the 2048x2048 dynamics step for a world of W row blocks, measured
 on a single GPU with the ghost exchanges replaced by no-ops (the values in the ghost rows go stale, only the
 timing is meaningful).  Gives the compute-side bound on the strong-scaling speed-up that the 8-GPU run of the
-driver can reach: T(1 block) / T(share).  usage: python tools/rank_share_timing.py [W ...]"""
+driver can reach: T(1 block) / T(share).  usage: python tools/rank_share_timing.py [--halo native|torch] [--rccl-loopback] [--no-overlap] [--k K,...] [W ...]"""
 import os
 import sys
 import time
@@ -25,7 +25,27 @@ GRID = int(os.environ.get("NSDG_SHARE_GRID", "2048"))  # smaller grid / fewer su
 NSUB = int(os.environ.get("NSDG_SHARE_NSUB", "120"))
 
 
-def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopback=False):
+def check_loopback_values(core):
+    """one ghost exchange of an interior block whose neighbours are the rank itself, on distinct random data:
+    what was sent upwards must arrive as the ghost rows from below and vice versa, block by block -- this pins the
+    pack / send / receive / unpack ordering of the exchanger on the device"""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    for f in core.sb + [core.ub, core.vb]:
+        f.copy_(torch.rand(f.shape, dtype=f.dtype, device=f.device, generator=g))
+    core._ghost_exchange_finish(core._ghost_exchange_start())
+    torch.cuda.synchronize()
+    plans = [p for k, p in core.halo._cache.items() if k[0] == "r"]
+    assert plans, "no ghost-zone plan was built"
+    n = 0
+    for p in plans:
+        assert len(p.up_send) == len(p.from_below) and len(p.down_send) == len(p.from_above)
+        for a, b in list(zip(p.up_send, p.from_below)) + list(zip(p.down_send, p.from_above)):
+            assert a.shape == b.shape and torch.equal(a, b), "loopback exchange delivered wrong values"
+            n += a.numel()
+    return n
+
+
+def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopback=False, halo="native"):
     dev = torch.device("cuda:0")
     ctx = abi.Context(dev)
     L, dt = 512e3, 120.0
@@ -40,8 +60,11 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
     if world > 1 and loopback:  # real RCCL send/recv, both neighbours = this rank (periodic wrap: values meaningless)
         if blk.below is None or blk.above is None:
             raise SystemExit("--rccl-loopback needs a block with two neighbours (world >= 3)")
-        blk.below = blk.above = 0
-        exchanger = rowblock.HaloExchanger(blk, loopback=True)
+        if halo == "native":  # pack kernel + ncclSend/ncclRecv group + unpack kernel behind the C ABI
+            exchanger = rowblock.NativeHaloExchanger(ctx, blk, loopback=True)
+        else:  # torch.distributed P2P ops
+            blk.below = blk.above = 0
+            exchanger = rowblock.HaloExchanger(blk, loopback=True)
     elif world > 1:
         exchanger = NullExchanger(blk)
     core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=exchanger, overlap=overlap)
@@ -56,20 +79,27 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
         core.step()
     host = time.perf_counter() - t0
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3, host / steps * 1e3, blk.ny
+    res = (time.perf_counter() - t0) / steps * 1e3, host / steps * 1e3, blk.ny
+    if world > 1 and loopback and core.per_pass >= 2:
+        print("loopback values: ok (%d doubles compared)" % check_loopback_values(core), flush=True)
+    return res
 
 
 if __name__ == "__main__":
     ks = (1, 4)
     args = sys.argv[1:]
-    overlap, loopback = True, False
+    overlap, loopback, halo = True, False, "native"
+    if args and args[0] == "--halo":  # native (default): exchanges behind the C ABI; torch: torch.distributed P2P ops
+        halo = args[1]
+        args = args[2:]
     if args and args[0] == "--rccl-loopback":  # exchanges are real RCCL send/recv to self (one rank on one GPU)
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29551")
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        if halo == "torch":
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29551")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         loopback = True
         args = args[1:]
     if args and args[0] == "--no-overlap":  # one launch per pass, the exchange would follow it un-overlapped
@@ -82,11 +112,11 @@ if __name__ == "__main__":
     base = None
     for w in worlds:
         for k in ((1,) if w == 1 else ks):
-            ms, host_ms, rows = run(w, k, overlap=overlap, loopback=loopback)
+            ms, host_ms, rows = run(w, k, overlap=overlap, loopback=loopback, halo=halo)
             base = ms if w == 1 else base
-            print(("RCCL loopback  " if loopback else "") + ("" if overlap else "no-overlap  ") + "world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
+            print(("RCCL loopback (%s halo)  " % halo if loopback else "") + ("" if overlap else "no-overlap  ") + "world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
                   % (w, k, rows, ms, host_ms, "%.2f" % (base / ms) if base else "-"), flush=True)
-    if loopback:
+    if loopback and halo == "torch":
         import torch.distributed as dist
 
         dist.barrier()
