@@ -289,6 +289,57 @@ int nsdg_halo_counts(const nsdg_halo* plan, int64_t* up, int64_t* down, int64_t*
 int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* plan);
 int nsdg_halo_finish(nsdg_ctx* ctx, nsdg_halo* plan);
 
+/* ---- row-block drivers: one call per model step for the sub-cycle and for the transport of a rank's block ------
+ * The sequence of kernel passes and ghost exchanges that a multi-rank model step (IModelStep::iterate,
+ * core/src/include/IModelStep.hpp:16-34) issues, built once from the block geometry and the device arrays:
+ *   local array nx x ny (ghost rows included), owned element rows [j0, j1), nominal ghost depths
+ *   (depth_below, depth_above) -- the same on every rank -- and the neighbour ranks (-1 = physical boundary; a
+ *   rank keeps ghost rows only towards existing neighbours: j0 = depth_below or 0, j1 = ny - depth_above or ny).
+ * Kernels with v = 3 / 2 sub-iterations per pass (nsdg_mevp_variant_set) are used when the depths are (v k, v k - 1)
+ * -- k passes run between two exchanges, the ghost rows are advanced redundantly -- or when the block has no
+ * neighbours; otherwise one sub-iteration per pass with (1, 1).  Both calls are asynchronous on the context's
+ * stream.  Blocks with neighbours need a communicator (nsdg_comm_init*) before the plan is created. */
+typedef struct nsdg_rb_mevp nsdg_rb_mevp;
+typedef struct {
+    int32_t nx, ny, j0, j1;
+    int32_t depth_below, depth_above;
+    int32_t rank_below, rank_above;
+    int32_t nsub; /* sub-iterations per model step */
+    int32_t overlap; /* launch the rows whose results travel first, post the exchange, then the interior */
+    int32_t use_graph; /* replay the launches between two exchanges as one hipGraph */
+    int32_t reserved;
+    double *s11[2], *s12[2], *s22[2]; /* ping-pong: tiled stress */
+    double *u[2], *v[2]; /* ping-pong: CG2 velocity */
+    const double* packed; /* nsdg_mevp_prepare / nsdg_mevp_pack_nodal output of this step */
+    const double* pg; /* nsdg_ice_strength output of this step */
+} nsdg_rb_mevp_desc;
+int nsdg_rb_mevp_create(nsdg_ctx* ctx, const nsdg_rb_mevp_desc* desc, nsdg_rb_mevp** out);
+int nsdg_rb_mevp_destroy(nsdg_rb_mevp* plan);
+/* sub-iterations per kernel pass and passes between two exchanges the plan settled on */
+int nsdg_rb_mevp_info(const nsdg_rb_mevp* plan, int32_t* per_pass, int32_t* group_passes);
+/* nsub sub-iterations; `parity` = which of the ping-pong buffers holds the current iterate (ghost rows valid),
+ * *parity_out = which one holds the result (ghost rows refreshed) */
+int nsdg_rb_mevp_run(nsdg_ctx* ctx, nsdg_rb_mevp* plan, int32_t parity, int32_t* parity_out);
+
+#define NSDG_RB_MAX_FIELDS 4
+typedef struct nsdg_rb_transport nsdg_rb_transport;
+typedef struct {
+    int32_t nx, ny, j0, j1;
+    int32_t depth_below, depth_above;
+    int32_t rank_below, rank_above;
+    int32_t order; /* 2 */
+    int32_t nfields;
+    double* phi[NSDG_RB_MAX_FIELDS]; /* DG2 coefficient planes [6][ny][nx] of each advected field */
+    double* t1[NSDG_RB_MAX_FIELDS]; /* same size: stage buffer; receives the new state */
+    double* t2[NSDG_RB_MAX_FIELDS]; /* same size: stage buffer */
+    const double *vx_dg, *vy_dg, *un_x, *un_y; /* nsdg_prepare_advection output of this step */
+} nsdg_rb_transport_desc;
+int nsdg_rb_transport_create(nsdg_ctx* ctx, const nsdg_rb_transport_desc* desc, nsdg_rb_transport** out);
+int nsdg_rb_transport_destroy(nsdg_rb_transport* plan);
+/* one SSP-RK3 step.  parity 0: the state is in phi[], the new state (ghost rows refreshed) is written to t1[];
+ * parity 1: the other way round; *parity_out = 1 - parity */
+int nsdg_rb_transport_run(nsdg_ctx* ctx, nsdg_rb_transport* plan, double dt, int32_t parity, int32_t* parity_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,19 @@ class HaloSeg(C.Structure):
 
 
 COMM_ID_BYTES = 128
+RB_MAX_FIELDS = 4
+
+
+class RbMevpDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nx", "ny", "j0", "j1", "depth_below", "depth_above", "rank_below", "rank_above", "nsub",
+                                          "overlap", "use_graph", "reserved")] + [
+        (n, C.c_void_p * 2) for n in ("s11", "s12", "s22", "u", "v")] + [("packed", C.c_void_p), ("pg", C.c_void_p)]
+
+
+class RbTransportDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nx", "ny", "j0", "j1", "depth_below", "depth_above", "rank_below", "rank_above", "order",
+                                          "nfields")] + [
+        (n, C.c_void_p * RB_MAX_FIELDS) for n in ("phi", "t1", "t2")] + [(n, C.c_void_p) for n in ("vx_dg", "vy_dg", "un_x", "un_y")]
 
 
 class NsdgError(RuntimeError):
@@ -92,6 +105,13 @@ SYMBOLS = {
     "nsdg_halo_counts": (C.c_int, [VP] + [C.POINTER(I64)] * 4),
     "nsdg_halo_start": (C.c_int, [VP, VP]),
     "nsdg_halo_finish": (C.c_int, [VP, VP]),
+    "nsdg_rb_mevp_create": (C.c_int, [VP, C.POINTER(RbMevpDesc), C.POINTER(VP)]),
+    "nsdg_rb_mevp_destroy": (C.c_int, [VP]),
+    "nsdg_rb_mevp_info": (C.c_int, [VP, C.POINTER(I32), C.POINTER(I32)]),
+    "nsdg_rb_mevp_run": (C.c_int, [VP, VP, I32, C.POINTER(I32)]),
+    "nsdg_rb_transport_create": (C.c_int, [VP, C.POINTER(RbTransportDesc), C.POINTER(VP)]),
+    "nsdg_rb_transport_destroy": (C.c_int, [VP]),
+    "nsdg_rb_transport_run": (C.c_int, [VP, VP, D, I32, C.POINTER(I32)]),
 }
 
 _lib = None
@@ -297,6 +317,65 @@ class Context:
     def halo_plan(self, below, above, up_send, down_send, from_above, from_below):
         """plan of one kind of exchange; the arguments are lists of CONTIGUOUS tensor views (row blocks)"""
         return HaloPlanHandle(self, below, above, up_send, down_send, from_above, from_below)
+
+    # ---- row-block drivers (csrc/rowblock.hip): one call per model step
+    def _geometry(self, desc, blk, peers):
+        desc.nx, desc.ny, desc.j0, desc.j1 = blk.nx, blk.ny, blk.j0, blk.j1
+        desc.depth_below, desc.depth_above = blk.depth_below, blk.depth_above
+        desc.rank_below = -1 if peers[0] is None else peers[0]
+        desc.rank_above = -1 if peers[1] is None else peers[1]
+
+    def rb_mevp(self, blk, peers, nsub, overlap, use_graph, s2, uv2, packed, pg):
+        """native sub-cycle driver of a row block; s2 = (s, sb): two lists of three tiled stress arrays, uv2 =
+        ((u, v), (ub, vb)).  Returns run(parity) -> parity of the result and the plan's (per_pass, group_passes)."""
+        d = RbMevpDesc()
+        self._geometry(d, blk, peers)
+        d.nsub, d.overlap, d.use_graph = nsub, int(bool(overlap)), int(bool(use_graph))
+        ts = list(s2[0]) + list(s2[1]) + list(uv2[0]) + list(uv2[1]) + [packed, pg]
+        _check_f64(*ts)
+        for k in range(2):
+            d.s11[k], d.s12[k], d.s22[k] = (s2[k][i].data_ptr() for i in range(3))
+            d.u[k], d.v[k] = uv2[k][0].data_ptr(), uv2[k][1].data_ptr()
+        d.packed, d.pg = packed.data_ptr(), pg.data_ptr()
+        h = VP()
+        self._call(self.lib.nsdg_rb_mevp_create(self.h, C.byref(d), C.byref(h)))
+        per_pass, group = I32(), I32()
+        self._call(self.lib.nsdg_rb_mevp_info(h, C.byref(per_pass), C.byref(group)))
+        out, fn, ch = I32(), self.lib.nsdg_rb_mevp_run, self.h
+
+        def run(parity):
+            rc = fn(ch, h, parity, C.byref(out))
+            if rc != 0:
+                self._call(rc)
+            return out.value
+
+        run.keep = ts
+        run.handle = h
+        return run, per_pass.value, group.value
+
+    def rb_transport(self, blk, peers, phi, t1, t2, adv):
+        """native SSP-RK3 transport driver of a row block; returns run(dt, parity) -> parity of the new state"""
+        d = RbTransportDesc()
+        self._geometry(d, blk, peers)
+        d.order, d.nfields = 2, len(phi)
+        ts = list(phi) + list(t1) + list(t2) + list(adv)
+        _check_f64(*ts)
+        for i in range(len(phi)):
+            d.phi[i], d.t1[i], d.t2[i] = phi[i].data_ptr(), t1[i].data_ptr(), t2[i].data_ptr()
+        d.vx_dg, d.vy_dg, d.un_x, d.un_y = (a.data_ptr() for a in adv)
+        h = VP()
+        self._call(self.lib.nsdg_rb_transport_create(self.h, C.byref(d), C.byref(h)))
+        out, fn, ch = I32(), self.lib.nsdg_rb_transport_run, self.h
+
+        def run(dt, parity):
+            rc = fn(ch, h, float(dt), parity, C.byref(out))
+            if rc != 0:
+                self._call(rc)
+            return out.value
+
+        run.keep = ts
+        run.handle = h
+        return run
 
     # ---- arrays private to the mEVP sub-cycle (stress, ice strength) live in the tiled layout
     def private_zeros(self, nc, ny, nx, device):

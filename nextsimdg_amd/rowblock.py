@@ -261,9 +261,14 @@ class DynamicsCore:
 
     ORDER = 2
 
-    def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None, overlap=True):
+    def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None, overlap=True, native=False, use_graph=False):
         self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
         self.overlap = overlap
+        # native: the sub-cycle and the transport of a step are ONE C call each (csrc/rowblock.hip runs the same
+        # sequence of passes and exchanges as subcycle() / transport() below); needs the C-ABI ops and, with
+        # neighbours, a NativeHaloExchanger (it owns the communicator).  use_graph: replay the launches between
+        # two exchanges as one hipGraph.
+        self.native, self.use_graph = native, use_graph
         self._calls = {}
         # v sub-iterations per kernel pass (v = 3: variant 3, v = 2: variant 2) need a (v k, v k - 1) ghost depth
         # for k passes between two exchanges; a single domain has no ghosts at all.  All variants produce
@@ -294,6 +299,20 @@ class DynamicsCore:
         self.adv = (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
         self.t1 = [z(6, ny, nx), z(6, ny, nx)]
         self.t2 = [z(6, ny, nx), z(6, ny, nx)]
+        if native:
+            self._init_native()
+
+    def _init_native(self):
+        b = self.blk
+        if b.world > 1 and not isinstance(self.halo, NativeHaloExchanger):
+            raise ValueError("the native driver exchanges ghost rows through the C ABI: pass a NativeHaloExchanger")
+        peers = (self.halo.peer_below, self.halo.peer_above) if b.world > 1 else (None, None)
+        self._sbuf, self._uvbuf, self._par = (self.s, self.sb), ((self.u, self.v), (self.ub, self.vb)), 0
+        self._run_mevp, per_pass, group = self.ops.rb_mevp(b, peers, self.nsub, self.overlap, self.use_graph, self._sbuf, self._uvbuf,
+                                                           self.packed, self.pg)
+        assert (per_pass, group) == (self.per_pass, self.group_passes), "native plan and driver disagree on the pass structure"
+        self._fbuf, self._tpar = ((self.H, self.A), (self.t1[0], self.t1[1])), 0
+        self._run_transport = self.ops.rb_transport(b, peers, self._fbuf[0], self._fbuf[1], self.t2, self.adv)
 
     def load_global(self, H, A, uo, vo, ua, va, u=None, v=None):
         """fill the local arrays (ghost rows included) from global numpy arrays"""
@@ -336,6 +355,11 @@ class DynamicsCore:
     def subcycle(self):
         """the nsub mEVP sub-iterations of one model step (ghost rows exchanged as the ghost depth requires)"""
         ops, b = self.ops, self.blk
+        if self.native:
+            par = self._par = self._run_mevp(self._par)
+            self.s, self.sb = self._sbuf[par], self._sbuf[1 - par]
+            (self.u, self.v), (self.ub, self.vb) = self._uvbuf[par], self._uvbuf[1 - par]
+            return
         it = 0
         if self.per_pass >= 2:
             # v sub-iterations per pass (the intermediate stress / velocity stay on chip).  With several ranks the
@@ -456,6 +480,10 @@ class DynamicsCore:
     def transport(self):
         ops, b = self.ops, self.blk
         ops.prepare_advection(self.ORDER, self.u, self.v, *self.adv)
+        if self.native:
+            par = self._tpar = self._run_transport(self.dt, self._tpar)
+            (self.H, self.A), (self.t1[0], self.t1[1]) = self._fbuf[par], self._fbuf[1 - par]
+            return
         f = [self.H, self.A]
         # Shu-Osher SSP-RK3: out = a*phi0 + b*(phis + dt L(phis)).  A stage reads one element row on each side
         # of the rows it updates: with at least 3 ghost rows per interior side the first two stages also
