@@ -15,8 +15,11 @@
  *  - One context per GPU/stream.  Calls on one context must not be issued concurrently from two
  *    host threads; different contexts are independent.  (The reference is single-threaded and
  *    non-re-entrant: static m_dt / m_freezer, core/src/PrognosticData.cpp:12-13.)
- *  - NaN/Inf propagate as in the reference: no clamping or input checking is added to the physics
- *    (SURVEY.md section 8b "Errors").
+ *  - No clamping or input checking is added to the physics (SURVEY.md section 8b "Errors").  Input domain of the
+ *    column step: slp > 0, temperatures above -250 C, finite values.  Inside it the results follow the reference's
+ *    arithmetic, including its Inf / NaN for mld == 0, dt == 0 or vanishing fluxes (those divisions are IEEE
+ *    divisions; csrc/column_step.hip lists them).  Outside it (e.g. slp == 0) the reciprocal-based divisions of the
+ *    saturation-pressure and density formulae return NaN where IEEE division would return Inf.
  *
  * Data layout
  *  - element (ix, iy) of an nx x ny local array, ix fastest:  e = iy*nx + ix.  (The reference's
@@ -172,11 +175,30 @@ int nsdg_dg_to_cg(nsdg_ctx* ctx, int32_t ncoef, const double* f_dg, double* f_cg
 /* P = pstar * max(H,0) * exp(-C (1 - clamp(A,0,1))) at the 3x3 Gauss points of rows [j0, j1) */
 int nsdg_ice_strength(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* H, const double* A, double* pg);
 
-/* Analytic forcing provider for the square box test of side domain_size [m] at model time t [s], evaluated on
- * the device on the CG2 lattice of the local array (which must start at the domain's origin): cyclone wind
- * (ua, va) and circular ocean current (uo, vo); either pair may be NULL.  Stands in for the reference's constant
- * DummyExternalData (core/src/include/DummyExternalData.hpp:22-34) on the dynamics side. */
+/* ---- external forcing providers, evaluated on the device at the model time of each step (csrc/forcing.hip) ----
+ * They replace DummyExternalData::setAll (core/src/include/DummyExternalData.hpp:22-34: the same eight constants in
+ * every element, set once) and fill PhysicsData::windSpeed (physics/src/include/PhysicsData.hpp:26,44), which a run
+ * of the reference never sets.
+ *
+ * Placement of the local array in the global domain for these providers: local element row 0 is global row `row0`
+ * of `ny_global` rows (defaults 0 and the local ny: a single domain).  A row block then evaluates the very
+ * expressions the single domain evaluates, bit for bit. */
+int nsdg_block_set(nsdg_ctx* ctx, int32_t row0, int32_t ny_global);
+
+/* Square box test of side domain_size [m] at model time t [s] on the CG2 lattice of the local array: cyclone wind
+ * (ua, va), its centre drifting along the diagonal, and circular ocean current (uo, vo); either pair may be NULL. */
 int nsdg_boxtest_forcing(nsdg_ctx* ctx, double domain_size, double t, double* ua, double* va, double* uo, double* vo);
+
+/* Thermodynamic forcing planes of the column step (nx*ny doubles each) at model time t [s]:
+ * NSDG_FORCING_DUMMY = the reference's constants (tair -1, tdew -4, slp 1e5, qsw 0, qlw 311, mld 10, snowfall 0);
+ * NSDG_FORCING_WINTER = smooth winter fields in the ranges of SURVEY.md section 8(d): a synoptic pattern drifting eastwards
+ * with a 5-day period and a diurnal cycle of the short-wave flux. */
+enum { NSDG_FORCING_DUMMY = 0, NSDG_FORCING_WINTER = 1 };
+int nsdg_column_forcing(nsdg_ctx* ctx, int32_t kind, double t, double* tair, double* tdew, double* slp, double* qsw, double* qlw,
+    double* mld, double* snowfall);
+
+/* wind speed of the column step = |u_a| at the element centre (CG2 node (2 ix + 1, 2 iy + 1)) */
+int nsdg_column_wind(nsdg_ctx* ctx, const double* ua, const double* va, double* wind);
 
 /* tau_a = c_atm * rho_atm * |u_a| u_a at nnodes nodes */
 int nsdg_wind_stress(nsdg_ctx* ctx, int64_t nnodes, const double* ua, const double* va, double* tax, double* tay);

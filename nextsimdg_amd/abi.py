@@ -83,6 +83,9 @@ SYMBOLS = {
     "nsdg_dg_to_cg": (C.c_int, [VP, I32, VP, VP]),
     "nsdg_ice_strength": (C.c_int, [VP, I32, I32, VP, VP, VP]),
     "nsdg_boxtest_forcing": (C.c_int, [VP, D, D, VP, VP, VP, VP]),
+    "nsdg_block_set": (C.c_int, [VP, I32, I32]),
+    "nsdg_column_forcing": (C.c_int, [VP, I32, D] + [VP] * 7),
+    "nsdg_column_wind": (C.c_int, [VP, VP, VP, VP]),
     "nsdg_wind_stress": (C.c_int, [VP, I64, VP, VP, VP, VP]),
     "nsdg_mevp_stress": (C.c_int, [VP, I32, I32] + [VP] * 6),
     "nsdg_mevp_pack_nodal": (C.c_int, [VP, D] + [VP] * 9),
@@ -473,6 +476,20 @@ class Context:
         ts = list(wind or (None, None)) + list(ocean or (None, None))
         _check_f64(*ts)
         self._call(self.lib.nsdg_boxtest_forcing(self.h, float(domain_size), float(t), *[_ptr(x) for x in ts]))
+
+    def set_block(self, row0, ny_global):
+        """placement of the local array in the global domain (analytic forcing providers)"""
+        self._call(self.lib.nsdg_block_set(self.h, int(row0), int(ny_global)))
+
+    def column_forcing(self, kind, t, forcing):
+        """thermodynamic forcing planes at model time t; kind: "dummy" (the reference's constants) or "winter" """
+        ts = [forcing[k] for k in ("tair", "tdew", "slp", "qsw", "qlw", "mld", "snowfall")]
+        _check_f64(*ts)
+        self._call(self.lib.nsdg_column_forcing(self.h, {"dummy": 0, "winter": 1}[kind], float(t), *[_ptr(x) for x in ts]))
+
+    def column_wind(self, ua, va, wind):
+        _check_f64(ua, va, wind)
+        self._call(self.lib.nsdg_column_wind(self.h, _ptr(ua), _ptr(va), _ptr(wind)))
 
     def wind_stress(self, ua, va, tax, tay):
         _check_f64(ua, va, tax, tay)

@@ -44,9 +44,14 @@ __device__ __forceinline__ double kelvin(double c) { return c + WATER_TF; } // c
 //                   a launch parameter such as dt (3 instructions)
 // Both return the quotient to within one ulp (the residual step makes it the correctly rounded one in all but
 // a few per mille of the cases), far inside the 1e-13 parity tolerance.  What they drop is the range scaling and
-// the special-case fix-up: every denominator of the column physics is finite and non-zero for physical input
-// (the reference guards the only data-dependent zero, conc == 0, itself); a zero or non-finite denominator
-// yields NaN here where IEEE division yields Inf or 0.
+// the special-case fix-up: a zero, subnormal or non-finite denominator (or a non-finite numerator) yields NaN
+// where IEEE division yields Inf or 0.  They are therefore used only where the denominator is bounded away
+// from zero for every input of the documented domain (include/nsdg.h: pressures and absolute temperatures
+// positive, temperatures above -250 C): saturation-pressure and density formulae, the albedo weights, and
+// conc + del_c >= min_conc, which the reference tests itself.  The divisions whose denominator is a FREE input
+// or a difference of data -- the mixed-layer heat capacity (mld), deltaTml, the slab conductance and the
+// surface-temperature Newton step, and dt -- are IEEE divisions, so that mld == 0, dt == 0 or a vanishing flux
+// give the reference's Inf / 0 / NaN, bit for bit (tests: zero-denominator cases against the oracle).
 __device__ __forceinline__ double qdiv(double a, double b)
 {
     double r = __builtin_amdgcn_rcp(b);
@@ -128,6 +133,9 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     const double h_true = (conc != 0) ? rdiv(thick, conc, rconc) : 0;
     const double hs_true = (conc != 0) ? rdiv(snow, conc, rconc) : 0;
     const double idt = 1.0 / dt; // launch parameter: one IEEE division per lane
+    // x / dt: the 3-instruction form when dt is an ordinary number (wave-uniform test), IEEE otherwise (dt == 0 -> +-Inf)
+    const bool dt_regular = isnormal(dt) && isnormal(idt);
+    auto div_dt = [&](double a) { return dt_regular ? rdiv(a, dt, idt) : a / dt; };
     const double tf = freezing_point(P.freezing_kind, sss);
     const double mlbhc = mld * WATER_RHOOCEAN * WATER_CP;
 
@@ -178,7 +186,7 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     const double Qia = Qlhi + Qshi + Qlwi + Qswi;
     const double dQ_dT = dQlh_dT + dQsh_dT + dQlw_dT;
     // ice-ocean :222-226 -> BasicIceOceanHeatFlux.cpp:16-25
-    double Qio = rdiv((sst - tf) * mlbhc, dt, idt);
+    double Qio = div_dt((sst - tf) * mlbhc); // BasicIceOceanHeatFlux.cpp:24
 
     // ---- massFluxIceOcean :200-220
     double hifroms = 0;
@@ -192,10 +200,10 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
             hs = 0;
             Tnew = freezingPointIce;
         } else {
-            const double k_lSlab = qdiv(P.ks * ICE_KAPPA, P.ks * h_true + ICE_KAPPA * hs_true); // :58-59
+            const double k_lSlab = (P.ks * ICE_KAPPA) / (P.ks * h_true + ICE_KAPPA * hs_true); // :58-59 (IEEE: data-dependent denominator)
             const double QIceConduction = k_lSlab * (tf - tice); // :60
             const double remainingFlux = QIceConduction - Qia; // :61
-            Tnew = tice + qdiv(remainingFlux, k_lSlab + dQ_dT); // :62-63
+            Tnew = tice + remainingFlux / (k_lSlab + dQ_dT); // :62-63 (IEEE)
             Tnew = fmin((hs_true > 0.) ? 0. : freezingPointIce, Tnew); // :66-68
             const double snowMeltRate = CDIV(fmin(-remainingFlux, 0.), bulkLHFusionSnow); // :71
             const double snowSublRate = CDIV(subl, ICE_RHOSNOW); // :72
@@ -214,7 +222,7 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
             }
             if (hi < P.min_thick) { // :108-132
                 hifroms = 0;
-                Qio += rdiv(hi * bulkLHFusionIce, dt, idt) + rdiv(hs * bulkLHFusionSnow, dt, idt);
+                Qio += div_dt(hi * bulkLHFusionIce) + div_dt(hs * bulkLHFusionSnow);
                 hi = 0;
                 hs = 0;
                 Tnew = freezingPointIce;
@@ -223,10 +231,10 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     }
     { // newIceFormation :228-254; newice keeps its old value when the branch is not taken (A.7 quirk 1)
         const double coolingFlux = Qow;
-        const double deltaTml = qdiv(-coolingFlux, mlbhc) * dt;
+        const double deltaTml = -coolingFlux / mlbhc * dt; // :236 (IEEE: mld == 0 gives -+Inf as in the reference)
         const double t1 = sst + deltaTml;
         if (t1 < tf) {
-            const double sensibleFlux = qdiv(tf - sst, deltaTml) * coolingFlux;
+            const double sensibleFlux = (tf - sst) / deltaTml * coolingFlux; // :241 (IEEE)
             const double latentFlux = coolingFlux - sensibleFlux;
             Qow = sensibleFlux;
             newice = CDIV(latentFlux * dt * (1 - conc), ICE_LF * ICE_RHO);
@@ -242,13 +250,13 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
             const double rc = qdiv(1.0, conc + del_c);
             hi += rdiv(newice - hi * del_c, conc + del_c, rc); // updateThickness :257-260
             if (del_c < 0)
-                Qow -= rdiv(del_c * hs * ICE_LF * ICE_RHOSNOW, dt, idt);
+                Qow -= div_dt(del_c * hs * ICE_LF * ICE_RHOSNOW);
             else
                 hs += rdiv(0. - hs * del_c, conc + del_c, rc);
         }
     }
     if (c_new < P.min_conc || hi < P.min_thick) { // :211-219
-        Qow += rdiv(c_new * ICE_LF * (hi * ICE_RHO + hs * ICE_RHOSNOW), dt, idt);
+        Qow += div_dt(c_new * ICE_LF * (hi * ICE_RHO + hs * ICE_RHOSNOW));
         c_new = 0;
         hi = 0;
         hs = 0;

@@ -319,35 +319,6 @@ __global__ __launch_bounds__(256) void wind_stress_kernel(long n, double f_atm, 
     wind_tau(f_atm, ua[i], va[i], tax[i], tay[i]);
 }
 
-// Analytic forcing of the 512 km box test on the CG2 lattice at model time t (seconds): circular ocean
-// current and a cyclone whose centre drifts along the diagonal.  Replaces the reference's constant
-// DummyExternalData (core/src/include/DummyExternalData.hpp:22-34) for the dynamics; same formulae as
-// nextsimdg_amd/synthetic.py (BoxTest.ocean / BoxTest.wind).
-__global__ __launch_bounds__(256) void boxtest_forcing_kernel(int nx, int ny, double L, double t, double* __restrict__ ua,
-    double* __restrict__ va, double* __restrict__ uo, double* __restrict__ vo)
-{
-    const int gx = blockIdx.x * 64 + threadIdx.x;
-    const int gy = blockIdx.y * 4 + threadIdx.y;
-    const int nn = 2 * nx + 1, nm = 2 * ny + 1;
-    if (gx >= nn || gy >= nm)
-        return;
-    const long n = (long)gy * nn + gx;
-    const double x = gx * (L / (2 * nx)), y = gy * (L / (2 * ny));
-    if (uo) {
-        uo[n] = 0.01 * (2 * y - L) / L;
-        vo[n] = 0.01 * (L - 2 * x) / L;
-    }
-    if (ua) {
-        const double cm = 0.5 * L + 0.1 * L * t / 86400.0 / 4.0;
-        const double ca = 0.30901699437494745, sa = 0.95105651629515353; // cos / sin of 72 degrees
-        const double R = 0.2 * L;
-        const double dx = cm - x, dy = cm - y;
-        const double s = 15.0 * exp(-sqrt(dx * dx + dy * dy) / R) / R;
-        ua[n] = s * (ca * dx + sa * dy) * R / 1e5;
-        va[n] = s * (-sa * dx + ca * dy) * R / 1e5;
-    }
-}
-
 } // namespace nsdg_mevp_detail
 
 using namespace nsdg_mevp_detail;
@@ -408,20 +379,6 @@ int nsdg_ice_strength(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* H, co
     const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4));
     hipLaunchKernelGGL(ice_strength_kernel, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, ctx->mevp.pstar,
         ctx->mevp.compaction, H, A, pg);
-    NSDG_CHECK_LAUNCH();
-    return NSDG_OK;
-}
-
-int nsdg_boxtest_forcing(nsdg_ctx* ctx, double domain_size, double t, double* ua, double* va, double* uo, double* vo)
-{
-    NSDG_NEED_GRID(ctx);
-    NSDG_CHECK_ARG(domain_size > 0, "domain size must be positive");
-    NSDG_CHECK_ARG((ua != nullptr) == (va != nullptr) && (uo != nullptr) == (vo != nullptr), "wind / ocean components come in pairs");
-    if (!ua && !uo)
-        return NSDG_OK;
-    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    const dim3 block(64, 4), grid(nsdg_div_up(2 * ctx->nx + 1, 64), nsdg_div_up(2 * ctx->ny + 1, 4));
-    hipLaunchKernelGGL(boxtest_forcing_kernel, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, domain_size, t, ua, va, uo, vo);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }

@@ -75,6 +75,7 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     nsdg_column_default_params(&c->column);
     nsdg_mevp_default_params(&c->mevp);
     c->nx = c->ny = 0;
+    c->row0 = c->ny_global = 0;
     c->hx = c->hy = 0.;
     c->mevp_variant = 3;
     c->strip_rows = 0;

@@ -15,6 +15,7 @@ struct nsdg_ctx {
     nsdg_column_params column;
     nsdg_mevp_params mevp;
     int nx, ny; // local element array
+    int row0, ny_global; // its placement in the global domain (analytic forcing providers); ny_global 0 = single domain
     double hx, hy;
     int mevp_variant;
     int strip_rows; // rows per strip of the fused marching kernel (0 = chosen per launch)

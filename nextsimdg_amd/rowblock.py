@@ -330,6 +330,14 @@ class DynamicsCore:
 
     def _set_grid(self):
         self.ops.set_grid(self.blk.nx, self.blk.ny, self.hx, self.hy)
+        place = getattr(self.ops, "set_block", None)
+        if place is not None:  # where the local array sits in the global domain (device-side forcing providers)
+            place(self.blk.lo, self.blk.ny_glob)
+
+    def device_wind(self, domain_size, t):
+        """cyclone wind of the box test at model time t, evaluated on the device for this rank's rows"""
+        self._set_grid()
+        self.ops.boxtest_forcing(domain_size, t, wind=(self.ua, self.va))
 
     def momentum(self):
         self.prepare()
@@ -532,11 +540,16 @@ class CoupledCore(DynamicsCore):
     COLUMN_STATE = ("hsnow", "tice0")
     COLUMN_FORCING = ("sst", "sss", "tair", "tdew", "slp", "qsw", "qlw", "mld", "snowfall", "wind")
 
-    def __init__(self, ops, blk, hx, hy, dt, nsub, device, **kw):
+    def __init__(self, ops, blk, hx, hy, dt, nsub, device, forcing=None, **kw):
+        """forcing: None = the forcing planes are whatever load_column() put there (constant in time);
+        "dummy" / "winter" = regenerated on the device at every step's model time (nsdg_column_forcing) and the
+        column wind speed is |u_a| of the dynamics' wind (nsdg_column_wind) -- the replacement of the reference's
+        DummyExternalData (core/src/include/DummyExternalData.hpp:22-34) and of its never-set windSpeed"""
         super().__init__(ops, blk, hx, hy, dt, nsub, device, **kw)
         z = lambda: torch.zeros(blk.ny, blk.nx, dtype=torch.float64, device=device)
         self.col = {k: z() for k in self.COLUMN_STATE + self.COLUMN_FORCING}
         self.newice = z()
+        self.forcing, self.time = forcing, 0.0
 
     def load_column(self, fields):
         """fields: dict name -> global [ny, nx] numpy array for hsnow, tice0 and the 10 forcing fields"""
@@ -551,8 +564,15 @@ class CoupledCore(DynamicsCore):
         forcing = {k: self.col[k] for k in self.COLUMN_FORCING}
         self.ops.column_step(self.dt, state, forcing, self.newice)
 
+    def external_forcing(self):
+        if self.forcing is not None:
+            self.ops.column_forcing(self.forcing, self.time, self.col)
+            self.ops.column_wind(self.ua, self.va, self.col["wind"])
+
     def step(self):
         self._set_grid()
+        self.external_forcing()
         self.thermodynamics()
         self.momentum()
         self.transport()
+        self.time += self.dt

@@ -134,6 +134,66 @@ def test_column_edge_cases(ctx):
         ctx.set_column_params(ctx.column_default_params(albedo_kind=7))
 
 
+def same_class(g, w):
+    """NaN where NaN, +Inf where +Inf, -Inf where -Inf"""
+    return (np.array_equal(np.isnan(g), np.isnan(w)) and np.array_equal(np.isposinf(g), np.isposinf(w))
+            and np.array_equal(np.isneginf(g), np.isneginf(w)))
+
+
+@pytest.mark.parametrize("dt", [600.0, 0.0])
+def test_column_zero_denominators_follow_the_reference_arithmetic(ctx, dt):
+    """The divisions of the reference whose denominator is a free input or a difference of data
+    (NextsimPhysics.cpp:236,241 -- mixed-layer heat capacity and deltaTml; BasicIceOceanHeatFlux.cpp:24 and the other
+    x/dt; ThermoIce0.cpp:58-63) are IEEE divisions on the device too: a zero mixed-layer depth, dt == 0, a flux
+    that vanishes exactly, a concentration at the cut-off and an Inf forcing value give the oracle's Inf / NaN /
+    finite values in every state variable and diagnostic, class for class and to 1e-11 where finite."""
+    n = 4096
+    state, forcing, newice = synthetic.column_fields(n, seed=99)
+    rng = np.random.default_rng(5)
+    forcing["mld"][rng.random(n) < 0.25] = 0.0  # mlbhc == 0: deltaTml = -+Inf (or NaN when the cooling flux is 0 too)
+    state["cice"][rng.random(n) < 0.1] = 1e-12  # exactly min_conc
+    state["cice"][rng.random(n) < 0.05] = 1e-13  # below it
+    state["hice"][rng.random(n) < 0.05] = 5e-324  # subnormal thickness
+    forcing["qlw"][:7] = np.inf
+    # a column whose open-water flux vanishes exactly is not constructible from inputs; a zero wind and equal
+    # temperatures remove all turbulent fluxes instead
+    forcing["wind"][rng.random(n) < 0.3] = 0.0
+    po = O.column_params()
+    ctx.set_column_params(ctx.column_default_params())
+    ds, df, dn = {k: dev(v) for k, v in state.items()}, {k: dev(v) for k, v in forcing.items()}, dev(newice)
+    diag = torch.zeros(abi.NDIAG, n, dtype=torch.float64, device="cuda")
+    for step in range(3):
+        with np.errstate(all="ignore"):
+            want = O.column_step(po, dt, state, forcing, newice, want_diag=True)
+        ctx.column_step(dt, ds, df, dn, diag)
+        got = {k: host(ds[k]) for k in abi.STATE}
+        got["newice"] = host(dn)
+        wantv = dict(state, newice=newice)
+        for k in list(abi.STATE) + ["newice"]:
+            assert same_class(got[k], wantv[k]), (step, k)
+            fin = np.isfinite(wantv[k])
+            assert_close(got[k][fin], wantv[k][fin], 1e-11, 1e-13, "step %d %s" % (step, k))
+        d = host(diag)
+        for i, k in enumerate(abi.DIAG):
+            assert same_class(d[i], want[k]), (step, k)
+            fin = np.isfinite(want[k])
+            scale = np.max(np.abs(want[k][fin])) if fin.any() else 1.0
+            assert_close(d[i][fin], want[k][fin], 1e-10, 1e-13 * scale, "step %d diag %s" % (step, k))
+        for k in abi.STATE:  # re-synchronise (see test_column_step_matches_oracle)
+            state[k][:] = got[k]
+        newice[:] = got["newice"]
+    if dt > 0:
+        assert np.isfinite(state["hice"]).mean() > 0.7  # the irregular inputs poison their own columns only
+    # the production (two elements per lane, no diagnostics) kernel gives the same state as the diagnostic one
+    ds2, dn2 = {k: dev(v) for k, v in state.items()}, dev(newice)
+    ds3, dn3 = {k: dev(v) for k, v in state.items()}, dev(newice)
+    ctx.column_step(dt, ds2, df, dn2, None)
+    ctx.column_step(dt, ds3, df, dn3, diag)
+    for k in abi.STATE:
+        a, b = host(ds2[k]), host(ds3[k])
+        assert same_class(a, b) and np.array_equal(a[np.isfinite(a)], b[np.isfinite(b)]), k
+
+
 # ------------------------------------------------------------------------------------ DG transport
 def adv_on_device(ctx, nx, ny, order, u, v):
     nc, ng = basis.NCOEF[order], order + 1

@@ -70,7 +70,7 @@ _local_group = [1000]  # ids of the in-process communicator groups of csrc/halo.
 
 
 def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, overlap, group=1, data=None, column=None,
-             alpha=300.0, keep=("H", "A", "u", "v", "s11"), transport="mailbox", local_group=None):
+             alpha=300.0, keep=("H", "A", "u", "v", "s11"), transport="mailbox", local_group=None, native=False, use_graph=False, core_kw=None):
     try:
         ctx = abi.Context(torch.device("cuda:0"))
         ctx.set_mevp_variant(variant)
@@ -83,7 +83,9 @@ def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, 
             exchanger = rowblock.NativeHaloExchanger(ctx, blk, local_group=local_group) if world > 1 else None
         else:
             exchanger = ThreadExchanger(blk, mailbox)
-        core = cls(ctx, blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cuda"), exchanger=exchanger, overlap=overlap)
+        # native: sub-cycle and transport are one C call each (csrc/rowblock.hip) instead of the Python sequence
+        core = cls(ctx, blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cuda"), exchanger=exchanger, overlap=overlap, native=native,
+                   use_graph=use_graph, **(core_kw or {}))
         core.load_global(H, A, uo, vo, ua, va)
         if coupled:
             if column is None:

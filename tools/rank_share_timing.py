@@ -1,7 +1,8 @@
 """Diagnostic: GPU time of ONE rank's share of the 2048x2048 dynamics step for a world of W row blocks, measured
 on a single GPU with the ghost exchanges replaced by no-ops (the values in the ghost rows go stale, only the
 timing is meaningful).  Gives the compute-side bound on the strong-scaling speed-up that the 8-GPU run of the
-driver can reach: T(1 block) / T(share).  usage: python tools/rank_share_timing.py [--halo native|torch] [--rccl-loopback] [--no-overlap] [--k K,...] [W ...]"""
+driver can reach: T(1 block) / T(share).  usage: python tools/rank_share_timing.py [--native [--graph]] [--halo native|torch] [--rccl-loopback] [--no-overlap] [--k K,...] [W ...]"""
+import gc
 import os
 import sys
 import time
@@ -45,7 +46,7 @@ def check_loopback_values(core):
     return n
 
 
-def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopback=False, halo="native"):
+def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopback=False, halo="native", native=False, graph=False):
     dev = torch.device("cuda:0")
     ctx = abi.Context(dev)
     L, dt = 512e3, 120.0
@@ -67,13 +68,16 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
             exchanger = rowblock.HaloExchanger(blk, loopback=True)
     elif world > 1:
         exchanger = NullExchanger(blk)
-    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=exchanger, overlap=overlap)
+    if native and world > 1 and not isinstance(exchanger, rowblock.NativeHaloExchanger):
+        raise SystemExit("--native needs --rccl-loopback with the native halo (or world 1)")
+    core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, exchanger=exchanger, overlap=overlap, native=native, use_graph=graph)
     H, A = bt.dg_fields()
     uo, vo = bt.ocean()
     ua, va = bt.wind(0.0)
     core.load_global(H, A, uo, vo, ua, va)
     core.step()
     torch.cuda.synchronize()
+    gc.collect()  # contexts and plans of earlier runs die here (hipFree synchronises), not inside the timed loop
     t0 = time.perf_counter()
     for _ in range(steps):
         core.step()
@@ -88,7 +92,13 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
 if __name__ == "__main__":
     ks = (1, 4)
     args = sys.argv[1:]
-    overlap, loopback, halo = True, False, "native"
+    overlap, loopback, halo, native, graph = True, False, "native", False, False
+    if args and args[0] == "--native":  # sub-cycle and transport as one C call each (csrc/rowblock.hip)
+        native = True
+        args = args[1:]
+    if args and args[0] == "--graph":  # ... with the launches between two exchanges replayed as one hipGraph
+        graph = True
+        args = args[1:]
     if args and args[0] == "--halo":  # native (default): exchanges behind the C ABI; torch: torch.distributed P2P ops
         halo = args[1]
         args = args[2:]
@@ -112,9 +122,9 @@ if __name__ == "__main__":
     base = None
     for w in worlds:
         for k in ((1,) if w == 1 else ks):
-            ms, host_ms, rows = run(w, k, overlap=overlap, loopback=loopback, halo=halo)
+            ms, host_ms, rows = run(w, k, overlap=overlap, loopback=loopback, halo=halo, native=native, graph=graph)
             base = ms if w == 1 else base
-            print(("RCCL loopback (%s halo)  " % halo if loopback else "") + ("" if overlap else "no-overlap  ") + "world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
+            print(("native driver%s  " % (" + graphs" if graph else "") if native else "") + ("RCCL loopback (%s halo)  " % halo if loopback else "") + ("" if overlap else "no-overlap  ") + "world %d  passes/exchange %d  local rows %4d  step %7.3f ms  (host issue %6.3f ms)  speed-up bound %s"
                   % (w, k, rows, ms, host_ms, "%.2f" % (base / ms) if base else "-"), flush=True)
     if loopback and halo == "torch":
         import torch.distributed as dist
