@@ -49,8 +49,8 @@ __device__ __forceinline__ double kelvin(double c) { return c + WATER_TF; } // c
 // from zero for every input of the documented domain (include/nsdg.h: pressures and absolute temperatures
 // positive, temperatures above -250 C): saturation-pressure and density formulae, the albedo weights, and
 // conc + del_c >= min_conc, which the reference tests itself.  The divisions whose denominator is a FREE input
-// or a difference of data -- the mixed-layer heat capacity (mld), deltaTml, the slab conductance and the
-// surface-temperature Newton step, and dt -- are IEEE divisions, so that mld == 0, dt == 0 or a vanishing flux
+// or a difference of data -- the concentration and the true thickness, the mixed-layer heat capacity (mld), deltaTml,
+// the slab conductance and the surface-temperature Newton step, and dt -- are IEEE divisions, so that mld == 0, dt == 0 or a vanishing flux
 // give the reference's Inf / 0 / NaN, bit for bit (tests: zero-denominator cases against the oracle).
 __device__ __forceinline__ double qdiv(double a, double b)
 {
@@ -129,9 +129,9 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     double newice = in.newice;
 
     // PrognosticData.hpp:56,75,78; ExternalData.hpp:60
-    const double rconc = qdiv(1.0, conc); // NaN for conc == 0, never used then
-    const double h_true = (conc != 0) ? rdiv(thick, conc, rconc) : 0;
-    const double hs_true = (conc != 0) ? rdiv(snow, conc, rconc) : 0;
+    // true thicknesses: IEEE divisions (conc is a free input; a subnormal concentration must not turn into NaN)
+    const double h_true = (conc != 0) ? thick / conc : 0;
+    const double hs_true = (conc != 0) ? snow / conc : 0;
     const double idt = 1.0 / dt; // launch parameter: one IEEE division per lane
     // x / dt: the 3-instruction form when dt is an ordinary number (wave-uniform test), IEEE otherwise (dt == 0 -> +-Inf)
     const bool dt_regular = isnormal(dt) && isnormal(idt);
@@ -177,7 +177,7 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     const double dQlh_dT = Li * (P.drag_ice_t * rho * wind * dq_dT);
     const double Qshi = P.drag_ice_t * rho * cspec * wind * (tice - tair);
     const double dQsh_dT = P.drag_ice_t * rho * cspec * wind;
-    const double albedoValue = ice_albedo(P, tice, (conc > 0) ? rdiv(snow, conc, rconc) : 0.);
+    const double albedoValue = ice_albedo(P, tice, (conc > 0) ? hs_true : 0.); // :183 snow / conc for conc > 0
     const double Qswi = -qsw * (1. - P.i0) * (1 - albedoValue);
     const double ticeK = kelvin(tice), ticeK2 = ticeK * ticeK;
     const double sb_i = ICE_EPSILON * SIGMA * (ticeK2 * ticeK2);
@@ -244,7 +244,7 @@ __device__ __forceinline__ ColumnOut column_element(const nsdg_column_params& P,
     { // lateralGrowth :262-289 with HiblerConcentration.cpp:32-47
         double del_c = newice * (1. / P.h0);
         if (hi < h_true && !(conc >= 1))
-            del_c += qdiv((hi - h_true) * conc * P.phi_m, h_true);
+            del_c += (hi - h_true) * conc * P.phi_m / h_true; // HiblerConcentration.cpp:40-47 (IEEE: h is data)
         c_new = conc + del_c;
         if (c_new >= P.min_conc) {
             const double rc = qdiv(1.0, conc + del_c);

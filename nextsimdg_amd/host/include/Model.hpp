@@ -78,17 +78,18 @@ inline void Model::configure()
     initialFileName = getConfiguration(keyMap.at(RESTARTFILE_KEY), std::string(""));
     finalFileName = getConfiguration(keyMap.at(FINALFILE_KEY), finalFileName);
     modelStep->setInitFile(initialFileName);
-    const std::string type = RectGrid::typeInFile(initialFileName);
-    if (!type.empty()) { // NetCDF-4 (HDF5 subset reader) or the raw sidecar
+    if (!initialFileName.empty()) {
+        // as the reference (core/src/Model.cpp:59-62): the named restart file MUST be readable; a missing, truncated
+        // or unsupported file stops the run (std::runtime_error / Hdf5Error / std::invalid_argument) instead of
+        // silently starting from something else
         dataStructure = StructureFactory::generateFromFile(initialFileName);
         dataStructure->init(initialFileName);
-        std::cout << "Initial state read from " << initialFileName << " (structure " << type << ", " << dataStructure->nx() << " x "
-                  << dataStructure->ny() << ")" << std::endl;
-    } else { // no such file: constants from the init.* keys (defaults = run/dev_res.py:10-20 of the reference)
+        std::cout << "Initial state read from " << initialFileName << " (structure " << dataStructure->structureType() << ", "
+                  << dataStructure->nx() << " x " << dataStructure->ny() << ")" << std::endl;
+    } else { // no init file configured: constants from the init.* keys (defaults = run/dev_res.py:10-20 of the reference)
         dataStructure = StructureFactory::generate(getConfiguration(keyMap.at(STRUCTURE_KEY), std::string("devgrid")));
         dataStructure->init("");
-        if (!initialFileName.empty())
-            std::cout << "Initial file " << initialFileName << " not found or not a restart file: constant initial state" << std::endl;
+        std::cout << "No model.init_file: constant initial state from the [init] keys" << std::endl;
     }
     modelStep->setInitialData(*dataStructure);
     modelStep->init();

@@ -34,8 +34,9 @@ public:
     ElementData& cursorData() override { return m_current; }
     void incrCursor() override;
 
-    //! Reads the structure type recorded in a restart file ("" if unreadable).
-    static std::string typeInFile(const std::string& filePath);
+    //! Reads the structure type recorded in a restart file ("" if unreadable; throwOnError: a corrupt or
+    //! unsupported HDF5 file raises Hdf5Error instead).
+    static std::string typeInFile(const std::string& filePath, bool throwOnError = false);
 
 protected:
     int m_nx, m_ny;

@@ -115,12 +115,14 @@ bool readHeader(std::istream& f, std::string& type, int& nx, int& ny, int& nl)
 }
 } // namespace
 
-std::string RectGrid::typeInFile(const std::string& filePath)
+std::string RectGrid::typeInFile(const std::string& filePath, bool throwOnError)
 {
     if (Hdf5File::isHdf5(filePath)) { // the reference's NetCDF-4 layout: group "structure", attribute "type" (StructureFactory.cpp:46-58)
         try {
             return Hdf5File(filePath).stringAttribute("/" + metadataNodeName(), typeNodeName());
         } catch (const Hdf5Error&) {
+            if (throwOnError)
+                throw; // a corrupt or unsupported file must stop the run with the reader's message
             return std::string();
         }
     }
@@ -251,7 +253,12 @@ std::shared_ptr<IStructure> StructureFactory::generate(const std::string& struct
 
 std::shared_ptr<IStructure> StructureFactory::generateFromFile(const std::string& filePath)
 {
-    const std::string type = RectGrid::typeInFile(filePath);
+    {
+        std::ifstream probe(filePath, std::ios::binary);
+        if (!probe)
+            throw std::runtime_error("StructureFactory::generateFromFile: cannot open " + filePath);
+    }
+    const std::string type = RectGrid::typeInFile(filePath, true);
     if (type.empty())
         throw std::invalid_argument("StructureFactory::generateFromFile: no structure type in " + filePath);
     return generate(type);

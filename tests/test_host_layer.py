@@ -73,8 +73,32 @@ def test_executable_fails_loudly_without_gpu(host_build):
 
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
-    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg")], cwd="/tmp")
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg")], cwd=GOLDEN)
     assert rc != 0 and "no HIP device" in out
+
+
+def test_unreadable_init_file_stops_the_run(host_build, tmp_path):
+    """the reference's Model::configure builds the structure from the named restart file unconditionally and throws
+    (core/src/Model.cpp:59-62): a typo in model.init_file, a truncated or a foreign file must end the run with a
+    non-zero status and no restart file -- never a plausible run from constants"""
+    exe = os.path.join(host_build, "nextsim_amd")
+    cfg = os.path.join(ROOT, "run", "dev1.cfg")
+    final = os.path.join(str(tmp_path), "restart.nc")
+    rc, out = run([exe, "--config-file", cfg, "--model.final_file=" + final], cwd=str(tmp_path))  # dev1.res.nc is not here
+    assert rc != 0 and "cannot open dev1.res.nc" in out, out
+    assert not os.path.exists(final)
+    whole = open(os.path.join(GOLDEN, "dev1.res.nc"), "rb").read()
+    trunc = os.path.join(str(tmp_path), "truncated.nc")
+    with open(trunc, "wb") as f:
+        f.write(whole[:len(whole) // 3])
+    rc, out = run([exe, "--config-file", cfg, "--model.init_file=" + trunc, "--model.final_file=" + final], cwd=str(tmp_path))
+    assert rc != 0 and "nextsim_amd:" in out, out
+    assert not os.path.exists(final)
+    junk = os.path.join(str(tmp_path), "junk.nc")
+    with open(junk, "wb") as f:
+        f.write(b"this is not a restart file\n" * 10)
+    rc, out = run([exe, "--config-file", cfg, "--model.init_file=" + junk, "--model.final_file=" + final], cwd=str(tmp_path))
+    assert rc != 0 and "no structure type" in out, out
 
 
 @pytest.mark.gpu
@@ -88,7 +112,7 @@ def test_host_gpu_cases(host_build, gpu):
 def test_dev1_cfg_end_to_end(host_build, gpu, tmp_path):
     """BASELINE config 1: ./nextsim --config-file dev1.cfg (run/dev1.sh:5 of the reference) -> one
     iterate(1) on 100 elements; expected state = SURVEY.md Appendix C row 'dev1'."""
-    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"),
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"), "--model.init_file=",
                    "--model.final_file=%s" % os.path.join(str(tmp_path), "restart.nsdg")], cwd=str(tmp_path))
     assert rc == 0, out
     m = re.search(r"elements=(\d+) launches=(\d+) hice=(\S+) cice=(\S+) hsnow=(\S+) tice0=(\S+) sst=(\S+)", out)
@@ -99,7 +123,7 @@ def test_dev1_cfg_end_to_end(host_build, gpu, tmp_path):
     for g, w in zip(got, want):
         assert abs(g - w) <= 1e-12 * abs(w), (got, want)
     assert os.path.exists(os.path.join(str(tmp_path), "restart.nsdg"))
-    assert "constant initial state" in out  # dev1.res.nc is not in the working directory: [init] constants were used
+    assert "constant initial state" in out  # init_file explicitly empty: the [init] constants were used
     # the same run started from the reference's own NetCDF-4 restart file (tests/golden/dev1.res.nc is a copy of
     # run/dev1.res.nc; `init_file = dev1.res.nc` is relative to the working directory as in run/dev1.sh) and
     # writing its restart file in the same format
@@ -111,7 +135,7 @@ def test_dev1_cfg_end_to_end(host_build, gpu, tmp_path):
     with open(os.path.join(str(tmp_path), "restart.nc"), "rb") as f:
         assert f.read(8) == b"\x89HDF\r\n\x1a\n"
     # command-line override of a config value (first-wins precedence): 3 steps instead of 1
-    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"),
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"), "--model.init_file=",
                    "--model.stop=3", "--model.final_file=%s" % os.path.join(str(tmp_path), "r2.nsdg")], cwd=str(tmp_path))
     assert rc == 0 and "launches=3" in out, out
 
@@ -166,7 +190,7 @@ def test_dynamics_step_executable_matches_python_driver(host_build, gpu, tmp_pat
 def test_timing_report(host_build, gpu, tmp_path):
     """model.timing = true prints the hierarchical timer tree (Timer::report format of the reference,
     core/src/Timer.cpp:141-198) with device work charged to the node that enqueued it"""
-    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"), "--model.timing=true",
+    rc, out = run([os.path.join(host_build, "nextsim_amd"), "--config-file", os.path.join(ROOT, "run", "dev1.cfg"), "--model.timing=true", "--model.init_file=",
                    "--model.stop=4", "--model.final_file=%s" % os.path.join(str(tmp_path), "r.nsdg")], cwd=str(tmp_path))
     assert rc == 0, out
     assert re.search(r"Total: ticks = 1", out) and re.search(r"run: ticks = 1", out), out
