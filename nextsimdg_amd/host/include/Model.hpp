@@ -34,6 +34,7 @@ private:
     std::unique_ptr<IModelStep> modelStep;
     std::shared_ptr<IStructure> dataStructure;
     std::string initialFileName, finalFileName;
+    bool configured = false;
 };
 
 
@@ -59,7 +60,7 @@ inline Model::Model()
 inline Model::~Model()
 {
     try {
-        if (dataStructure)
+        if (dataStructure && configured) // a run that failed in configure() has no state worth a restart file
             writeRestartFile();
     } catch (std::exception& e) {
         // swallowed, as in the reference destructor
@@ -94,6 +95,7 @@ inline void Model::configure()
     modelStep->setInitialData(*dataStructure);
     modelStep->init();
     DummyExternalData::setAll(*dataStructure); // core/src/Model.cpp:76
+    configured = true;
 }
 
 inline void Model::run()

@@ -187,6 +187,8 @@ NSDG_REGISTER_MODULE(IModelStep, DynamicsStep, "Nextsim::IModelStep", "Nextsim::
 
 void DynamicsStep::writeRestartFile(const std::string& filePath)
 {
+    if (!pStructure)
+        throw std::logic_error("DynamicsStep::writeRestartFile: setInitialData() was not called");
     stop(0);
     pStructure->dump(filePath);
 }

@@ -115,6 +115,8 @@ void HipStep::stop(const Iterator::TimePoint&) { syncToHost(); }
 
 void HipStep::writeRestartFile(const std::string& filePath)
 {
+    if (!pStructure)
+        throw std::logic_error("HipStep::writeRestartFile: setInitialData() was not called");
     syncToHost();
     pStructure->dump(filePath);
 }
