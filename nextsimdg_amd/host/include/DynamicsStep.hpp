@@ -1,20 +1,36 @@
-// DynamicsStep.hpp -- IModelStep implementation of the dynamics core on one GPU: per time step the mEVP
-// stress/velocity sub-cycle followed by the DG2 transport of the mean thickness H and concentration A,
-// optionally preceded by the column thermodynamics (BASELINE config 5 coupling).  Everything numerical
-// happens behind the C ABI (include/nsdg.h); this class owns the device arrays and the call sequence.
+// DynamicsStep.hpp -- IModelStep implementation of the dynamics core: per time step the mEVP stress/velocity
+// sub-cycle followed by the DG2 transport of the mean thickness H and concentration A, optionally preceded by
+// the column thermodynamics (BASELINE config 5 coupling).  Everything numerical happens behind the C ABI
+// (include/nsdg.h); this class owns the device arrays and the call sequence.
 //
 // The reference has no dynamics component (CMakeLists.txt:43-46); the class plugs into the reference's
-// batched seam exactly like HipStep does and is selected with
+// batched seam (IModelStep, core/src/include/IModelStep.hpp:16-34) exactly like HipStep does and is selected with
 //     [Modules] Nextsim::IModelStep = Nextsim::DynamicsStep
+// The rectangular mesh is split into ROW BLOCKS with ghost rows; every block has its own context and is advanced
+// by the row-block drivers of the ABI (nsdg_rb_mevp_run / nsdg_rb_transport_run: kernel passes and ghost-row
+// exchanges of a step in one call each).  Three ways to run:
+//   * one block (default): the whole grid on one GPU;
+//   * dynamics.row_blocks = N: N blocks in THIS process, one host thread each, ghost rows through the in-process
+//     transport (nsdg_comm_init_local) -- devices round-robin over dynamics.devices (default: all on device 0);
+//   * one process per GPU under a launcher that sets WORLD_SIZE / RANK / LOCAL_RANK / MASTER_ADDR / MASTER_PORT
+//     (Rendezvous.hpp): every process owns ONE block, ghost rows over RCCL send/recv (nsdg_comm_init).  Every rank
+//     reads the same initial state and writes the rows it owns to <final_file>.rank<r>.
 // Configuration keys (all optional):
 //     dynamics.domain_size   side of the square box in m        (512e3)
 //     dynamics.nsub          mEVP sub-iterations per step        (120)
 //     dynamics.alpha/.beta   mEVP parameters (0 = stability bound of the mesh, see stableAlpha())
 //     dynamics.thermodynamics  run the column physics first       (false)
-// The structure's cell means initialise the DG fields: H <- hice, A <- cice (coefficient 0; higher
-// coefficients start at zero) and receive them back at stop().  Ocean current and wind come from the
-// device-side forcing provider nsdg_boxtest_forcing (the wind is re-evaluated at every step's model time).
+//     dynamics.forcing       thermodynamic forcing: host (the structure's planes, constant in time) | dummy | winter
+//                            (generated on the device at every step's model time, wind speed from the dynamics' wind)
+//     dynamics.row_blocks, dynamics.devices, dynamics.passes_per_exchange (6), dynamics.overlap (true),
+//     dynamics.graph (false), dynamics.loopback_world (0: off; N: rehearse an interior block of N on one GPU with
+//     real RCCL send/recv to the rank itself -- values wrap around, for timing and call-path checks only)
+// The structure's cell means initialise the DG fields: H <- hice, A <- cice (coefficient 0; higher coefficients
+// start at zero) and receive them back at stop().  Ocean current and wind come from the device-side forcing
+// provider nsdg_boxtest_forcing (the wind is re-evaluated at every step's model time).
 #pragma once
+#include <memory>
+#include <string>
 #include <vector>
 
 #include "Configured.hpp"
@@ -23,6 +39,8 @@
 struct nsdg_ctx;
 
 namespace Nextsim {
+
+class DynamicsBlock; // one row block: context, device arrays, driver plans (DynamicsStep.cpp)
 
 class DynamicsStep : public IModelStep, public Configured<DynamicsStep> {
 public:
@@ -40,23 +58,27 @@ public:
     void stop(const Iterator::TimePoint& stopTime) override;
     long launches() const override { return m_steps; }
 
-    //! diagnostics after stop(): max |u|, sum of the H and A cell means
+    //! diagnostics after stop(): max |u|, sum of the H and A cell means (of the rows this process owns)
     double maxSpeed() const { return m_umax; }
     double sumH() const { return m_sumH; }
     double sumA() const { return m_sumA; }
+    int blocks() const { return (int)m_blocks.size(); }
     static double stableAlpha(double h, double dt);
+
+    //! rows [r0, r1) of block `rank` of `world` (the same split as nextsimdg_amd/rowblock.py split_rows)
+    static void splitRows(int ny, int world, int rank, int& r0, int& r1);
 
 private:
     void release();
+    template <class F> void forEachBlock(F&& f); //!< one thread per block when there are several
     IStructure* pStructure = nullptr;
-    nsdg_ctx* ctx = nullptr;
-    double* d_block = nullptr;
-    std::vector<double*> d; // named sub-arrays of the block
+    std::vector<std::unique_ptr<DynamicsBlock>> m_blocks;
     int nxf = 0, nyf = 0; // fast / slow grid dimensions as the dynamics ABI names them
-    long N = 0, NN = 0;
     double L = 512e3, alpha = 0, beta = 0;
-    int nsub = 120;
-    bool thermo = false;
+    int nsub = 120, rowBlocks = 1, passesPerExchange = 6, loopbackWorld = 0;
+    bool thermo = false, overlap = true, graph = false, m_inited = false;
+    std::string forcing = "host", devices;
+    int m_world = 1, m_rank = 0; // multi-process run (one block per process)
     long m_steps = 0;
     double m_time = 0; // model time of the next step [s]
     double m_umax = 0, m_sumH = 0, m_sumA = 0;

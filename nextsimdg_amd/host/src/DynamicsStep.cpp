@@ -3,13 +3,19 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstring>
+#include <exception>
+#include <sstream>
 #include <stdexcept>
+#include <thread>
 
 #include "../../../include/nsdg.h"
 #include "ModuleLoader.hpp"
-#include "Timer.hpp"
 #include "PhysicsModules.hpp"
+#include "Rendezvous.hpp"
+#include "Timer.hpp"
 
 namespace Nextsim {
 
@@ -24,26 +30,61 @@ void checkHip(hipError_t e, const char* what)
     if (e != hipSuccess)
         throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
-// layout of the device block
-enum Arr { H, A, T1, T2, S11, S12, S22, PG, VXDG, VYDG, UNX, UNY, U, V, U0, V0, UA, VA, TAX, TAY, UO, VO, CGH, CGA, SCRATCH, COL, NARR };
+std::atomic<long> g_localGroup { 1 }; // ids of the in-process communicator groups of this process
+
+// device arrays of a block; the advected fields, the stress and the velocity exist twice (ping-pong)
+enum Arr { H0, A0, H1, A1, T2H, T2A, S11a, S12a, S22a, S11b, S12b, S22b, PG, VXDG, VYDG, UNX, UNY, Ua, Va, Ub, Vb, UA, VA, UO, VO, PACKED, COL, NARR };
+// column planes inside COL
+enum Col { C_HSNOW, C_TICE, C_SST, C_SSS, C_TAIR, C_TDEW, C_SLP, C_QSW, C_QLW, C_MLD, C_SNOWFALL, C_WIND, C_NEWICE, NCOL };
 } // namespace
+
+// ------------------------------------------------------------------------------------------------ one row block
+class DynamicsBlock {
+public:
+    // geometry: global rows [r0, r1) owned, [lo, hi) held locally; j0/j1 = owned local rows
+    int rank = 0, world = 1, device = 0;
+    int nx = 0, nyGlobal = 0, r0 = 0, r1 = 0, lo = 0, hi = 0, ny = 0, j0 = 0, j1 = 0;
+    int depthBelow = 0, depthAbove = 0, peerBelow = -1, peerAbove = -1;
+    long N = 0, NN = 0;
+    nsdg_ctx* ctx = nullptr;
+    double* block = nullptr;
+    std::vector<double*> d;
+    nsdg_rb_mevp* mevp = nullptr;
+    nsdg_rb_transport* transport = nullptr;
+    int par = 0, tpar = 0; // which buffers hold the velocity/stress iterate and the advected state
+
+    ~DynamicsBlock() { release(); }
+    void release()
+    {
+        if (ctx)
+            (void)hipSetDevice(device);
+        nsdg_rb_mevp_destroy(mevp);
+        nsdg_rb_transport_destroy(transport);
+        mevp = nullptr, transport = nullptr;
+        if (block)
+            (void)hipFree(block);
+        block = nullptr;
+        if (ctx)
+            nsdg_ctx_destroy(ctx); // finalises the communicator too
+        ctx = nullptr;
+    }
+    double* curH() const { return d[tpar == 0 ? H0 : H1]; }
+    double* curA() const { return d[tpar == 0 ? A0 : A1]; }
+    double* curU() const { return d[par == 0 ? Ua : Ub]; }
+    double* curV() const { return d[par == 0 ? Va : Vb]; }
+    double* col(int k) const { return d[COL] + (long)k * N; }
+};
 
 template <>
 const std::map<int, std::string> Configured<DynamicsStep>::keyMap = { { 0, "dynamics.domain_size" }, { 1, "dynamics.nsub" },
-    { 2, "dynamics.alpha" }, { 3, "dynamics.beta" }, { 4, "dynamics.thermodynamics" } };
+    { 2, "dynamics.alpha" }, { 3, "dynamics.beta" }, { 4, "dynamics.thermodynamics" }, { 5, "dynamics.row_blocks" },
+    { 6, "dynamics.passes_per_exchange" }, { 7, "dynamics.overlap" }, { 8, "dynamics.graph" }, { 9, "dynamics.forcing" },
+    { 10, "dynamics.devices" }, { 11, "dynamics.loopback_world" } };
 
 DynamicsStep::DynamicsStep() = default;
 DynamicsStep::~DynamicsStep() { release(); }
 
-void DynamicsStep::release()
-{
-    if (d_block)
-        (void)hipFree(d_block);
-    d_block = nullptr;
-    if (ctx)
-        nsdg_ctx_destroy(ctx);
-    ctx = nullptr;
-}
+void DynamicsStep::release() { m_blocks.clear(); }
 
 double DynamicsStep::stableAlpha(double h, double dt)
 { // alpha*beta >= pi^2 zeta_max dt / (m h^2), zeta_max = P* H / (2 Delta_min); same rule as synthetic.BoxTest.stable_alpha
@@ -53,6 +94,12 @@ double DynamicsStep::stableAlpha(double h, double dt)
     return std::max(1500., 1.2 * std::sqrt(pi * pi * zeta * dt / (rho * hice * h * h)));
 }
 
+void DynamicsStep::splitRows(int ny, int world, int rank, int& r0, int& r1)
+{
+    r0 = (int)(((long)rank * ny) / world);
+    r1 = (int)(((long)(rank + 1) * ny) / world);
+}
+
 void DynamicsStep::configure()
 {
     L = getConfiguration(keyMap.at(0), 512e3);
@@ -60,21 +107,62 @@ void DynamicsStep::configure()
     alpha = getConfiguration(keyMap.at(2), 0.);
     beta = getConfiguration(keyMap.at(3), 0.);
     thermo = getConfiguration(keyMap.at(4), false);
+    rowBlocks = getConfiguration(keyMap.at(5), 1);
+    passesPerExchange = getConfiguration(keyMap.at(6), 6);
+    overlap = getConfiguration(keyMap.at(7), true);
+    graph = getConfiguration(keyMap.at(8), false);
+    forcing = getConfiguration(keyMap.at(9), std::string("host"));
+    devices = getConfiguration(keyMap.at(10), std::string(""));
+    loopbackWorld = getConfiguration(keyMap.at(11), 0);
+    if (rowBlocks < 1 || passesPerExchange < 1 || nsub < 0)
+        throw std::invalid_argument("dynamics.row_blocks and dynamics.passes_per_exchange must be >= 1, dynamics.nsub >= 0");
+    if (forcing != "host" && forcing != "dummy" && forcing != "winter")
+        throw std::invalid_argument("dynamics.forcing must be host, dummy or winter");
+    if (loopbackWorld != 0 && loopbackWorld < 3)
+        throw std::invalid_argument("dynamics.loopback_world needs an interior block: at least 3");
 }
 
 void DynamicsStep::init()
 {
     configure();
-    if (!ctx)
-        check(nsdg_ctx_create(0, nullptr, &ctx), "DynamicsStep::init");
-    if (thermo) {
-        nsdg_column_params p;
-        IPhysics1d& phys = ModuleLoader::getLoader().getImplementation<IPhysics1d>();
-        tryConfigure(phys);
+    const RankEnvironment env = RankEnvironment::fromEnv();
+    m_world = env.world, m_rank = env.rank;
+    if (m_world > 1 && (rowBlocks > 1 || loopbackWorld))
+        throw std::invalid_argument("a multi-process run (WORLD_SIZE > 1) owns one row block per process: leave dynamics.row_blocks / loopback_world unset");
+    if (rowBlocks > 1 && loopbackWorld)
+        throw std::invalid_argument("dynamics.row_blocks and dynamics.loopback_world exclude each other");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw std::runtime_error(std::string("DynamicsStep::init: no HIP device available"));
+    if (thermo) { // the column-physics plugins read their keys once (shared static instances, as in the reference)
+        tryConfigure(ModuleLoader::getLoader().getImplementation<IPhysics1d>());
         tryConfigure(ModuleLoader::getLoader().getImplementation<IFreezingPoint>());
-        phys.describe(p);
-        check(nsdg_column_params_set(ctx, &p), "DynamicsStep::init");
     }
+    m_inited = true;
+}
+
+template <class F> void DynamicsStep::forEachBlock(F&& f)
+{
+    if (m_blocks.size() == 1) {
+        f(*m_blocks[0]);
+        return;
+    }
+    // the in-process transport hands ghost rows over between host threads: one thread per block
+    std::vector<std::thread> threads;
+    std::vector<std::exception_ptr> errors(m_blocks.size());
+    for (std::size_t k = 0; k < m_blocks.size(); ++k)
+        threads.emplace_back([&, k] {
+            try {
+                f(*m_blocks[k]);
+            } catch (...) {
+                errors[k] = std::current_exception();
+            }
+        });
+    for (auto& t : threads)
+        t.join();
+    for (auto& e : errors)
+        if (e)
+            std::rethrow_exception(e);
 }
 
 void DynamicsStep::start(const Iterator::TimePoint& startTime)
@@ -82,51 +170,157 @@ void DynamicsStep::start(const Iterator::TimePoint& startTime)
     ScopedTimer timer("start (upload)");
     if (!pStructure)
         throw std::logic_error("DynamicsStep: setInitialData() was not called");
-    if (!ctx)
+    if (!m_inited)
         init();
     FieldStore& f = pStructure->fields();
     nxf = pStructure->ny(); // fast dimension of the x-major index i*ny + j
     nyf = pStructure->nx();
-    N = (long)nxf * nyf;
-    NN = (long)(2 * nxf + 1) * (2 * nyf + 1);
-    // stress and ice strength are private to the sub-cycle and use the ABI's tiled layout
-    const long TS = nsdg_tiled_len(nxf, nyf, 8), TP = nsdg_tiled_len(nxf, nyf, 9);
-    const long sizes[NARR] = { 6 * N, 6 * N, 12 * N, 12 * N, TS, TS, TS, TP, 6 * N, 6 * N, 3L * (nxf + 1) * nyf, 3L * nxf * (nyf + 1), NN, NN,
-        NN, NN, NN, NN, NN, NN, NN, NN, NN, NN, 10 * NN + 3 * TS, 13 * N };
-    long total = 0;
-    for (long s : sizes)
-        total += s + 2; // keep every sub-array 16-byte aligned
-    if (d_block)
-        (void)hipFree(d_block);
-    checkHip(hipMalloc(reinterpret_cast<void**>(&d_block), total * sizeof(double)), "DynamicsStep: hipMalloc");
-    checkHip(hipMemset(d_block, 0, total * sizeof(double)), "DynamicsStep: hipMemset");
-    d.assign(NARR, nullptr);
-    long off = 0;
-    for (int k = 0; k < NARR; ++k) {
-        d[k] = d_block + off;
-        off += (sizes[k] + 1) & ~1L;
-    }
-    const double hx = L / nxf, hy = L / nyf;
-    check(nsdg_grid_set(ctx, nxf, nyf, hx, hy), "DynamicsStep::start");
-    // cell means -> DG coefficient 0
-    checkHip(hipMemcpy(d[H], f.hice.data(), N * sizeof(double), hipMemcpyHostToDevice), "upload H");
-    checkHip(hipMemcpy(d[A], f.cice.data(), N * sizeof(double), hipMemcpyHostToDevice), "upload A");
-    // analytic box-test forcing, evaluated on the device (ocean once, wind at the current model time every step)
-    check(nsdg_boxtest_forcing(ctx, L, (double)startTime, d[UA], d[VA], d[UO], d[VO]), "forcing");
     m_time = (double)startTime;
-    if (thermo) { // column planes: hsnow, tice0, sst, sss, tair, tdew, slp, qsw, qlw, mld, snowfall, wind, newice
-        const std::vector<double>* planes[13] = { &f.hsnow, nullptr, &f.sst, &f.sss, &f.tair, &f.tdew, &f.slp, &f.qsw, &f.qlw, &f.mld,
-            &f.snowfall, &f.wind, &f.newice };
-        for (int k = 0; k < 13; ++k)
-            checkHip(hipMemcpy(d[COL] + k * N, k == 1 ? f.tice.data() : planes[k]->data(), N * sizeof(double), hipMemcpyHostToDevice),
-                "upload column fields");
+
+    // ---- the blocks of this process
+    const bool loop = loopbackWorld > 0;
+    const int world = m_world > 1 ? m_world : (loop ? loopbackWorld : rowBlocks);
+    int ndev = 1;
+    (void)hipGetDeviceCount(&ndev);
+    std::vector<int> devs;
+    {
+        std::stringstream ss(devices);
+        std::string item;
+        while (std::getline(ss, item, ','))
+            if (!item.empty())
+                devs.push_back(std::stoi(item));
+        if (devs.empty())
+            devs.push_back(m_world > 1 ? RankEnvironment::fromEnv().localRank % std::max(ndev, 1) : 0);
+        for (int dv : devs)
+            if (dv < 0 || dv >= ndev)
+                throw std::invalid_argument("dynamics.devices names a device that does not exist");
     }
+    // ghost depth: (v k, v k - 1) for k passes of the v-iterations-per-pass kernel between two exchanges
+    const int v = 3; // the library's default kernel
+    int k = world > 1 ? std::max(1, std::min(passesPerExchange, (nyf / world) / 16)) : 1;
+    const int depthBelow = world > 1 ? v * k : 0, depthAbove = world > 1 ? v * k - 1 : 0;
+    if (world > 1 && nyf < world * 2 * std::max(depthBelow, 1))
+        throw std::invalid_argument("too few element rows per block for the ghost depth");
+    m_blocks.clear();
+    const long group = g_localGroup++;
+    std::vector<int> ranks;
+    if (m_world > 1)
+        ranks.push_back(m_rank);
+    else if (loop)
+        ranks.push_back(loopbackWorld / 2);
+    else
+        for (int r = 0; r < world; ++r)
+            ranks.push_back(r);
+    for (std::size_t i = 0; i < ranks.size(); ++i) {
+        auto b = std::make_unique<DynamicsBlock>();
+        b->rank = ranks[i], b->world = world, b->device = devs[i % devs.size()];
+        b->nx = nxf, b->nyGlobal = nyf;
+        splitRows(nyf, world, b->rank, b->r0, b->r1);
+        b->depthBelow = depthBelow, b->depthAbove = depthAbove;
+        const bool below = b->rank > 0, above = b->rank < world - 1;
+        b->lo = b->r0 - (below ? depthBelow : 0), b->hi = b->r1 + (above ? depthAbove : 0);
+        b->ny = b->hi - b->lo;
+        b->j0 = b->r0 - b->lo, b->j1 = b->r1 - b->lo;
+        b->peerBelow = below ? (loop ? 0 : b->rank - 1) : -1;
+        b->peerAbove = above ? (loop ? 0 : b->rank + 1) : -1;
+        m_blocks.push_back(std::move(b));
+    }
+    // the RCCL communicator id travels before anything else (multi-process run)
+    unsigned char commId[NSDG_COMM_ID_BYTES];
+    std::memset(commId, 0, sizeof commId);
+    if (m_world > 1 || loop) {
+        if (m_rank == 0)
+            check(nsdg_comm_unique_id(commId), "nsdg_comm_unique_id");
+        if (m_world > 1)
+            broadcastFromRankZero(RankEnvironment::fromEnv(), commId, sizeof commId);
+    }
+
+    const double hx = L / nxf, hy = L / nyf;
+    forEachBlock([&](DynamicsBlock& b) {
+        checkHip(hipSetDevice(b.device), "hipSetDevice");
+        check(nsdg_ctx_create(b.device, nullptr, &b.ctx), "nsdg_ctx_create");
+        if (world > 1) {
+            if (m_world > 1)
+                check(nsdg_comm_init(b.ctx, m_rank, m_world, commId), "nsdg_comm_init");
+            else if (loop)
+                check(nsdg_comm_init(b.ctx, 0, 1, commId), "nsdg_comm_init (loopback)");
+            else
+                check(nsdg_comm_init_local(b.ctx, group, b.rank, b.world), "nsdg_comm_init_local");
+        }
+        if (thermo) {
+            nsdg_column_params p;
+            IPhysics1d& phys = ModuleLoader::getLoader().getImplementation<IPhysics1d>();
+            phys.describe(p);
+            check(nsdg_column_params_set(b.ctx, &p), "nsdg_column_params_set");
+        }
+        b.N = (long)b.nx * b.ny;
+        b.NN = (long)(2 * b.nx + 1) * (2 * b.ny + 1);
+        const long N = b.N, NN = b.NN;
+        const long TS = nsdg_tiled_len(b.nx, b.ny, 8), TP = nsdg_tiled_len(b.nx, b.ny, 9);
+        long sizes[NARR];
+        for (int a = 0; a < NARR; ++a)
+            sizes[a] = 0;
+        for (int a : { H0, A0, H1, A1, T2H, T2A, VXDG, VYDG })
+            sizes[a] = 6 * N;
+        for (int a : { S11a, S12a, S22a, S11b, S12b, S22b })
+            sizes[a] = TS;
+        sizes[PG] = TP;
+        sizes[UNX] = 3L * (b.nx + 1) * b.ny, sizes[UNY] = 3L * b.nx * (b.ny + 1);
+        for (int a : { Ua, Va, Ub, Vb, UA, VA, UO, VO })
+            sizes[a] = NN;
+        sizes[PACKED] = 8 * NN;
+        sizes[COL] = (long)NCOL * N;
+        long total = 0;
+        for (long s : sizes)
+            total += (s + 1) & ~1L; // keep every sub-array 16-byte aligned
+        checkHip(hipMalloc(reinterpret_cast<void**>(&b.block), total * sizeof(double)), "DynamicsStep: hipMalloc");
+        checkHip(hipMemset(b.block, 0, total * sizeof(double)), "DynamicsStep: hipMemset");
+        b.d.assign(NARR, nullptr);
+        long off = 0;
+        for (int a = 0; a < NARR; ++a) {
+            b.d[a] = b.block + off;
+            off += (sizes[a] + 1) & ~1L;
+        }
+        check(nsdg_grid_set(b.ctx, b.nx, b.ny, hx, hy), "nsdg_grid_set");
+        check(nsdg_block_set(b.ctx, b.lo, b.nyGlobal), "nsdg_block_set");
+        // cell means -> DG coefficient 0 (the local rows, ghost rows included, are one contiguous slice)
+        const std::size_t first = (std::size_t)b.lo * b.nx;
+        checkHip(hipMemcpy(b.d[H0], f.hice.data() + first, N * sizeof(double), hipMemcpyHostToDevice), "upload H");
+        checkHip(hipMemcpy(b.d[A0], f.cice.data() + first, N * sizeof(double), hipMemcpyHostToDevice), "upload A");
+        // analytic box-test forcing, evaluated on the device (ocean once, wind at the current model time every step)
+        check(nsdg_boxtest_forcing(b.ctx, L, m_time, b.d[UA], b.d[VA], b.d[UO], b.d[VO]), "nsdg_boxtest_forcing");
+        if (thermo) {
+            const std::vector<double>* planes[NCOL] = { &f.hsnow, &f.tice, &f.sst, &f.sss, &f.tair, &f.tdew, &f.slp, &f.qsw, &f.qlw, &f.mld,
+                &f.snowfall, &f.wind, &f.newice };
+            for (int c = 0; c < NCOL; ++c)
+                checkHip(hipMemcpy(b.col(c), planes[c]->data() + first, N * sizeof(double), hipMemcpyHostToDevice), "upload column fields");
+        }
+        // driver plans
+        nsdg_rb_mevp_desc m;
+        std::memset(&m, 0, sizeof m);
+        m.nx = b.nx, m.ny = b.ny, m.j0 = b.j0, m.j1 = b.j1, m.depth_below = b.depthBelow, m.depth_above = b.depthAbove;
+        m.rank_below = b.peerBelow, m.rank_above = b.peerAbove;
+        m.nsub = nsub, m.overlap = overlap, m.use_graph = graph;
+        m.s11[0] = b.d[S11a], m.s12[0] = b.d[S12a], m.s22[0] = b.d[S22a], m.u[0] = b.d[Ua], m.v[0] = b.d[Va];
+        m.s11[1] = b.d[S11b], m.s12[1] = b.d[S12b], m.s22[1] = b.d[S22b], m.u[1] = b.d[Ub], m.v[1] = b.d[Vb];
+        m.packed = b.d[PACKED], m.pg = b.d[PG];
+        check(nsdg_rb_mevp_create(b.ctx, &m, &b.mevp), "nsdg_rb_mevp_create");
+        nsdg_rb_transport_desc t;
+        std::memset(&t, 0, sizeof t);
+        t.nx = b.nx, t.ny = b.ny, t.j0 = b.j0, t.j1 = b.j1, t.depth_below = b.depthBelow, t.depth_above = b.depthAbove;
+        t.rank_below = b.peerBelow, t.rank_above = b.peerAbove;
+        t.order = 2, t.nfields = 2;
+        t.phi[0] = b.d[H0], t.phi[1] = b.d[A0], t.t1[0] = b.d[H1], t.t1[1] = b.d[A1], t.t2[0] = b.d[T2H], t.t2[1] = b.d[T2A];
+        t.vx_dg = b.d[VXDG], t.vy_dg = b.d[VYDG], t.un_x = b.d[UNX], t.un_y = b.d[UNY];
+        check(nsdg_rb_transport_create(b.ctx, &t, &b.transport), "nsdg_rb_transport_create");
+        b.par = b.tpar = 0;
+    });
 }
 
 void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
 {
     ScopedTimer timer("iterate");
-    if (!d_block)
+    if (m_blocks.empty())
         start(0);
     const double dt = dtSeconds;
     nsdg_mevp_params p;
@@ -134,25 +328,35 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
     const double a = alpha > 0 ? alpha : stableAlpha(std::min(L / nxf, L / nyf), dt);
     p.alpha = a;
     p.beta = beta > 0 ? beta : a;
-    check(nsdg_mevp_params_set(ctx, &p), "DynamicsStep::iterate");
-    if (thermo) {
-        double* c = d[COL];
-        check(nsdg_column_step(ctx, N, dt, d[H], d[A], c, c + N, c + 2 * N, c + 3 * N, c + 4 * N, c + 5 * N, c + 6 * N, c + 7 * N, c + 8 * N,
-                  c + 9 * N, c + 10 * N, c + 11 * N, c + 12 * N, nullptr),
-            "column step");
-    }
-    check(nsdg_boxtest_forcing(ctx, L, m_time, d[UA], d[VA], nullptr, nullptr), "forcing"); // the cyclone moves
-    check(nsdg_ice_strength(ctx, 0, nyf, d[H], d[A], d[PG]), "ice_strength");
-    // nsdg_mevp_subcycle takes the unpacked nodal fields (general entry point); u0/v0 may alias u/v
-    check(nsdg_dg_to_cg(ctx, 6, d[H], d[CGH]), "dg_to_cg");
-    check(nsdg_dg_to_cg(ctx, 6, d[A], d[CGA]), "dg_to_cg");
-    check(nsdg_wind_stress(ctx, NN, d[UA], d[VA], d[TAX], d[TAY]), "wind_stress");
-    check(nsdg_mevp_subcycle(ctx, dt, nsub, d[S11], d[S12], d[S22], d[U], d[V], d[U], d[V], d[TAX], d[TAY], d[UO], d[VO], d[CGH], d[CGA],
-              d[PG], d[SCRATCH]),
-        "mevp_subcycle");
-    check(nsdg_prepare_advection(ctx, 2, d[U], d[V], d[VXDG], d[VYDG], d[UNX], d[UNY]), "prepare_advection");
-    double* fields[2] = { d[H], d[A] };
-    check(nsdg_transport_step(ctx, 2, dt, 2, fields, d[VXDG], d[VYDG], d[UNX], d[UNY], d[T1]), "transport_step"); // T1,T2 contiguous: 24N scratch
+    const double t = m_time;
+    const int kind = forcing == "winter" ? NSDG_FORCING_WINTER : NSDG_FORCING_DUMMY;
+    forEachBlock([&](DynamicsBlock& b) {
+        checkHip(hipSetDevice(b.device), "hipSetDevice");
+        nsdg_ctx* ctx = b.ctx;
+        check(nsdg_mevp_params_set(ctx, &p), "nsdg_mevp_params_set");
+        check(nsdg_boxtest_forcing(ctx, L, t, b.d[UA], b.d[VA], nullptr, nullptr), "nsdg_boxtest_forcing"); // the cyclone moves
+        if (thermo) {
+            if (forcing != "host") { // DummyExternalData's replacement, and the wind speed the reference never sets
+                check(nsdg_column_forcing(ctx, kind, t, b.col(C_TAIR), b.col(C_TDEW), b.col(C_SLP), b.col(C_QSW), b.col(C_QLW), b.col(C_MLD),
+                          b.col(C_SNOWFALL)),
+                    "nsdg_column_forcing");
+                check(nsdg_column_wind(ctx, b.d[UA], b.d[VA], b.col(C_WIND)), "nsdg_column_wind");
+            }
+            // the column physics needs no exchange: it runs on the ghost rows too, redundantly
+            check(nsdg_column_step(ctx, b.N, dt, b.curH(), b.curA(), b.col(C_HSNOW), b.col(C_TICE), b.col(C_SST), b.col(C_SSS), b.col(C_TAIR),
+                      b.col(C_TDEW), b.col(C_SLP), b.col(C_QSW), b.col(C_QLW), b.col(C_MLD), b.col(C_SNOWFALL), b.col(C_WIND), b.col(C_NEWICE),
+                      nullptr),
+                "nsdg_column_step");
+        }
+        check(nsdg_ice_strength(ctx, 0, b.ny, b.curH(), b.curA(), b.d[PG]), "nsdg_ice_strength");
+        check(nsdg_mevp_prepare(ctx, dt, b.curH(), b.curA(), b.d[UA], b.d[VA], b.d[UO], b.d[VO], b.curU(), b.curV(), b.d[PACKED]), "nsdg_mevp_prepare");
+        int32_t out = 0;
+        check(nsdg_rb_mevp_run(ctx, b.mevp, b.par, &out), "nsdg_rb_mevp_run");
+        b.par = out;
+        check(nsdg_prepare_advection(ctx, 2, b.curU(), b.curV(), b.d[VXDG], b.d[VYDG], b.d[UNX], b.d[UNY]), "nsdg_prepare_advection");
+        check(nsdg_rb_transport_run(ctx, b.transport, dt, b.tpar, &out), "nsdg_rb_transport_run");
+        b.tpar = out;
+    });
     ++m_steps;
     m_time += dt;
 }
@@ -160,27 +364,39 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
 void DynamicsStep::stop(const Iterator::TimePoint&)
 {
     ScopedTimer timer("stop (download)");
-    if (!d_block)
+    if (m_blocks.empty())
         return;
-    check(nsdg_ctx_synchronize(ctx), "DynamicsStep::stop");
     FieldStore& f = pStructure->fields();
-    checkHip(hipMemcpy(f.hice.data(), d[H], N * sizeof(double), hipMemcpyDeviceToHost), "download H");
-    checkHip(hipMemcpy(f.cice.data(), d[A], N * sizeof(double), hipMemcpyDeviceToHost), "download A");
-    if (thermo) {
-        checkHip(hipMemcpy(f.hsnow.data(), d[COL], N * sizeof(double), hipMemcpyDeviceToHost), "download hsnow");
-        checkHip(hipMemcpy(f.tice.data(), d[COL] + N, N * sizeof(double), hipMemcpyDeviceToHost), "download tice");
-        checkHip(hipMemcpy(f.newice.data(), d[COL] + 12 * N, N * sizeof(double), hipMemcpyDeviceToHost), "download newice");
+    std::vector<double> umax(m_blocks.size(), 0.);
+    std::size_t idx = 0;
+    for (auto& bp : m_blocks) { // sequential: the blocks write disjoint row ranges of the host structure
+        DynamicsBlock& b = *bp;
+        checkHip(hipSetDevice(b.device), "hipSetDevice");
+        check(nsdg_ctx_synchronize(b.ctx), "DynamicsStep::stop");
+        const std::size_t first = (std::size_t)b.r0 * b.nx, count = (std::size_t)(b.r1 - b.r0) * b.nx, skip = (std::size_t)b.j0 * b.nx;
+        checkHip(hipMemcpy(f.hice.data() + first, b.curH() + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download H");
+        checkHip(hipMemcpy(f.cice.data() + first, b.curA() + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download A");
+        if (thermo) {
+            checkHip(hipMemcpy(f.hsnow.data() + first, b.col(C_HSNOW) + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download hsnow");
+            checkHip(hipMemcpy(f.tice.data() + first, b.col(C_TICE) + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download tice");
+            checkHip(hipMemcpy(f.newice.data() + first, b.col(C_NEWICE) + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download newice");
+        }
+        // owned node rows: [2 j0, 2 j1) plus the top boundary row on the last block
+        const long nn = 2L * b.nx + 1;
+        const long rows = 2L * (b.j1 - b.j0) + (b.peerAbove < 0 ? 1 : 0);
+        std::vector<double> u(rows * nn);
+        checkHip(hipMemcpy(u.data(), b.curU() + 2L * b.j0 * nn, u.size() * sizeof(double), hipMemcpyDeviceToHost), "download u");
+        for (double x : u)
+            umax[idx] = std::max(umax[idx], std::fabs(x));
+        ++idx;
     }
-    std::vector<double> u(NN);
-    checkHip(hipMemcpy(u.data(), d[U], NN * sizeof(double), hipMemcpyDeviceToHost), "download u");
-    m_umax = 0;
-    for (double x : u)
-        m_umax = std::max(m_umax, std::fabs(x));
+    m_umax = *std::max_element(umax.begin(), umax.end());
     m_sumH = m_sumA = 0;
-    for (long e = 0; e < N; ++e) {
-        m_sumH += f.hice[e];
-        m_sumA += f.cice[e];
-    }
+    for (auto& bp : m_blocks)
+        for (long e = (long)bp->r0 * nxf; e < (long)bp->r1 * nxf; ++e) {
+            m_sumH += f.hice[e];
+            m_sumA += f.cice[e];
+        }
 }
 
 NSDG_REGISTER_MODULE(IModelStep, DynamicsStep, "Nextsim::IModelStep", "Nextsim::DynamicsStep");
@@ -190,7 +406,8 @@ void DynamicsStep::writeRestartFile(const std::string& filePath)
     if (!pStructure)
         throw std::logic_error("DynamicsStep::writeRestartFile: setInitialData() was not called");
     stop(0);
-    pStructure->dump(filePath);
+    // a multi-process run holds only its own rows up to date: every rank writes its own file
+    pStructure->dump(m_world > 1 ? filePath + ".rank" + std::to_string(m_rank) : filePath);
 }
 
 } // namespace Nextsim

@@ -1,0 +1,118 @@
+#include "Rendezvous.hpp"
+
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+
+namespace Nextsim {
+
+namespace {
+int envInt(const char* name, int fallback)
+{
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : fallback;
+}
+
+void sendAll(int fd, const char* p, std::size_t n)
+{
+    while (n > 0) {
+        const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (k <= 0)
+            throw std::runtime_error("rendezvous: send failed");
+        p += k, n -= (std::size_t)k;
+    }
+}
+
+void recvAll(int fd, char* p, std::size_t n)
+{
+    while (n > 0) {
+        const ssize_t k = ::recv(fd, p, n, 0);
+        if (k <= 0)
+            throw std::runtime_error("rendezvous: connection closed before the communicator id arrived");
+        p += k, n -= (std::size_t)k;
+    }
+}
+
+struct Socket {
+    int fd = -1;
+    ~Socket()
+    {
+        if (fd >= 0)
+            ::close(fd);
+    }
+};
+} // namespace
+
+RankEnvironment RankEnvironment::fromEnv()
+{
+    RankEnvironment e;
+    e.world = envInt("WORLD_SIZE", 1);
+    e.rank = envInt("RANK", 0);
+    e.localRank = envInt("LOCAL_RANK", e.rank);
+    if (const char* a = std::getenv("MASTER_ADDR"))
+        if (*a)
+            e.masterAddr = a;
+    e.masterPort = envInt("MASTER_PORT", 29500);
+    if (e.world < 1 || e.rank < 0 || e.rank >= e.world)
+        throw std::invalid_argument("RANK / WORLD_SIZE in the environment are inconsistent");
+    return e;
+}
+
+void broadcastFromRankZero(const RankEnvironment& env, void* buffer, std::size_t bytes, int timeoutSeconds)
+{
+    if (env.world <= 1)
+        return;
+    const int port = env.masterPort + 17;
+    sockaddr_in addr;
+    std::memset(&addr, 0, sizeof addr);
+    addr.sin_family = AF_INET;
+    addr.sin_port = htons((unsigned short)port);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeoutSeconds);
+    if (env.rank == 0) {
+        Socket srv;
+        srv.fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (srv.fd < 0)
+            throw std::runtime_error("rendezvous: socket() failed");
+        const int one = 1;
+        ::setsockopt(srv.fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        addr.sin_addr.s_addr = htonl(INADDR_ANY);
+        if (::bind(srv.fd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) != 0 || ::listen(srv.fd, env.world) != 0)
+            throw std::runtime_error("rendezvous: cannot listen on port " + std::to_string(port));
+        timeval tv = { timeoutSeconds, 0 };
+        ::setsockopt(srv.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        for (int k = 1; k < env.world; ++k) {
+            Socket c;
+            c.fd = ::accept(srv.fd, nullptr, nullptr);
+            if (c.fd < 0)
+                throw std::runtime_error("rendezvous: only " + std::to_string(k - 1) + " of " + std::to_string(env.world - 1) + " ranks connected");
+            sendAll(c.fd, static_cast<const char*>(buffer), bytes);
+        }
+        return;
+    }
+    if (::inet_pton(AF_INET, env.masterAddr.c_str(), &addr.sin_addr) != 1)
+        throw std::runtime_error("rendezvous: MASTER_ADDR must be a dotted IPv4 address, got " + env.masterAddr);
+    for (;;) { // rank 0 may not be listening yet
+        Socket c;
+        c.fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (c.fd < 0)
+            throw std::runtime_error("rendezvous: socket() failed");
+        if (::connect(c.fd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) == 0) {
+            timeval tv = { timeoutSeconds, 0 };
+            ::setsockopt(c.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+            recvAll(c.fd, static_cast<char*>(buffer), bytes);
+            return;
+        }
+        if (std::chrono::steady_clock::now() > deadline)
+            throw std::runtime_error("rendezvous: rank 0 did not answer on " + env.masterAddr + ":" + std::to_string(port));
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+}
+
+} // namespace Nextsim

@@ -2,6 +2,7 @@
 // implementation, the behaviour the reference's Catch2 tests pin (file:line given per case); the GPU
 // cases (run with --gpu) drive HipStep / Model through the C ABI and compare with the reference's
 // known answers.  Tiny self-contained harness: CHECK() records failures, exit code = #failures.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,7 @@
 #include <functional>
 #include <iostream>
 #include <sstream>
+#include <thread>
 #include <typeinfo>
 
 #include "Configurator.hpp"
@@ -19,6 +21,7 @@
 #include "Model.hpp"
 #include "ModuleLoader.hpp"
 #include "PhysicsModules.hpp"
+#include "Rendezvous.hpp"
 #include "Timer.hpp"
 
 using namespace Nextsim;
@@ -547,6 +550,92 @@ static void test_dynamics_step()
     ModuleLoader::getLoader().setAllDefaults();
 }
 
+static void test_rendezvous()
+{ // two "ranks" of a multi-process run agree on 128 bytes over the loopback interface
+    int r0, r1, covered = 0;
+    for (int world : { 1, 3, 8 })
+        for (int r = 0; r < world; ++r) {
+            DynamicsStep::splitRows(2048, world, r, r0, r1);
+            CHECK(r0 == covered % 2048 || r == 0);
+            covered = r1;
+            CHECK(r1 > r0 && (r != world - 1 || r1 == 2048));
+        }
+    RankEnvironment a, b;
+    a.world = b.world = 2;
+    a.rank = 0, b.rank = 1;
+    a.masterPort = b.masterPort = 20000 + (int)(std::hash<std::thread::id>()(std::this_thread::get_id()) % 20000);
+    unsigned char sent[128], got[128];
+    for (int i = 0; i < 128; ++i)
+        sent[i] = (unsigned char)(3 * i + 1), got[i] = 0;
+    std::exception_ptr err;
+    std::thread client([&] {
+        try {
+            broadcastFromRankZero(b, got, sizeof got, 20);
+        } catch (...) {
+            err = std::current_exception();
+        }
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(300)); // the client starts first and has to retry
+    broadcastFromRankZero(a, sent, sizeof sent, 20);
+    client.join();
+    CHECK(!err);
+    CHECK(std::memcmp(sent, got, sizeof sent) == 0);
+    RankEnvironment lonely; // nobody listens: a clear error after the timeout, not a hang
+    lonely.world = 2, lonely.rank = 1, lonely.masterPort = a.masterPort + 100;
+    CHECK_THROWS_AS(broadcastFromRankZero(lonely, got, sizeof got, 1), std::runtime_error);
+}
+
+static FieldStore run_dynamics(const std::string& extra, double* umax)
+{
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    addConfig("[Modules]\nNextsim::IModelStep = Nextsim::DynamicsStep\n[model]\nstructure = rectgrid\nstart = 0\nstop = 360\ntime_step = 120\n"
+              "final_file = /tmp/nsdg_dyn_blocks.nsdg\n[rectgrid]\nnx = 128\nny = 96\n[init]\nhice = 0.3\ncice = 0.9\nsst = -1.76\nhsnow = 0.05\ntice = -8\n"
+              "[dynamics]\nnsub = 23\nthermodynamics = true\nforcing = winter\n" + extra);
+    ConfiguredModule::parseConfigurator();
+    FieldStore out;
+    {
+        Model model;
+        model.configure();
+        model.run();
+        DynamicsStep& dyn = dynamic_cast<DynamicsStep&>(model.step());
+        dyn.stop(0);
+        *umax = dyn.maxSpeed();
+        out = model.structure().fields();
+    }
+    std::remove("/tmp/nsdg_dyn_blocks.nsdg");
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    return out;
+}
+
+static void test_dynamics_row_blocks()
+{ // the multi-block step (threads + in-process transport, native row-block drivers) against the single block: bit for bit
+    double u1 = 0, u3 = 0, u4 = 0, ul = 0;
+    const FieldStore one = run_dynamics("", &u1);
+    CHECK(u1 > 1e-6 && u1 < 1.0);
+    double lo = 1e9, hi = -1e9;
+    for (double t : one.tice)
+        lo = std::min(lo, t), hi = std::max(hi, t);
+    CHECK(lo > -40 && hi <= 0 && hi > lo); // the device-side winter forcing and the wind coupling changed the ice temperature
+    const FieldStore three = run_dynamics("row_blocks = 3\npasses_per_exchange = 2\n", &u3);
+    const FieldStore four = run_dynamics("row_blocks = 4\npasses_per_exchange = 1\noverlap = false\ngraph = true\n", &u4);
+    for (const FieldStore* f : { &three, &four }) {
+        CHECK(f->hice == one.hice);
+        CHECK(f->cice == one.cice);
+        CHECK(f->hsnow == one.hsnow);
+        CHECK(f->tice == one.tice);
+        CHECK(f->newice == one.newice);
+    }
+    CHECK(u3 == u1 && u4 == u1);
+    // RCCL from the C++ host on one GPU: an interior block of 8 whose neighbours are the rank itself
+    const FieldStore loop = run_dynamics("loopback_world = 8\npasses_per_exchange = 1\n", &ul);
+    bool finite = std::isfinite(ul);
+    for (double h : loop.hice)
+        finite = finite && std::isfinite(h);
+    CHECK(finite && ul > 0);
+}
+
 int main(int argc, char** argv)
 {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "--gpu") == 0;
@@ -561,10 +650,12 @@ int main(int argc, char** argv)
             test_physics_config();
             test_structure();
             test_restart_hdf5();
+            test_rendezvous();
         } else {
             test_hipstep_melting();
             test_model_dev1();
             test_dynamics_step();
+            test_dynamics_row_blocks();
         }
     } catch (const std::exception& e) {
         std::printf("FAIL: unexpected exception: %s\n", e.what());
