@@ -295,6 +295,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["native", "torch"], default="native",
                     help="N > 1: ghost-row exchange through the C ABI (nsdg_halo_*, RCCL calls and pack kernels in libnsdg.so) or through torch.distributed P2P ops")
+    ap.add_argument("--driver", choices=["native", "python"], default="native",
+                    help="sub-cycle and transport of a step as one C call each (nsdg_rb_*_run) or as the Python sequence of the same launches")
+    ap.add_argument("--graph", action="store_true", help="native driver: replay the launches between two exchanges as one hipGraph")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (gloo): launch, rendezvous, planning; no metric")
     args = ap.parse_args()
 
@@ -347,7 +350,9 @@ def main():
     exchanger = None
     if world > 1 or os.environ.get("NSDG_FORCE_DIST"):
         exchanger = make_exchanger(args.halo, ctx, blk, device)
-    core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device, exchanger=exchanger)
+    native = args.driver == "native" and (exchanger is None or isinstance(exchanger, rowblock.NativeHaloExchanger))
+    core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device, exchanger=exchanger,
+                                                                        native=native, use_graph=args.graph)
     if coupled:
         # thermodynamic forcing held constant in time: smooth analytic fields in the ranges of SURVEY.md section 8(d)
         # with the mixed layer at the freezing point (synthetic.column_fields_smooth explains why not the per-element
@@ -447,6 +452,7 @@ def main():
                            ", ghost depth %d/%d rows, one exchange per %d mEVP passes, halo=%s" % (depth[0], depth[1], core.group_passes, args.halo) if world > 1 else ""),
                        "mevp_passes": "%s sub-iteration%s per kernel pass" % ({3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
                        "mevp_variant": args.variant if args.variant is not None else "default",
+                       "driver": ("native (nsdg_rb_mevp_run / nsdg_rb_transport_run)" + (" + hipGraph replay" if args.graph else "")) if native else "python sequence",
                        "parity": "dynamics parity unpinned (the reference snapshot has no DG/mEVP code); self-check of this run: "
                                  + ("fused pass == single sub-iterations bitwise on the live state" if guard else "finite fields")},
             "roofline": roof,

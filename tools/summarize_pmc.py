@@ -2,7 +2,10 @@
 """Turn the rocprofv3 PMC passes of bench.py (FETCH_SIZE pass, WRITE_SIZE pass) into
 profiles/<tag>_hbm_traffic.{md,json} and profiles/hbm_traffic_latest.json.
 
-usage: tools/summarize_pmc.py <fetch_dir> <write_dir> <tag> <nx> <ny> "<config note>"
+usage: tools/summarize_pmc.py <fetch_dir> <write_dir> <tag> <nx> <ny> "<config note>" [<sq_dir>]
+
+With <sq_dir> (a pass with SQ_INSTS_VALU ...) the VALU wave-instructions per launch are recorded too.  The JSON carries
+a hash of the kernel sources so that bench.py can tell when a committed profile no longer belongs to the code.
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE (KB) reads exactly 1/2 of the bytes of a
 coalesced stream -- re-checked here on three kernels of the same run whose traffic is known exactly
@@ -30,10 +33,18 @@ def load(d):
     return agg
 
 
+def source_hash():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+
+    return bench.kernel_source_hash()
+
+
 def main():
     fdir, wdir, tag, nx, ny, note = sys.argv[1:7]
     nx, ny = int(nx), int(ny)
     fe, wr = load(fdir), load(wdir)
+    sq = load(sys.argv[7]) if len(sys.argv) > 7 else {}
     N, nn = nx * ny, (2 * nx + 1) * (2 * ny + 1)
     mean = lambda a: sum(a) / len(a)
     known = {"wind_stress_kernel": (2 * 8 * nn, 2 * 8 * nn), "ice_strength_kernel": (12 * 8 * N, 9 * 8 * N),
@@ -57,9 +68,14 @@ def main():
             L.append("| %s | %d | %.3f | %.3f | %.3f | %s |\n" % (k, len(fe[k]["FETCH_SIZE"]), rd / 1e9, w / 1e9, (rd + w) / 1e9,
                                                                   "%.3f" % (alg / 1e9) if alg else "-"))
             out[k] = {"read_bytes": rd, "write_bytes": w, "total_bytes": rd + w, "algorithmic_bytes": alg}
+            if k in sq and "SQ_INSTS_VALU" in sq[k]:
+                out[k]["valu_wave_insts"] = mean(sq[k]["SQ_INSTS_VALU"])
+                for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "SQ_WAVES"):
+                    if c in sq[k]:
+                        out[k][c] = mean(sq[k][c])
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     open(os.path.join(root, tag + "_hbm_traffic.md"), "w").write("".join(L))
-    js = {"nx": nx, "ny": ny, "config": note, "kernels": out}
+    js = {"nx": nx, "ny": ny, "config": note, "file": tag + "_hbm_traffic.json", "kernel_source_hash": source_hash(), "kernels": out}
     json.dump(js, open(os.path.join(root, tag + "_hbm_traffic.json"), "w"), indent=1)
     json.dump(js, open(os.path.join(root, "hbm_traffic_latest.json"), "w"), indent=1)
     print("".join(L))
