@@ -121,13 +121,22 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nblocks)
 // subnormal range (Delta^2 >= Delta_min^2 = 4e-18; denominators >= rho h_min/dt).
 __device__ __forceinline__ double fast_rcp(double x)
 {
+#ifdef NSDG_OLD_ELEMENTARY
     double r = __builtin_amdgcn_rcp(x);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
+#else
+    // the seed is good to 2^-24 (profiles/r02_seed_accuracy.txt): ONE second-order step r (1 + e + e^2), e = 1 - x r,
+    // leaves an error of e^3 = 2^-72 -- 3 instructions instead of the 4 of two Newton steps, same 1.0 ulp maximum
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(__builtin_fma(e, e, e), r, r);
+#endif
 }
 __device__ __forceinline__ double fast_rsqrt(double x)
 {
+#ifdef NSDG_OLD_ELEMENTARY
     double y = __builtin_amdgcn_rsq(x);
     // y <- y + y*(1 - x y^2)/2, twice
     double e = __builtin_fma(-x * y, y, 1.0);
@@ -135,14 +144,25 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     e = __builtin_fma(-x * y, y, 1.0);
     y = __builtin_fma(0.5 * y, e, y);
     return y;
+#else
+    // one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - x y^2: 5 instructions instead of 8, the same 1.24 ulp maximum
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, __builtin_fma(0.375, e, 0.5), y);
+#endif
 }
 __device__ __forceinline__ double fast_sqrt(double x)
 {
-    // sqrt(x) = x * rsqrt(x), one Goldschmidt-style correction on the product; exact zero stays zero
     const double y = fast_rsqrt(x);
+#ifdef NSDG_OLD_ELEMENTARY
+    // sqrt(x) = x * rsqrt(x), one Goldschmidt-style correction on the product; exact zero stays zero
     double g = x * y;
     g = __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);
     return x > 0. ? g : 0.;
+#else
+    // sqrt(x) = x * rsqrt(x) (within 2 ulp: it only scales the ocean drag); exact zero stays zero
+    return x > 0. ? x * y : 0.;
+#endif
 }
 
 // Neighbour-lane exchange of the marching kernels as DPP moves (GFX9 wave_shr:1 / wave_shl:1 shift the
