@@ -91,26 +91,44 @@ private:
         std::size_t& dataOff) const;
 };
 
-//! Writer of the same subset: groups, float64 datasets and string attributes, collected in memory and
-//! laid out by write().
+//! Writer of the same subset: groups, float64 datasets, string and int32 attributes, and NetCDF-4 named dimensions
+//! (HDF5 dimension scales), collected in memory and laid out by write().
 class Hdf5Writer {
 public:
     //! creates the group (and its parents) if it does not exist yet
     void group(const std::string& path);
     void stringAttribute(const std::string& objectPath, const std::string& name, const std::string& value);
+    void intAttribute(const std::string& objectPath, const std::string& name, const std::vector<std::int32_t>& values, bool scalar);
     void dataset(const std::string& path, const std::vector<std::uint64_t>& dims, const std::vector<double>& values);
+    //! A NetCDF-4 dimension `name` of length n in `groupPath` that is not a variable: the dataset netCDF creates for it
+    //! (big-endian float32, no values written) with CLASS = "DIMENSION_SCALE", the NAME netCDF gives such dimensions and
+    //! _Netcdf4Dimid (core/src/DevGridIO.cpp:169-172 creates x, y, nLayers this way through netCDF-cxx4).
+    void dimension(const std::string& groupPath, const std::string& name, std::uint64_t n, int dimid);
+    //! Names the axes of a dataset: DIMENSION_LIST (one object reference per axis, through the global heap) and
+    //! _Netcdf4Coordinates on the variable, an entry in REFERENCE_LIST of every dimension (core/src/DevGridIO.cpp:174-201).
+    void attachDimensions(const std::string& datasetPath, const std::vector<std::string>& dimensionPaths);
     void write(const std::string& filePath) const;
 
 private:
+    struct Attribute {
+        std::string name;
+        std::vector<unsigned char> type, space, data; // message parts; `data` is patched with addresses by write()
+        std::vector<std::pair<std::size_t, std::string>> objectRefs; // offset in data -> path whose header address goes there
+        std::vector<std::pair<std::size_t, int>> heapRefs; // offset in data -> global heap object index (address + index go there)
+    };
     struct Node {
-        bool isDataset = false;
+        bool isDataset = false, isDimension = false;
+        int dimid = -1;
         std::vector<std::string> children; // insertion order
-        std::vector<std::pair<std::string, std::string>> attributes;
+        std::vector<Attribute> attributes;
         std::vector<std::uint64_t> dims;
         std::vector<double> values;
+        std::vector<std::string> axes; // attached dimensions (variables)
+        std::vector<std::pair<std::string, int>> referencedBy; // (variable, axis) pairs (dimensions)
     };
     std::map<std::string, Node> m_nodes = { { "/", Node() } };
     Node& ensureGroup(const std::string& path);
+    Node& find(const std::string& path);
 };
 
 } // namespace Nextsim

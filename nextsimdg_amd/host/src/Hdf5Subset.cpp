@@ -3,6 +3,8 @@
 // IV.A.2.* header messages).
 #include "Hdf5Subset.hpp"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iterator>
@@ -565,12 +567,111 @@ Hdf5Writer::Node& Hdf5Writer::ensureGroup(const std::string& pathIn)
 
 void Hdf5Writer::group(const std::string& path) { ensureGroup(path); }
 
+Hdf5Writer::Node& Hdf5Writer::find(const std::string& path)
+{
+    const auto it = m_nodes.find(normalise(path));
+    if (it == m_nodes.end())
+        throw Hdf5Error("no object " + path);
+    return it->second;
+}
+
+namespace {
+// message parts of the datatypes / dataspaces the writer knows (HDF5 File Format Specification IV.A.2.b, IV.A.2.d)
+std::vector<unsigned char> stringType(std::size_t size)
+{
+    std::vector<unsigned char> b = { 0x13, 0, 0, 0 }; // class 3 string, null-terminated, ASCII
+    put(b, size, 4);
+    return b;
+}
+std::vector<unsigned char> int32Type()
+{
+    std::vector<unsigned char> b = { 0x10, 0x08, 0, 0 }; // class 0 fixed point, little endian, signed
+    put(b, 4, 4);
+    put(b, 0, 2), put(b, 32, 2); // bit offset, precision
+    return b;
+}
+std::vector<unsigned char> float64Type()
+{
+    std::vector<unsigned char> b = { 0x11, 0x20, 0x3f, 0x00 }; // IEEE float, little endian, implied mantissa msb, sign bit 63
+    put(b, 8, 4);
+    put(b, 0, 2), put(b, 64, 2); // bit offset, precision
+    b.push_back(52), b.push_back(11), b.push_back(0), b.push_back(52); // exponent location/size, mantissa location/size
+    put(b, 1023, 4);
+    return b;
+}
+std::vector<unsigned char> float32BigEndianType()
+{
+    std::vector<unsigned char> b = { 0x11, 0x21, 0x1f, 0x00 }; // IEEE float, big endian, implied mantissa msb, sign bit 31
+    put(b, 4, 4);
+    put(b, 0, 2), put(b, 32, 2);
+    b.push_back(23), b.push_back(8), b.push_back(0), b.push_back(23);
+    put(b, 127, 4);
+    return b;
+}
+std::vector<unsigned char> objectReferenceType()
+{
+    std::vector<unsigned char> b = { 0x17, 0, 0, 0 }; // class 7 reference, type 0 = object reference
+    put(b, 8, 4);
+    return b;
+}
+std::vector<unsigned char> vlenOfObjectReferencesType()
+{
+    std::vector<unsigned char> b = { 0x19, 0, 0, 0 }; // class 9 variable length, type 0 = sequence
+    put(b, 16, 4); // in the file: 4-byte length + global heap id (8-byte address + 4-byte index)
+    const auto base = objectReferenceType();
+    b.insert(b.end(), base.begin(), base.end());
+    return b;
+}
+std::vector<unsigned char> referenceListType()
+{ // H5DS: compound { hobj_ref_t dataset; int dimension; } with the in-memory layout of ds_list_t (16 bytes)
+    std::vector<unsigned char> b = { 0x36, 2, 0, 0 }; // class 6 compound, version 3, two members
+    put(b, 16, 4);
+    for (const char c : std::string("dataset"))
+        b.push_back((unsigned char)c);
+    b.push_back(0);
+    b.push_back(0); // byte offset of the member (one byte: the compound is smaller than 256 bytes)
+    auto t = objectReferenceType();
+    b.insert(b.end(), t.begin(), t.end());
+    for (const char c : std::string("dimension"))
+        b.push_back((unsigned char)c);
+    b.push_back(0);
+    b.push_back(8);
+    t = int32Type();
+    b.insert(b.end(), t.begin(), t.end());
+    return b;
+}
+std::vector<unsigned char> scalarSpace() { return { 2, 0, 0, 0 }; }
+std::vector<unsigned char> simpleSpace(const std::vector<std::uint64_t>& dims)
+{
+    std::vector<unsigned char> b = { 2, (unsigned char)dims.size(), 0, 1 };
+    for (std::uint64_t d : dims)
+        put(b, d, 8);
+    return b;
+}
+} // namespace
+
 void Hdf5Writer::stringAttribute(const std::string& objectPath, const std::string& name, const std::string& value)
 {
-    const auto it = m_nodes.find(normalise(objectPath));
-    if (it == m_nodes.end())
-        throw Hdf5Error("no object " + objectPath);
-    it->second.attributes.emplace_back(name, value);
+    Attribute a;
+    a.name = name;
+    a.type = stringType(value.size() + 1);
+    a.space = scalarSpace();
+    a.data.assign(value.begin(), value.end());
+    a.data.push_back(0);
+    find(objectPath).attributes.push_back(a);
+}
+
+void Hdf5Writer::intAttribute(const std::string& objectPath, const std::string& name, const std::vector<std::int32_t>& values, bool scalar)
+{
+    if (scalar && values.size() != 1)
+        throw Hdf5Error("a scalar attribute has one value: " + name);
+    Attribute a;
+    a.name = name;
+    a.type = int32Type();
+    a.space = scalar ? scalarSpace() : simpleSpace({ (std::uint64_t)values.size() });
+    for (std::int32_t v : values)
+        put(a.data, (std::uint32_t)v, 4);
+    find(objectPath).attributes.push_back(a);
 }
 
 void Hdf5Writer::dataset(const std::string& pathIn, const std::vector<std::uint64_t>& dims, const std::vector<double>& values)
@@ -589,30 +690,97 @@ void Hdf5Writer::dataset(const std::string& pathIn, const std::vector<std::uint6
     node.values = values;
 }
 
+void Hdf5Writer::dimension(const std::string& groupPath, const std::string& name, std::uint64_t n, int dimid)
+{
+    const std::string path = normalise(groupPath + "/" + name);
+    if (m_nodes.count(path))
+        throw Hdf5Error("object exists: " + path);
+    Node& node = ensureGroup(path);
+    node.isDataset = node.isDimension = true;
+    node.dimid = dimid;
+    node.dims = { n };
+    stringAttribute(path, "CLASS", "DIMENSION_SCALE");
+    char text[80];
+    std::snprintf(text, sizeof text, "This is a netCDF dimension but not a netCDF variable.%10llu", (unsigned long long)n);
+    stringAttribute(path, "NAME", text);
+    intAttribute(path, "_Netcdf4Dimid", { dimid }, true);
+}
+
+void Hdf5Writer::attachDimensions(const std::string& datasetPath, const std::vector<std::string>& dimensionPaths)
+{
+    Node& var = find(datasetPath);
+    if (!var.isDataset || var.isDimension || var.dims.size() != dimensionPaths.size())
+        throw Hdf5Error("attachDimensions: " + datasetPath + " needs one dimension per axis");
+    if (!var.axes.empty())
+        throw Hdf5Error("attachDimensions: " + datasetPath + " has its dimensions already");
+    std::vector<std::int32_t> ids;
+    for (std::size_t k = 0; k < dimensionPaths.size(); ++k) {
+        Node& d = find(dimensionPaths[k]);
+        if (!d.isDimension || d.dims[0] != var.dims[k])
+            throw Hdf5Error("attachDimensions: " + dimensionPaths[k] + " is not a dimension of the right length");
+        d.referencedBy.emplace_back(normalise(datasetPath), (int)k);
+        var.axes.push_back(normalise(dimensionPaths[k]));
+        ids.push_back(d.dimid);
+    }
+    intAttribute(datasetPath, "_Netcdf4Coordinates", ids, false);
+}
+
 void Hdf5Writer::write(const std::string& filePath) const
 {
-    // message bodies that do not depend on addresses
-    auto attributeBody = [](const std::pair<std::string, std::string>& a) {
+    // ---- attributes that refer to other objects are generated here, when all attachments are known
+    std::map<std::string, std::vector<Attribute>> attrs;
+    int heapObjects = 0; // global heap: one 8-byte object reference per (variable, axis)
+    std::vector<std::string> heapTargets; // heap object i+1 holds the address of this path
+    for (const auto& kv : m_nodes) {
+        std::vector<Attribute> list = kv.second.attributes;
+        const Node& n = kv.second;
+        if (!n.axes.empty()) {
+            Attribute a;
+            a.name = "DIMENSION_LIST";
+            a.type = vlenOfObjectReferencesType();
+            a.space = simpleSpace({ (std::uint64_t)n.axes.size() });
+            for (const std::string& axis : n.axes) {
+                put(a.data, 1, 4); // sequence of one reference
+                a.heapRefs.emplace_back(a.data.size(), ++heapObjects);
+                put(a.data, 0, 8), put(a.data, 0, 4); // heap address + object index, patched below
+                heapTargets.push_back(axis);
+            }
+            list.insert(list.begin(), a);
+        }
+        if (n.isDimension && !n.referencedBy.empty()) {
+            Attribute a;
+            a.name = "REFERENCE_LIST";
+            a.type = referenceListType();
+            a.space = simpleSpace({ (std::uint64_t)n.referencedBy.size() });
+            for (const auto& ref : n.referencedBy) {
+                a.objectRefs.emplace_back(a.data.size(), ref.first);
+                put(a.data, 0, 8);
+                put(a.data, (std::uint32_t)ref.second, 4);
+                put(a.data, 0, 4); // padding of ds_list_t
+            }
+            list.push_back(a);
+        }
+        attrs[kv.first] = list;
+    }
+    auto attributeBody = [](const Attribute& a) {
         std::vector<unsigned char> b = { 3, 0 };
-        put(b, a.first.size() + 1, 2);
-        put(b, 8, 2); // datatype size
-        put(b, 4, 2); // dataspace size
+        put(b, a.name.size() + 1, 2);
+        put(b, a.type.size(), 2);
+        put(b, a.space.size(), 2);
         b.push_back(0); // ASCII name
-        b.insert(b.end(), a.first.begin(), a.first.end());
+        b.insert(b.end(), a.name.begin(), a.name.end());
         b.push_back(0);
-        b.push_back(0x13), b.push_back(0), b.push_back(0), b.push_back(0); // string, null-terminated, ASCII
-        put(b, a.second.size() + 1, 4);
-        b.push_back(2), b.push_back(0), b.push_back(0), b.push_back(0); // scalar dataspace (version 2)
-        b.insert(b.end(), a.second.begin(), a.second.end());
-        b.push_back(0);
+        b.insert(b.end(), a.type.begin(), a.type.end());
+        b.insert(b.end(), a.space.begin(), a.space.end());
+        b.insert(b.end(), a.data.begin(), a.data.end());
         return b;
     };
-    // header size per node: prefix (4 + 1 + 1 + 4) + messages + checksum
-    auto headerSize = [&](const Node& n) {
+    // header size per node: messages only (the prefix and the checksum are added by the caller)
+    auto headerSize = [&](const std::string& path, const Node& n) {
         std::size_t s = 0;
         if (n.isDataset) {
             s += 4 + 4 + 8 * n.dims.size(); // dataspace
-            s += 4 + 20; // datatype
+            s += 4 + (n.isDimension ? float32BigEndianType().size() : float64Type().size()); // datatype
             s += 4 + 2; // fill value
             s += 4 + 18; // layout
         } else {
@@ -621,22 +789,34 @@ void Hdf5Writer::write(const std::string& filePath) const
             for (const std::string& c : n.children)
                 s += 4 + 3 + c.size() + 8;
         }
-        for (const auto& a : n.attributes)
+        for (const auto& a : attrs.at(path))
             s += 4 + attributeBody(a).size();
         return s;
     };
-    // addresses: superblock, all object headers (map order), then the raw data, 8-byte aligned
+    auto storageBytes = [](const Node& n) { return n.isDimension ? 4 * n.dims[0] : 8 * (std::uint64_t)n.values.size(); };
+    // addresses: superblock, all object headers (map order), the global heap collection, then the raw data, 8-byte aligned
     std::map<std::string, std::uint64_t> headerAt, dataAt;
     std::uint64_t at = 48;
     for (const auto& kv : m_nodes) {
         headerAt[kv.first] = at;
-        at += 10 + headerSize(kv.second) + 4;
+        const std::size_t hs = headerSize(kv.first, kv.second);
+        if (hs > 0xffffffffu)
+            throw Hdf5Error("object header too large");
+        at += 10 + hs + 4;
+    }
+    std::uint64_t heapAt = 0, heapSize = 0;
+    if (heapObjects > 0) {
+        at = (at + 7) / 8 * 8;
+        heapAt = at;
+        heapSize = std::max<std::uint64_t>(4096, 16 + 24 * (std::uint64_t)heapObjects + 16);
+        heapSize = (heapSize + 7) / 8 * 8;
+        at += heapSize;
     }
     for (const auto& kv : m_nodes)
         if (kv.second.isDataset) {
             at = (at + 7) / 8 * 8;
             dataAt[kv.first] = at;
-            at += 8 * kv.second.values.size();
+            at += storageBytes(kv.second);
         }
     const std::uint64_t eof = at;
 
@@ -645,24 +825,22 @@ void Hdf5Writer::write(const std::string& filePath) const
     put(f, 0, 8), put(f, UNDEF, 8), put(f, eof, 8), put(f, headerAt.at("/"), 8);
     put(f, hdf5Checksum(f.data(), f.size()), 4);
 
+    auto patch = [](std::vector<unsigned char>& b, std::size_t off, std::uint64_t v, int n) {
+        for (int i = 0; i < n; ++i)
+            b[off + i] = (unsigned char)(v >> (8 * i));
+    };
     for (const auto& kv : m_nodes) {
         const Node& n = kv.second;
+        const std::size_t hs = headerSize(kv.first, n);
+        // chunk-0 size field: 1, 2 or 4 bytes (flags bits 0-1); 4 bytes always keeps the layout arithmetic simple
         std::vector<unsigned char> h = { 'O', 'H', 'D', 'R', 2, 0x02 };
-        put(h, headerSize(n), 4);
+        put(h, hs, 4);
         if (n.isDataset) {
-            std::vector<unsigned char> b = { 2, (unsigned char)n.dims.size(), 0, 1 };
-            for (std::uint64_t d : n.dims)
-                put(b, d, 8);
-            message(h, MSG_DATASPACE, b);
-            b = { 0x11, 0x20, 0x3f, 0x00 }; // IEEE float, little endian, implied mantissa msb, sign bit 63
-            put(b, 8, 4);
-            put(b, 0, 2), put(b, 64, 2); // bit offset, precision
-            b.push_back(52), b.push_back(11), b.push_back(0), b.push_back(52); // exponent location/size, mantissa location/size
-            put(b, 1023, 4);
-            message(h, MSG_DATATYPE, b);
+            message(h, MSG_DATASPACE, simpleSpace(n.dims));
+            message(h, MSG_DATATYPE, n.isDimension ? float32BigEndianType() : float64Type());
             message(h, MSG_FILL_VALUE, { 3, 0x09 }); // early allocation, fill written if set, no fill value defined
-            b = { 3, 1 };
-            put(b, dataAt.at(kv.first), 8), put(b, 8 * n.values.size(), 8);
+            std::vector<unsigned char> b = { 3, 1 };
+            put(b, dataAt.at(kv.first), 8), put(b, storageBytes(n), 8);
             message(h, MSG_LAYOUT, b);
         } else {
             std::vector<unsigned char> b = { 0, 0 };
@@ -678,19 +856,41 @@ void Hdf5Writer::write(const std::string& filePath) const
                 message(h, MSG_LINK, b);
             }
         }
-        for (const auto& a : n.attributes)
+        for (Attribute a : attrs.at(kv.first)) {
+            for (const auto& r : a.objectRefs)
+                patch(a.data, r.first, headerAt.at(r.second), 8);
+            for (const auto& r : a.heapRefs) {
+                patch(a.data, r.first, heapAt, 8);
+                patch(a.data, r.first + 8, (std::uint64_t)r.second, 4);
+            }
             message(h, MSG_ATTRIBUTE, attributeBody(a));
+        }
         put(h, hdf5Checksum(h.data(), h.size()), 4);
-        if (f.size() != headerAt.at(kv.first) || h.size() != 10 + headerSize(n) + 4)
+        if (f.size() != headerAt.at(kv.first) || h.size() != 10 + hs + 4)
             throw Hdf5Error("internal layout error");
         f.insert(f.end(), h.begin(), h.end());
+    }
+    if (heapObjects > 0) { // global heap collection (III.E): the targets of the DIMENSION_LIST references
+        f.resize((std::size_t)heapAt, 0);
+        std::vector<unsigned char> g = { 'G', 'C', 'O', 'L', 1, 0, 0, 0 };
+        put(g, heapSize, 8);
+        for (int i = 0; i < heapObjects; ++i) {
+            put(g, (std::uint64_t)(i + 1), 2), put(g, 1, 2), put(g, 0, 4); // index, reference count, reserved
+            put(g, 8, 8); // object size
+            put(g, headerAt.at(heapTargets[(std::size_t)i]), 8);
+        }
+        const std::uint64_t free = heapSize - g.size();
+        put(g, 0, 2), put(g, 0, 2), put(g, 0, 4), put(g, free, 8); // object 0: the free space, its size includes this header
+        g.resize((std::size_t)heapSize, 0);
+        f.insert(f.end(), g.begin(), g.end());
     }
     for (const auto& kv : m_nodes)
         if (kv.second.isDataset) {
             f.resize((std::size_t)dataAt.at(kv.first), 0);
             const std::size_t at0 = f.size();
-            f.resize(at0 + 8 * kv.second.values.size());
-            std::memcpy(&f[at0], kv.second.values.data(), 8 * kv.second.values.size()); // host is little endian (x86-64)
+            f.resize(at0 + (std::size_t)storageBytes(kv.second), 0);
+            if (!kv.second.isDimension && !kv.second.values.empty())
+                std::memcpy(&f[at0], kv.second.values.data(), 8 * kv.second.values.size()); // host is little endian (x86-64)
         }
     std::ofstream out(filePath, std::ios::binary);
     if (!out || !out.write(reinterpret_cast<const char*>(f.data()), (std::streamsize)f.size()))

@@ -156,11 +156,19 @@ void RectGrid::dump(const std::string& filePath) const
         Hdf5Writer w;
         w.group("/" + metadataNodeName());
         w.stringAttribute("/" + metadataNodeName(), typeNodeName(), structureType());
-        w.group("/" + dataNodeName());
+        const std::string data = "/" + dataNodeName();
+        w.group(data);
+        // the named dimensions of core/src/DevGridIO.cpp:169-172 (NetCDF-4 stores them as HDF5 dimension scales)
+        w.dimension(data, "x", (std::uint64_t)m_nx, 0);
+        w.dimension(data, "y", (std::uint64_t)m_ny, 1);
+        w.dimension(data, "nLayers", (std::uint64_t)m_store.nLayers, 2);
         const std::vector<double>* planes[5] = { &m_store.hice, &m_store.cice, &m_store.hsnow, &m_store.sst, &m_store.sss };
-        for (int k = 0; k < 5; ++k)
-            w.dataset("/" + dataNodeName() + "/" + PLANE_NAMES[k], { (std::uint64_t)m_nx, (std::uint64_t)m_ny }, *planes[k]);
-        w.dataset("/" + dataNodeName() + "/tice", { (std::uint64_t)m_nx, (std::uint64_t)m_ny, (std::uint64_t)m_store.nLayers }, t);
+        for (int k = 0; k < 5; ++k) {
+            w.dataset(data + "/" + PLANE_NAMES[k], { (std::uint64_t)m_nx, (std::uint64_t)m_ny }, *planes[k]);
+            w.attachDimensions(data + "/" + PLANE_NAMES[k], { data + "/x", data + "/y" }); // DevGridIO.cpp:174-190
+        }
+        w.dataset(data + "/tice", { (std::uint64_t)m_nx, (std::uint64_t)m_ny, (std::uint64_t)m_store.nLayers }, t);
+        w.attachDimensions(data + "/tice", { data + "/x", data + "/y", data + "/nLayers" }); // DevGridIO.cpp:192-201
         w.write(filePath);
         return;
     }

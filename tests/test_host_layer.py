@@ -55,6 +55,30 @@ def test_written_restart_file_is_read_by_the_hdf5_library(host_build, tmp_path):
         assert needle in head, (needle, head)
     rc, attr = run([h5dump, "-a", "/structure/type", path])
     assert rc == 0 and '"rectgrid"' in attr, attr
+    # NetCDF-4 named dimensions x, y, nLayers (core/src/DevGridIO.cpp:169-201): the HDF5 library resolves the object
+    # references of DIMENSION_LIST / REFERENCE_LIST (global heap, compound type) exactly as in the reference's own file
+    rc, att = run([h5dump, "-A", path])
+    assert rc == 0, att
+    rc, ref = run([h5dump, "-A", os.path.join(GOLDEN, "dev1.res.nc")])
+    assert rc == 0, ref
+
+    def attributes(text):  # {dataset: sorted attribute names}, and the resolved reference targets
+        out, cur = {}, None
+        for ln in text.splitlines():
+            m = re.search(r'DATASET "(\w+)" \{', ln)
+            if m:
+                cur = m.group(1)
+                out[cur] = []
+            m = re.search(r'ATTRIBUTE "(\w+)"', ln)
+            if m and cur:
+                out[cur].append(m.group(1))
+        return {k: sorted(v) for k, v in out.items()}
+
+    assert attributes(att) == attributes(ref)  # same datasets (x, y, nLayers included), same attributes on each
+    assert re.search(r"\(DATASET \d+ /data/x \), \(DATASET \d+ /data/y \),\s+\(2\): \(DATASET \d+ /data/nLayers \)", att)  # tice: (x, y, nLayers)
+    assert att.count("/data/x ), (DATASET") >= 6 and '"This is a netCDF dimension but not a netCDF variable.         6"' in att
+    for needle in ('"DIMENSION_SCALE"', "H5T_IEEE_F32BE", 'H5T_STD_I32LE "dimension"', "(0): 0, 1, 2"):
+        assert needle in att, needle
     rc, data = run([h5dump, "-d", "/data/hice", "-w", "400", path])
     assert rc == 0, data
     row4 = [ln for ln in data.splitlines() if ln.strip().startswith("(4,0):")]
