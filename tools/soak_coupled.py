@@ -1,8 +1,20 @@
-import os, sys, json
-sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+"""BASELINE config 5 as a run: dynamics + column thermodynamics for `steps` model steps of 120 s (720 = one day) on an
+n x n box, with the device-side forcing providers -- cyclone wind moving with model time (nsdg_boxtest_forcing), winter
+thermodynamic forcing with a diurnal short-wave cycle (nsdg_column_forcing) and the column wind speed taken from the
+dynamics' wind (nsdg_column_wind) -- on the native row-block driver.  Prints ranges every `every` steps and the wall time.
+usage: python tools/soak_coupled.py [steps=720] [n=512] [forcing=winter|dummy|host]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
 from nextsimdg_amd import abi, rowblock, synthetic
-nx = ny = 512
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 720
+nx = ny = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+forcing = sys.argv[3] if len(sys.argv) > 3 else "winter"
 L, dt, nsub = 512e3, 120.0, 120
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
@@ -10,21 +22,31 @@ bt = synthetic.BoxTest(nx, ny, L)
 alpha = bt.stable_alpha(dt)
 ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
 blk = rowblock.RowBlock(nx, ny, 0, 1)
-core = rowblock.CoupledCore(ctx, blk, L / nx, L / ny, dt, nsub, dev)
-if len(sys.argv) > 2 and sys.argv[2] == "random":
-    cs, cf, _ = synthetic.column_fields(nx * ny)
-    col = {k: v.reshape(ny, nx) for k, v in {**cs, **cf}.items() if k not in ("hice", "cice")}
-else:
-    cs, cf = synthetic.column_fields_smooth(nx, ny, L)
-    col = {**cs, **cf}
-core.load_column(col)
-H, A = bt.dg_fields(); uo, vo = bt.ocean(); ua, va = bt.wind(0.0)
+core = rowblock.CoupledCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, native=True, forcing=None if forcing == "host" else forcing)
+cs, cf = synthetic.column_fields_smooth(nx, ny, L)  # initial snow / ice temperature; sst at the freezing point (see the docstring there)
+core.load_column({**cs, **cf})
+H, A = bt.dg_fields()
+uo, vo = bt.ocean()
+ua, va = bt.wind(0.0)
 core.load_global(H, A, uo, vo, ua, va)
-for step in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+del H, A, uo, vo, ua, va, cs, cf
+m0 = float(core.H[0].sum())
+every = int(os.environ.get("NSDG_SOAK_EVERY", max(1, steps // 12)))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for step in range(steps):
+    core.device_wind(L, step * dt)  # the cyclone moves
     core.step()
-    fin = {k: bool(torch.isfinite(getattr(core, k)).all()) for k in ("u", "v", "H", "A")}
-    fin.update({k: bool(torch.isfinite(core.col[k]).all()) for k in ("hsnow", "tice0")})
-    if step % 10 == 0 or not all(fin.values()) or float(core.u.abs().max()) > 5.0:
-        print(step, fin, "umax %.3g Hmin %.3g Hmax %.3g Amin %.3g Amax %.3g" % (float(core.u.abs().max()), float(core.H[0].min()), float(core.H[0].max()), float(core.A[0].min()), float(core.A[0].max())), flush=True)
-    if not all(fin.values()) or float(core.u.abs().max()) > 5.0:
-        break
+    if step % every == 0 or step == steps - 1:
+        fin = all(bool(torch.isfinite(f).all()) for f in (core.u, core.v, core.H, core.A, core.col["hsnow"], core.col["tice0"]))
+        print("step %4d  t = %5.2f h  finite %s  umax %.3g  H [%.4f, %.4f]  A [%.4f, %.4f]  tice [%.2f, %.2f]  hsnow [%.3f, %.3f]  wind max %.1f  qsw max %.0f  newice max %.2e"
+              % (step, (step + 1) * dt / 3600.0, fin, float(core.u.abs().max()), float(core.H[0].min()), float(core.H[0].max()),
+                 float(core.A[0].min()), float(core.A[0].max()), float(core.col["tice0"].min()), float(core.col["tice0"].max()),
+                 float(core.col["hsnow"].min()), float(core.col["hsnow"].max()), float(core.col["wind"].max()), float(core.col["qsw"].max()),
+                 float(core.newice.max())), flush=True)
+        if not fin or float(core.u.abs().max()) > 5.0:
+            raise SystemExit("the coupled run left the physical range")
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+print("%d steps of %d x %d (%.1f model hours) in %.1f s wall: %.1f ms per step, %.3g element-steps/s; ice volume change %.3e (thermodynamic growth)"
+      % (steps, nx, ny, steps * dt / 3600.0, wall, 1e3 * wall / steps, nx * ny * steps / wall, float(core.H[0].sum()) / m0 - 1.0))

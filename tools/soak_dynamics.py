@@ -13,14 +13,15 @@ L, dt, nsub = 512e3, 120.0, 120
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
-alpha = bt.stable_alpha(dt)
+alpha = bt.stable_alpha(dt) * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # experiment: margin over the stability bound
 ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
-core = rowblock.DynamicsCore(ctx, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, dev)
+core = rowblock.DynamicsCore(ctx, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, dev, native=True)
 H, A = bt.dg_fields()
 uo, vo = bt.ocean()
 ua, va = bt.wind(0.0)
 core.load_global(H, A, uo, vo, ua, va)
 m0 = float(core.H[0].sum())
+start = int(os.environ.get("NSDG_SOAK_START", "0"))
 for step in range(720):
     ctx.set_grid(nx, ny, L / nx, L / ny)
     ctx.boxtest_forcing(L, step * dt, wind=(core.ua, core.va))
