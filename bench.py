@@ -369,6 +369,9 @@ def main():
     del H, A, uo, vo, ua, va
 
     def sync():
+        # drain this rank's own work first: the ghost exchanges run on the library's RCCL communicator, the barrier on
+        # torch's -- two communicators are never given work at the same time
+        torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -463,8 +466,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nsub)
         print(json.dumps(line), flush=True)
+    sync()
+    core = exchanger = None
+    ctx.close()  # the library's communicator goes before torch's process group
     if use_dist:
-        dist.barrier()
         dist.destroy_process_group()
 
 

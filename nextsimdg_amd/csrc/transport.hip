@@ -61,11 +61,67 @@ struct EdgeVel {
     double l[NG], r[NG], b[NG], t[NG];
 };
 
-// dphi_i/dt * m_i of one element from its own coefficients c, the four neighbours' coefficients (zero
+// What an element needs of a neighbour is the neighbour's TRACE at the NG Gauss points of the shared edge, not its NC
+// coefficients: the traces are formed as soon as a neighbour's coefficients are loaded and the coefficients die
+// (round 2: 12 instead of 24 live doubles for the four DG2 neighbours; the kernel was latency-bound at 2 waves per
+// SIMD with 191-197 registers).  Same sums in the same order as before: bit-identical results.
+template <int NG>
+struct NbTrace {
+    double l[NG], r[NG], b[NG], t[NG]; // the left / right / bottom / top neighbour's values on my edges
+};
+template <int ORDER>
+__device__ __forceinline__ void trace_of_left(const double (&cl)[DG<ORDER>::NC], double (&tr)[DG<ORDER>::NG])
+{
+#pragma unroll
+    for (int g = 0; g < DG<ORDER>::NG; ++g) {
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < DG<ORDER>::NC; ++k)
+            FMA_TAB(s, t_r<ORDER>(g, k), cl[k]); // the left neighbour's right trace
+        tr[g] = s;
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void trace_of_right(const double (&cr)[DG<ORDER>::NC], double (&tr)[DG<ORDER>::NG])
+{
+#pragma unroll
+    for (int g = 0; g < DG<ORDER>::NG; ++g) {
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < DG<ORDER>::NC; ++k)
+            FMA_TAB(s, t_l<ORDER>(g, k), cr[k]);
+        tr[g] = s;
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void trace_of_bottom(const double (&cb)[DG<ORDER>::NC], double (&tr)[DG<ORDER>::NG])
+{
+#pragma unroll
+    for (int g = 0; g < DG<ORDER>::NG; ++g) {
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < DG<ORDER>::NC; ++k)
+            FMA_TAB(s, t_t<ORDER>(g, k), cb[k]);
+        tr[g] = s;
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void trace_of_top(const double (&ct)[DG<ORDER>::NC], double (&tr)[DG<ORDER>::NG])
+{
+#pragma unroll
+    for (int g = 0; g < DG<ORDER>::NG; ++g) {
+        double s = 0.;
+#pragma unroll
+        for (int k = 0; k < DG<ORDER>::NC; ++k)
+            FMA_TAB(s, t_b<ORDER>(g, k), ct[k]);
+        tr[g] = s;
+    }
+}
+
+// dphi_i/dt * m_i of one element from its own coefficients c, the four neighbours' traces on its edges (zero
 // outside the array), its DG velocity (already divided by hx, hy) and its edge-normal velocities
 template <int ORDER>
-__device__ __forceinline__ void transport_rhs(const double (&c)[DG<ORDER>::NC], const double (&cl)[DG<ORDER>::NC],
-    const double (&cr)[DG<ORDER>::NC], const double (&cb)[DG<ORDER>::NC], const double (&ct)[DG<ORDER>::NC],
+__device__ __forceinline__ void transport_rhs(const double (&c)[DG<ORDER>::NC], const NbTrace<DG<ORDER>::NG>& nb,
     const double (&vx)[DG<ORDER>::NC], const double (&vy)[DG<ORDER>::NC], const EdgeVel<DG<ORDER>::NG>& E, double ihx, double ihy,
     double (&rhs)[DG<ORDER>::NC])
 {
@@ -95,17 +151,14 @@ __device__ __forceinline__ void transport_rhs(const double (&c)[DG<ORDER>::NC], 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const double unl = E.l[g], unr = E.r[g], unb = E.b[g], unt = E.t[g];
-        double in_r = 0., in_l = 0., in_t = 0., in_b = 0., out_r = 0., out_l = 0., out_t = 0., out_b = 0.;
+        double in_r = 0., in_l = 0., in_t = 0., in_b = 0.;
+        const double out_r = nb.r[g], out_l = nb.l[g], out_t = nb.t[g], out_b = nb.b[g];
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             FMA_TAB(in_r, t_r<ORDER>(g, k), c[k]);
             FMA_TAB(in_l, t_l<ORDER>(g, k), c[k]);
             FMA_TAB(in_t, t_t<ORDER>(g, k), c[k]);
             FMA_TAB(in_b, t_b<ORDER>(g, k), c[k]);
-            FMA_TAB(out_r, t_l<ORDER>(g, k), cr[k]);
-            FMA_TAB(out_l, t_r<ORDER>(g, k), cl[k]);
-            FMA_TAB(out_t, t_b<ORDER>(g, k), ct[k]);
-            FMA_TAB(out_b, t_t<ORDER>(g, k), cb[k]);
         }
         // upwind fluxes (outward normal velocity is +un on right/top, the flux direction is +x/+y)
         const double fr = (fmax(unr, 0.) * in_r + fmin(unr, 0.) * out_r) * ihx;
@@ -127,7 +180,7 @@ __device__ __forceinline__ void transport_rhs(const double (&c)[DG<ORDER>::NC], 
 // velocity are processed by the same lane, so the DG velocity and the edge velocities are loaded once.
 template <int ORDER>
 #ifndef NSDG_TR_WAVES
-#define NSDG_TR_WAVES 1
+#define NSDG_TR_WAVES 3 // 157 registers with the edge-trace form: 3 waves per SIMD without scratch (4 spill: slower)
 #endif
 __global__ __launch_bounds__(256, NSDG_TR_WAVES) void transport_stage_kernel(int nx, int ny, int j0, int j1, int nfields, double ihx, double ihy,
     double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
@@ -162,17 +215,32 @@ __global__ __launch_bounds__(256, NSDG_TR_WAVES) void transport_stage_kernel(int
         const double* __restrict__ phis = fp.phis[f];
         const double* __restrict__ phi0 = fp.phi0[f];
         double* __restrict__ out = fp.out[f];
-        double c[NC], cl[NC], cr[NC], cb[NC], ct[NC];
+        double c[NC];
+        NbTrace<NG> nb;
+        {
+            double w[NC];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            c[k] = phis[k * N + e];
-            cl[k] = hasL ? phis[k * N + e - 1] : 0.;
-            cr[k] = hasR ? phis[k * N + e + 1] : 0.;
-            cb[k] = hasB ? phis[k * N + e - nx] : 0.;
-            ct[k] = hasT ? phis[k * N + e + nx] : 0.;
+            for (int k = 0; k < NC; ++k)
+                w[k] = hasL ? phis[k * N + e - 1] : 0.;
+            trace_of_left<ORDER>(w, nb.l);
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                w[k] = hasR ? phis[k * N + e + 1] : 0.;
+            trace_of_right<ORDER>(w, nb.r);
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                w[k] = hasB ? phis[k * N + e - nx] : 0.;
+            trace_of_bottom<ORDER>(w, nb.b);
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                w[k] = hasT ? phis[k * N + e + nx] : 0.;
+            trace_of_top<ORDER>(w, nb.t);
         }
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            c[k] = phis[k * N + e];
         double rhs[NC];
-        transport_rhs<ORDER>(c, cl, cr, cb, ct, vx, vy, E, ihx, ihy, rhs);
+        transport_rhs<ORDER>(c, nb, vx, vy, E, ihx, ihy, rhs);
         if (a != 0.) {
 #pragma unroll
             for (int i = 0; i < NC; ++i)
@@ -246,7 +314,12 @@ __global__ __launch_bounds__(256) void transport_march_kernel(int nx, int ny, in
             E.t[g] = un_y[g * NEY + e + nx];
         }
         double rhs[NC];
-        transport_rhs<ORDER>(c, cl, cr, cb, ct, vx, vy, E, ihx, ihy, rhs);
+        NbTrace<NG> nb;
+        trace_of_left<ORDER>(cl, nb.l);
+        trace_of_right<ORDER>(cr, nb.r);
+        trace_of_bottom<ORDER>(cb, nb.b);
+        trace_of_top<ORDER>(ct, nb.t);
+        transport_rhs<ORDER>(c, nb, vx, vy, E, ihx, ihy, rhs);
         if (a != 0.) {
 #pragma unroll
             for (int i = 0; i < NC; ++i)

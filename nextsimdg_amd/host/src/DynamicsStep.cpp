@@ -91,7 +91,7 @@ double DynamicsStep::stableAlpha(double h, double dt)
     const double pstar = 27.5e3, dmin = 2e-9, rho = 900., hice = 0.3;
     const double zeta = pstar * hice / (2. * dmin);
     const double pi = 3.14159265358979323846;
-    return std::max(1500., 1.2 * std::sqrt(pi * pi * zeta * dt / (rho * hice * h * h)));
+    return std::max(1500., 2.4 * std::sqrt(pi * pi * zeta * dt / (rho * hice * h * h))); // 2.4: margin a one-day run needs
 }
 
 void DynamicsStep::splitRows(int ny, int world, int rank, int& r0, int& r1)

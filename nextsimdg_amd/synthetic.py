@@ -56,12 +56,16 @@ class BoxTest:
         self.nx, self.ny, self.L = nx, ny, L
         self.hx, self.hy = L / nx, L / ny
 
-    def stable_alpha(self, dt, pstar=27.5e3, delta_min=2e-9, rho_ice=900.0, h_ice=0.3, safety=1.2, floor=1500.0):
+    def stable_alpha(self, dt, pstar=27.5e3, delta_min=2e-9, rho_ice=900.0, h_ice=0.3, safety=2.4, floor=1500.0):
         """alpha = beta for which the mEVP pseudo-time iteration is linearly stable on this mesh:
         alpha*beta >= pi^2 * zeta_max * dt / (m * h^2), zeta_max = P*H/(2 Delta_min), m = rho_i H.
         (Measured on the MI355X, round 1: with alpha = beta = 1500 round-off differences between two
         kernel variants grow x150 per sub-iteration at h = 250 m; the bound -- 1.2e4 there -- is sharp:
-        12000 is stable, 6000 is not.  The flop and byte counts do not depend on alpha.)"""
+        12000 is stable, 6000 is not.  Round 2: that is the bound of the INITIAL state; a one-day run needs margin --
+        with 1.2 x the bound the dynamics at 2048^2 / 4096^2 diverge after 21-23 model hours (deformation zones sharpen,
+        the local ratio of ice strength to nodal mass grows), with 1.8 x they start to (free-drift speeds at hour 24),
+        with 2.4 x and 3.6 x the day completes (profiles/r02_alpha_margin.txt); the default is 2.4 x.
+        The flop and byte counts do not depend on alpha.)"""
         h = min(self.hx, self.hy)
         zeta_max = pstar * h_ice / (2.0 * delta_min)
         bound = np.sqrt(np.pi ** 2 * zeta_max * dt / (rho_ice * h_ice * h * h))

@@ -21,7 +21,6 @@ uo, vo = bt.ocean()
 ua, va = bt.wind(0.0)
 core.load_global(H, A, uo, vo, ua, va)
 m0 = float(core.H[0].sum())
-start = int(os.environ.get("NSDG_SOAK_START", "0"))
 for step in range(720):
     ctx.set_grid(nx, ny, L / nx, L / ny)
     ctx.boxtest_forcing(L, step * dt, wind=(core.ua, core.va))
