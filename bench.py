@@ -303,8 +303,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (gloo): launch, rendezvous, planning; no metric")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return self_launch(args.gpus)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("NSDG_BENCH_SELF_LAUNCH")):
+        return self_launch(args.gpus)  # NSDG_BENCH_SELF_LAUNCH: rehearse the launcher path with one rank on a one-GPU box
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
