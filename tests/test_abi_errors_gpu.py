@@ -89,3 +89,36 @@ def test_row_ranges_aliasing_and_sequence(ctx):
     ctx.transport_stage(2, 5, 5, 1.0, 0.0, 1.0, [z(6, ny, nx)], [z(6, ny, nx)], [z(6, ny, nx)],
                         (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx)))
     torch.cuda.synchronize()
+
+
+def test_parameter_or_grid_change_invalidates_the_packed_coefficients(ctx):
+    """the launch constants of the velocity update (K1, K2 from beta, rho_ice and dt) belong to the packing: changing the
+    mEVP parameters or the grid between nsdg_mevp_pack_nodal and an iterate must be an error, not a silent mix of two
+    parameter sets; repacking makes the call valid again"""
+    nx, ny = 70, 12
+    ctx.set_grid(nx, ny, 1.0, 1.0)
+    s = [ctx.private_zeros(8, ny, nx, "cuda") for _ in range(3)]
+    so = [torch.zeros_like(x) for x in s]
+    pg = ctx.private_zeros(9, ny, nx, "cuda")
+    u, v, un, vn = (z(2 * ny + 1, 2 * nx + 1) for _ in range(4))
+    packed = z(8 * u.numel())
+    nodal = [(u, v), (u, v), (u, v), u, v]
+    ctx.mevp_pack_nodal(120.0, *nodal, packed)
+    ctx.mevp_iterate(0, 0, ny, s, so, (u, v), (un, vn), packed, pg)  # fine
+    ctx.set_mevp_params(ctx.mevp_default_params(beta=777.0))
+    for call in (lambda: ctx.mevp_iterate(0, 0, ny, s, so, (u, v), (un, vn), packed, pg),
+                 lambda: ctx.mevp_iterate3(0, ny, s, so, (u, v), (un, vn), packed, pg),
+                 lambda: ctx.mevp_velocity(0, ny, s, (u, v), (un, vn), packed)):
+        with pytest.raises(abi.NsdgError, match="pack_nodal was not called"):
+            call()
+    ctx.mevp_pack_nodal(120.0, *nodal, packed)
+    ctx.mevp_iterate3(0, ny, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_grid(nx, ny, 2.0, 1.0)  # another cell size: the coefficients belong to the old grid
+    with pytest.raises(abi.NsdgError, match="pack_nodal was not called"):
+        ctx.mevp_iterate(0, 0, ny, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_grid(nx, ny, 2.0, 1.0)  # setting the same grid again changes nothing ...
+    ctx.mevp_pack_nodal(120.0, *nodal, packed)
+    ctx.set_grid(nx, ny, 2.0, 1.0)  # ... and does not invalidate a packing
+    ctx.mevp_iterate(0, 0, ny, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_mevp_params(ctx.mevp_default_params())
+    torch.cuda.synchronize()
