@@ -43,6 +43,22 @@ SHADER_CLOCK_PEAK_HZ = 2.4e9  # MI355X_MICROARCH.md: peak engine clock
 BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
 
 
+class stdout_to_stderr:
+    """RCCL prints a start-up banner (version, hostname, library path) on STDOUT when its first communicator is made;
+    stdout of this program carries exactly one JSON line, so file descriptor 1 points at stderr while communicators
+    are being created"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def host_cores():
     """usable host cores: the scheduler affinity, capped by the cgroup CPU quota of the box (a one-GPU box
     shows all hardware threads but grants a share of them; oversubscribing that share with one OpenMP thread
@@ -317,17 +333,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or bool(os.environ.get("NSDG_FORCE_DIST"))  # NSDG_FORCE_DIST: rehearse the RCCL set-up with one rank
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
     from nextsimdg_amd import build
 
     if rank == 0:
         build.build_lib(verbose=False)
-    if world > 1:
-        dist.barrier()
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.barrier()  # the first collective creates torch's communicator (and waits for rank 0's build)
+            torch.cuda.synchronize()
 
     if args.workload in ("column", "transport"):
         if world != 1:
@@ -351,7 +367,8 @@ def main():
     coupled = args.workload == "coupled"
     exchanger = None
     if world > 1 or os.environ.get("NSDG_FORCE_DIST"):
-        exchanger = make_exchanger(args.halo, ctx, blk, device)
+        with stdout_to_stderr():  # the library's own RCCL communicator
+            exchanger = make_exchanger(args.halo, ctx, blk, device)
     native = args.driver == "native" and (exchanger is None or isinstance(exchanger, rowblock.NativeHaloExchanger))
     core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device, exchanger=exchanger,
                                                                         native=native, use_graph=args.graph)

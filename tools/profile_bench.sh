@@ -7,6 +7,7 @@ set -o pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 TAG="${1:-prof}"; shift
 OUT="$ROOT/gpurun_out/prof_$TAG"
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 PY="$(command -v python3)"

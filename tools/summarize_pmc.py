@@ -19,7 +19,7 @@ import sys
 
 
 def load(d):
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)  # the newest pass in that directory
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
