@@ -57,14 +57,16 @@ def test_config3_1024_transport_and_mevp_120_subiterations(gpu):
 def test_config4_2048_four_row_blocks_equal_single_domain_bitwise(gpu):
     """config 4: 2048x2048 DG2 full dynamics, 4 row blocks of 512 rows, 120 sub-iterations, 6 passes of the
     three-iteration kernel between two ghost-row exchanges (ghost depth 18 / 17), overlap split on, 2 model steps:
-    every owned row of every block equals the single-domain run bit for bit"""
+    every owned row of every block equals the single-domain run (Python sequence of launches) bit for bit"""
     n, nsub, nsteps, world, group = 2048, 120, 2, 4, 6
     data = fields(n, n, wind_scale=1.0)
     alpha = data[0].stable_alpha(120.0)
     mass0 = (float(np.sum(data[1][0])), float(np.sum(data[2][0])))
     ref = run_world(1, 3, False, n, n, nsub, nsteps, data=data, alpha=alpha)[0]
     check_physical(ref, mass0, n, n)
-    parts = run_world(world, 3, False, n, n, nsub, nsteps, group=group, data=data, alpha=alpha)
+    # the product path: native row-block drivers (nsdg_rb_*_run) and the exchange behind the C ABI (nsdg_halo_*) on its
+    # in-process transport -- everything of the 4-GPU run except RCCL itself
+    parts = run_world(world, 3, False, n, n, nsub, nsteps, group=group, data=data, alpha=alpha, transport="native", native=True)
     for k in ("H", "A", "u", "v", "s11"):
         got = gather(parts, world, k)
         assert got.shape == ref[k].shape, k
@@ -94,7 +96,8 @@ def test_config5_4096_coupled_eight_row_blocks_equal_single_domain_bitwise(gpu):
     assert 0.9 < float(ref["A"][0].min()) and float(ref["A"][0].max()) < 1.01
     assert -40.0 < float(ref["tice0"].min()) and float(ref["tice0"].max()) <= 0.0
     assert float((ref["tice0"] - torch.from_numpy(column["tice0"]).cuda()).abs().max()) > 1e-3  # the column step ran
-    parts = run_world(world, 3, True, n, n, nsub, nsteps, group=group, data=data, column=column, alpha=alpha, keep=keep)
+    parts = run_world(world, 3, True, n, n, nsub, nsteps, group=group, data=data, column=column, alpha=alpha, keep=keep,
+                      transport="native", native=True)
     for k in keep + ("hsnow", "tice0"):
         got = gather(parts, world, k)
         assert got.shape == ref[k].shape, k
