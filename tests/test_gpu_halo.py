@@ -155,3 +155,42 @@ def test_native_driver_long_run_stays_bitwise(gpu):
     parts = run_world(4, 3, True, nx, ny, nsub, nsteps, group=2, transport="native", native=True, use_graph=True, **kw)
     for key in ("H", "A", "u", "v", "s11", "tice0", "hsnow"):
         assert torch.equal(gather(parts, 4, key), ref[key]), key
+
+
+def test_row_block_driver_argument_and_sequence_errors(ctx):
+    """nsdg_rb_*_create / _run: geometry that does not describe a block, a block with neighbours on a context without a
+    communicator, a grid that does not match the plan -- status codes and messages, no launch"""
+    from nextsimdg_amd import rowblock
+
+    nx, ny = 70, 40
+    ctx.set_grid(nx, ny, 1.0, 1.0)
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")
+    s2 = ([ctx.private_zeros(8, ny, nx, "cuda") for _ in range(3)], [ctx.private_zeros(8, ny, nx, "cuda") for _ in range(3)])
+    uv2 = ((z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)), (z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)))
+    packed, pg = z(8 * (2 * ny + 1) * (2 * nx + 1)), ctx.private_zeros(9, ny, nx, "cuda")
+    interior = rowblock.RowBlock(nx, 3 * 28, 1, 3, 6, 5)  # 28 owned + 6 + 5 ghost rows = 39 local rows: not this array
+    with pytest.raises(abi.NsdgError, match="needs nsdg_comm_init"):
+        blk = rowblock.RowBlock(nx, 3 * 29, 1, 3, 6, 5)  # 29 + 11 = 40 local rows, neighbours on both sides, no communicator
+        assert blk.ny == ny
+        ctx.rb_mevp(blk, (0, 2), 9, True, False, s2, uv2, packed, pg)
+    with pytest.raises(abi.NsdgError, match="owned rows must be"):
+        bad = rowblock.RowBlock(nx, ny, 0, 1)
+        bad.j0 = 3  # owned rows that do not start at the array edge although there is no neighbour below
+        ctx.rb_mevp(bad, (None, None), 9, True, False, s2, uv2, packed, pg)
+    single = rowblock.RowBlock(nx, ny, 0, 1)
+    run, per_pass, group = ctx.rb_mevp(single, (None, None), 7, True, False, s2, uv2, packed, pg)
+    assert (per_pass, group) == (3, 1)
+    with pytest.raises(abi.NsdgError, match="pack_nodal was not called"):
+        run(0)  # the coefficients of this step were never packed
+    ctx.set_grid(nx, ny - 1, 1.0, 1.0)
+    with pytest.raises(abi.NsdgError, match="does not match the plan"):
+        run(0)
+    ctx.set_grid(nx, ny, 1.0, 1.0)
+    out = C.c_int32()
+    assert ctx.lib.nsdg_rb_mevp_run(ctx.h, run.handle, 2, C.byref(out)) == -1  # parity must be 0 or 1
+    f = [z(6, ny, nx) for _ in range(6)]
+    adv = (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
+    tr = ctx.rb_transport(single, (None, None), f[0:2], f[2:4], f[4:6], adv)
+    assert tr(120.0, 0) == 1 and tr(120.0, 1) == 0  # the state alternates between the two array sets
+    torch.cuda.synchronize()
+    assert interior.ny == 39
