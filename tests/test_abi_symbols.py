@@ -32,6 +32,15 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert sorted(abi.SYMBOLS) == names
 
 
+def test_header_is_plain_c():
+    """include/nsdg.h is the boundary: it must compile as C99 on its own (no C++ types, no torch types)"""
+    import subprocess
+
+    p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "nsdg.h")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()
+
+
 def test_abi_version_and_default_params(lib):
     assert lib.nsdg_abi_version() == 2  # 2: nsdg_comm_* / nsdg_halo_* (row-block ghost exchange)
     p = abi.ColumnParams()
