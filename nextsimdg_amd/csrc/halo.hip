@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <deque>
@@ -217,6 +218,24 @@ __global__ __launch_bounds__(256) void halo_copy_kernel(SegTable T, double* __re
                 a[k] = b[k];
         }
     }
+}
+
+// Rehearsal aid (tools/rank_share_timing.py --wire-us N): a loopback exchange on one GPU has no wire time, so a kernel
+// that spins for N microseconds can be put between pack and transport to see how much of a real transfer the overlap
+// with the interior launch would hide.  Never active unless NSDG_HALO_DELAY_US is set in the environment.
+__global__ void halo_delay_kernel(long ticks)
+{
+    const long t0 = (long)__builtin_amdgcn_s_memrealtime(); // 100 MHz
+    while ((long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    }
+}
+long halo_delay_ticks()
+{
+    static const long ticks = [] {
+        const char* v = std::getenv("NSDG_HALO_DELAY_US");
+        return (v && *v) ? 100L * std::atol(v) : 0L;
+    }();
+    return ticks;
 }
 
 int launch_copy(bool pack, const SegTable& T, long longest, double* buf0, double* buf1, hipStream_t stream)
@@ -474,6 +493,8 @@ int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* p)
     int rc = launch_copy(true, p->send, p->max_send, p->b_up, p->b_down, c->stream);
     if (rc != NSDG_OK)
         return rc;
+    if (halo_delay_ticks() > 0 && (p->n_up || p->n_down)) // rehearsal only: simulated transfer time
+        hipLaunchKernelGGL(halo_delay_kernel, dim3(1), dim3(1), 0, c->stream, halo_delay_ticks());
     if (c->nccl) {
         NSDG_CHECK_RCCL(g_rccl.GroupStart());
         ncclResult_t r = ncclSuccess;

@@ -108,7 +108,7 @@ void DynamicsStep::configure()
     beta = getConfiguration(keyMap.at(3), 0.);
     thermo = getConfiguration(keyMap.at(4), false);
     rowBlocks = getConfiguration(keyMap.at(5), 1);
-    passesPerExchange = getConfiguration(keyMap.at(6), 6);
+    passesPerExchange = getConfiguration(keyMap.at(6), 8);
     overlap = getConfiguration(keyMap.at(7), true);
     graph = getConfiguration(keyMap.at(8), false);
     forcing = getConfiguration(keyMap.at(9), std::string("host"));

@@ -94,7 +94,7 @@ def test_driver_on_native_halo_equals_single_domain_bitwise(gpu, world, group, n
 @pytest.mark.parametrize("world,group,nsub,coupled,variant,graph", [(1, 1, 20, False, 3, False), (1, 1, 41, True, 3, True), (3, 2, 20, False, 3, False),
                                                                     (4, 4, 41, True, 3, True), (4, 3, 13, True, 2, False), (3, 1, 7, False, 1, False),
                                                                     (2, 1, 8, False, 3, True), (4, 5, 31, False, 3, False),
-                                                                    (3, 3, 17, True, 2, True)])
+                                                                    (3, 3, 17, True, 2, True), (2, 8, 53, False, 3, False)])
 def test_native_row_block_driver_equals_single_domain_bitwise(gpu, world, group, nsub, coupled, variant, graph):
     """the row-block drivers behind the C ABI (nsdg_rb_mevp_run / nsdg_rb_transport_run: one call per step each, with
     and without hipGraph replay of the launches between two exchanges) against the Python sequence on a single
