@@ -253,6 +253,13 @@ int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_
     const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
     double* u_new, double* v_new, const double* packed, const double* pg);
 
+/* The same on TWO disjoint row ranges [j0a, j1a) and [j0b, j1b) in ONE launch -- the two bands of rows whose results a row
+ * block sends to its neighbours: as one launch they share the resident wave slots instead of paying two pipeline fills
+ * one after the other.  Each range obeys the ghost-row conditions of nsdg_mevp_iterate3; bit-identical to two calls. */
+int nsdg_mevp_iterate3_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b, int32_t j1b, const double* s11_in, const double* s12_in,
+    const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old, double* u_new,
+    double* v_new, const double* packed, const double* pg);
+
 /* nsub sub-iterations over the whole local array (packs the nodal coefficients, then iterates);
  * result in s11/s12/s22 and u, v (u0/v0 may be the same arrays as u/v).  scratch: 10*(2nx+1)*(2ny+1) + 24*nx*ny doubles, 16-byte aligned
  * (packed coefficients + ping-pong copies of the velocity and the stress). */

@@ -94,6 +94,7 @@ SYMBOLS = {
     "nsdg_mevp_iterate": (C.c_int, [VP, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate2": (C.c_int, [VP, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate3": (C.c_int, [VP, I32, I32] + [VP] * 12),
+    "nsdg_mevp_iterate3_pair": (C.c_int, [VP, I32, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_occupancy_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
@@ -529,6 +530,12 @@ class Context:
     def mevp_iterate3(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         """three sub-iterations in one pass on the owned rows [j0, j1) (variant 3)"""
         self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=3)()
+
+    def mevp_iterate3_pair(self, ra, rb, s_in, s_out, uv_old, uv_new, packed, pg):
+        """three sub-iterations on two disjoint row ranges ra = (j0, j1), rb = (j0, j1) in one launch"""
+        ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
+        _check_f64(*ts)
+        self._call(self.lib.nsdg_mevp_iterate3_pair(self.h, ra[0], ra[1], rb[0], rb[1], *[_ptr(t) for t in ts]))
 
     def bind_mevp_iterate3(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         return self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=3)

@@ -341,6 +341,9 @@ static inline bool aligned16(std::initializer_list<const void*> ptrs)
 // defined in mevp_fused3.hip
 int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
     double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
+int nsdg_launch_mevp_fused3_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
+    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
+    const double* pg);
 // defined in mevp_fused2.hip
 int nsdg_launch_mevp_fused2(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
     double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
@@ -550,6 +553,34 @@ int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
         return nsdg_launch_mevp_fused3(ctx, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     nsdg_set_error("nsdg_mevp_iterate3: select variant 3 (nsdg_mevp_variant_set)");
     return NSDG_ERR_STATE;
+}
+
+int nsdg_mevp_iterate3_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b, int32_t j1b, const double* s11i, const double* s12i,
+    const double* s22i, double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
+    const double* packed, const double* pg)
+{
+    NSDG_NEED_GRID(ctx);
+    for (int k = 0; k < 2; ++k) {
+        const int j0 = k ? j0b : j0a, j1 = k ? j1b : j1a;
+        NSDG_CHECK_ARG(0 <= j0 && j0 < j1 && j1 <= ctx->ny, "row range outside the local array (or empty)");
+        NSDG_CHECK_ARG(j0 == 0 || j0 >= 3, "need three ghost rows below the rows of a range (or j0 == 0 at the physical boundary)");
+        NSDG_CHECK_ARG(j1 == ctx->ny || j1 + 2 <= ctx->ny, "need two ghost rows above the rows of a range (or j1 == ny at the physical boundary)");
+    }
+    NSDG_CHECK_ARG(j1a <= j0b || j1b <= j0a, "the two row ranges must be disjoint");
+    NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed && pg, "null field pointer");
+    NSDG_CHECK_TILED(s11i, s12i, s22i, s11, s12, s22, pg);
+    NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
+    NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
+    if (!(ctx->pack_dt > 0)) {
+        nsdg_set_error("nsdg_mevp_iterate3_pair: nsdg_mevp_pack_nodal was not called on this context");
+        return NSDG_ERR_STATE;
+    }
+    if (ctx->mevp_variant != 3) {
+        nsdg_set_error("nsdg_mevp_iterate3_pair: select variant 3 (nsdg_mevp_variant_set)");
+        return NSDG_ERR_STATE;
+    }
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    return nsdg_launch_mevp_fused3_ranges(ctx, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
 }
 
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u, double* v,

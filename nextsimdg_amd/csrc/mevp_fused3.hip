@@ -238,14 +238,22 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
     NSDG_STAMP(10);
 }
 
-__global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int R, int ncw, double hx, double hy,
+// Row ranges: [j0, j1) in strips of R rows and, when nsA > 0 strips are given for it, a SECOND disjoint range
+// [j0b, j1b) after them in the same launch (the two bands of rows a block sends to its neighbours: as one launch they
+// share the resident wave slots instead of paying two pipeline fills in a row).
+__global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw, double hx, double hy,
     double ialpha, double dmin2, StressPtrs3 S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
 {
     __shared__ double park[2 * PARK_SLOT]; // 32 KB: the B -> C hand-over of this wave
     const int lane = threadIdx.x;
     const int wave = xcd_contiguous_block(blockIdx.x, gridDim.x); // one wave per workgroup
-    const int strip = wave / ncw, cw = wave - strip * ncw;
+    int strip = wave / ncw;
+    const int cw = wave - strip * ncw;
+    if (strip >= nsA) { // wave-uniform: a strip of the second range
+        strip -= nsA;
+        j0 = j0b, j1 = j1b;
+    }
     MarchConst3 M;
     M.y0 = j0 + strip * R;
     if (M.y0 >= j1)
@@ -303,11 +311,14 @@ extern "C" int nsdg_debug_read_stamps3(unsigned* host_out)
 }
 #endif
 
-// three sub-iterations on the owned rows [j0, j1) of the local array
-int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
-    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg)
+// three sub-iterations on the rows [j0, j1) of the local array and, if j0b < j1b, on a second disjoint range [j0b, j1b)
+// in the same launch
+int nsdg_launch_mevp_fused3_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
+    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
+    const double* pg)
 {
     const int ncw = nsdg_div_up(ctx->nx, 59); // 59 owned columns per wave
+    const int rowsB = j0b < j1b ? j1b - j0b : 0;
     int R = ctx->strip_rows;
     if (R <= 0) {
         // every wave marches R+5 rows of A, R+3 of B and R+1 of C: R+5 march steps for R useful rows;
@@ -316,7 +327,7 @@ int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, c
         double best = 1e30;
         R = 16;
         for (int r = 1; r <= 256; ++r) {
-            const long waves = (long)nsdg_div_up(j1 - j0, r) * ncw;
+            const long waves = ((long)nsdg_div_up(j1 - j0, r) + nsdg_div_up(rowsB, r)) * ncw;
             const long rounds = (waves + slots - 1) / slots;
             const double cost = rounds * (r + 5.0) + (rounds == 1 ? 2.0 : 0.0);
             if (cost < best) {
@@ -325,13 +336,19 @@ int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, c
             }
         }
     }
-    const int nstrips = nsdg_div_up(j1 - j0, R);
-    const long nwaves = (long)ncw * nstrips;
+    const int nsA = nsdg_div_up(j1 - j0, R), nsB = nsdg_div_up(rowsB, R);
+    const long nwaves = (long)ncw * (nsA + nsB);
     const StressPtrs3 S = { s11i, s12i, s22i, s11, s12, s22 };
     const nsdg_mevp_params& P = ctx->mevp;
     const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
-    hipLaunchKernelGGL(mevp_fused3_kernel, dim3(nwaves), dim3(64), 0, ctx->stream, K, ctx->nx, ctx->ny, j0, j1, R, ncw, ctx->hx, ctx->hy,
-        1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg, u_new, v_new);
+    hipLaunchKernelGGL(mevp_fused3_kernel, dim3(nwaves), dim3(64), 0, ctx->stream, K, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
+        ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg, u_new, v_new);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
+}
+
+int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
+    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg)
+{
+    return nsdg_launch_mevp_fused3_ranges(ctx, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
 }

@@ -342,11 +342,19 @@ int nsdg_rb_mevp_run(nsdg_ctx* ctx, nsdg_rb_mevp* p, int32_t parity, int32_t* pa
                         const bool last = i == m;
                         pass_ranges(g, v, split_ok && last, m - i, r);
                         const size_t n = (split_ok && last) ? r.size() - 1 : r.size();
-                        for (size_t a = 0; a < n; ++a) {
-                            const int e = pass_launch(p, v, r[a], q);
+                        if (split_ok && last && n == 2 && v == 3) {
+                            // the rows that travel up and the rows that travel down: ONE launch (bit-identical to two)
+                            const nsdg_rb_mevp_desc& d = p->d;
+                            const int e = nsdg_mevp_iterate3_pair(p->ctx, r[0].j0, r[0].j1, r[1].j0, r[1].j1, d.s11[q], d.s12[q], d.s22[q], d.s11[1 - q],
+                                d.s12[1 - q], d.s22[1 - q], d.u[q], d.v[q], d.u[1 - q], d.v[1 - q], d.packed, d.pg);
                             if (e != NSDG_OK)
                                 return e;
-                        }
+                        } else
+                            for (size_t a = 0; a < n; ++a) {
+                                const int e = pass_launch(p, v, r[a], q);
+                                if (e != NSDG_OK)
+                                    return e;
+                            }
                         if (!last)
                             q = 1 - q;
                     }

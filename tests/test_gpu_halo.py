@@ -196,3 +196,49 @@ def test_row_block_driver_argument_and_sequence_errors(ctx):
     assert tr(120.0, 0) == 1 and tr(120.0, 1) == 0  # the state alternates between the two array sets
     torch.cuda.synchronize()
     assert interior.ny == 39
+
+
+def test_two_row_ranges_in_one_launch_equal_two_launches_bitwise(ctx):
+    """nsdg_mevp_iterate3_pair (the two bands of rows a block sends to its neighbours, one launch) against two
+    nsdg_mevp_iterate3 calls, for band heights 1 .. 30 and both strip-height choices; rows outside the bands untouched"""
+    from nextsimdg_amd import synthetic
+
+    nx, ny = 150, 96
+    bt = synthetic.BoxTest(nx, ny)
+    ctx.set_grid(nx, ny, bt.hx, bt.hy)
+    ctx.set_mevp_params(ctx.mevp_default_params(alpha=300.0, beta=300.0))
+    dev = lambda a: torch.from_numpy(a.copy()).cuda()
+    H, A = (dev(x) for x in bt.dg_fields())
+    uo, vo = (dev(x) for x in bt.ocean())
+    ua, va = (dev(3.0 * x) for x in bt.wind(0.0))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    u = 0.05 * torch.rand(2 * ny + 1, 2 * nx + 1, dtype=torch.float64, device="cuda", generator=g)
+    v = 0.05 * torch.rand(2 * ny + 1, 2 * nx + 1, dtype=torch.float64, device="cuda", generator=g)
+    s = [1e3 * torch.rand(ctx.private_zeros(8, ny, nx, "cuda").shape, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+    pg = ctx.private_zeros(9, ny, nx, "cuda")
+    packed = torch.zeros(8 * u.numel(), dtype=torch.float64, device="cuda")
+    ctx.ice_strength(H, A, pg)
+    ctx.mevp_prepare(120.0, H, A, (ua, va), (uo, vo), (u, v), packed)
+    for ra, rb, strip in (((72, 96), (0, 24), 0), ((60, 61), (10, 40), 0), ((3, 9), (50, 94), 5), ((70, 94), (24, 48), 1)):
+        ctx.set_mevp_strip_rows(strip)
+        outs = []
+        for pair in (True, False):
+            so = [torch.full_like(x, -7.0) for x in s]
+            un, vn = torch.full_like(u, -7.0), torch.full_like(v, -7.0)
+            if pair:
+                ctx.mevp_iterate3_pair(ra, rb, s, so, (u, v), (un, vn), packed, pg)
+            else:
+                ctx.mevp_iterate3(ra[0], ra[1], s, so, (u, v), (un, vn), packed, pg)
+                ctx.mevp_iterate3(rb[0], rb[1], s, so, (u, v), (un, vn), packed, pg)
+            outs.append(so + [un, vn])
+        torch.cuda.synchronize()
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (ra, rb, strip)
+        written = torch.zeros(ny, dtype=torch.bool, device="cuda")
+        written[ra[0]:ra[1]] = True
+        written[rb[0]:rb[1]] = True
+        assert bool((outs[0][0][~written] == -7.0).all()) and bool((outs[0][0][written] != -7.0).any())
+    ctx.set_mevp_strip_rows(0)
+    with pytest.raises(abi.NsdgError, match="disjoint"):
+        ctx.mevp_iterate3_pair((10, 40), (30, 60), s, [torch.zeros_like(x) for x in s], (u, v), (torch.zeros_like(u), torch.zeros_like(v)), packed, pg)
+    ctx.set_mevp_params(ctx.mevp_default_params())
