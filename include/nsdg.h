@@ -15,11 +15,11 @@
  *  - One context per GPU/stream.  Calls on one context must not be issued concurrently from two
  *    host threads; different contexts are independent.  (The reference is single-threaded and
  *    non-re-entrant: static m_dt / m_freezer, core/src/PrognosticData.cpp:12-13.)
- *  - No clamping or input checking is added to the physics (SURVEY.md section 8b "Errors").  Input domain of the
- *    column step: slp > 0, temperatures above -250 C, finite values.  Inside it the results follow the reference's
- *    arithmetic, including its Inf / NaN for mld == 0, dt == 0 or vanishing fluxes (those divisions are IEEE
- *    divisions; csrc/column_step.hip lists them).  Outside it (e.g. slp == 0) the reciprocal-based divisions of the
- *    saturation-pressure and density formulae return NaN where IEEE division would return Inf.
+ *  - No clamping or input checking is added to the physics (SURVEY.md section 8b "Errors").  The results follow the
+ *    reference's arithmetic, including its Inf / NaN / 0 for mld == 0, dt == 0, vanishing fluxes, zero pressure and
+ *    non-finite forcing values: every division either is an IEEE division or ends in the IEEE sequence's special-case
+ *    fix-up (csrc/column_step.hip).  The one exclusion: a SUBNORMAL or > 2^1022 value of slp, of an absolute
+ *    temperature or of conc + del_c makes the reciprocal-based divisions return NaN where IEEE division scales.
  *
  * Data layout
  *  - element (ix, iy) of an nx x ny local array, ix fastest:  e = iy*nx + ix.  (The reference's

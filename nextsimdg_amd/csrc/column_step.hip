@@ -43,11 +43,14 @@ __device__ __forceinline__ double kelvin(double c) { return c + WATER_TF; } // c
 //   rdiv(a, b, 1/b) the same correction with a reciprocal that is known already: b is a compile-time constant or
 //                   a launch parameter such as dt (3 instructions)
 // Both return the quotient to within one ulp (the residual step makes it the correctly rounded one in all but
-// a few per mille of the cases), far inside the 1e-13 parity tolerance.  What they drop is the range scaling and
-// the special-case fix-up: a zero, subnormal or non-finite denominator (or a non-finite numerator) yields NaN
-// where IEEE division yields Inf or 0.  They are therefore used only where the denominator is bounded away
-// from zero for every input of the documented domain (include/nsdg.h: pressures and absolute temperatures
-// positive, temperatures above -250 C): saturation-pressure and density formulae, the albedo weights, and
+// a few per mille of the cases), far inside the 1e-13 parity tolerance, and end in the IEEE sequence's own last
+// instruction, v_div_fixup_f64, which restores the special classes: x/0 = Inf, 0/0 = Inf/Inf = NaN, Inf/x = Inf,
+// x/Inf = 0, NaN in -> NaN out.  (Round 2 left the fix-up out: with qlw = Inf the snow melt rate -Inf / L became NaN
+// in the residual step, fmin / fmax swallowed the NaN, and the element kept its ice where the reference's -Inf
+// thickness zeroes it -- the 1.88-against-0 of profiles/r03_column_cutoff_cause.md.)  What they still drop is the
+// range SCALING: a subnormal denominator, or one above 2^1022, whose reciprocal is not representable, yields NaN.
+// They are therefore used only where the denominator is a normal number for every input of the documented domain
+// (include/nsdg.h): saturation-pressure and density formulae, the albedo weights, physical constants, and
 // conc + del_c >= min_conc, which the reference tests itself.  The divisions whose denominator is a FREE input
 // or a difference of data -- the concentration and the true thickness, the mixed-layer heat capacity (mld), deltaTml,
 // the slab conductance and the surface-temperature Newton step, and dt -- are IEEE divisions, so that mld == 0, dt == 0 or a vanishing flux
@@ -58,12 +61,12 @@ __device__ __forceinline__ double qdiv(double a, double b)
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
     const double q = a * r;
-    return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-b, q, a), r, q), b, a);
 }
 __device__ __forceinline__ double rdiv(double a, double b, double rb)
 {
     const double q = a * rb;
-    return __builtin_fma(__builtin_fma(-b, q, a), rb, q);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-b, q, a), rb, q), b, a);
 }
 #define CDIV(a, c) rdiv((a), (c), 1.0 / (c)) /* c is a compile-time constant: 1/c is folded */
 

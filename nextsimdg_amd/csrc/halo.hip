@@ -154,7 +154,10 @@ struct nsdg_comm {
 };
 
 // ---------------------------------------------------------------------------------------------- plans
-constexpr int HALO_MAX_SEGS = 32; // per direction pair (a pack or unpack launch covers both directions)
+// per direction pair (a pack or unpack launch covers both directions): the transport plan of NSDG_RB_MAX_FIELDS DG2 fields
+// moves 6 planes per field and direction = 48 blocks; the table travels as a kernel argument (64 entries = 1.8 KB)
+constexpr int HALO_MAX_SEGS = 64;
+static_assert(HALO_MAX_SEGS >= 2 * 6 * NSDG_RB_MAX_FIELDS, "segment table too small for the transport plan");
 
 struct SegTable {
     double* ptr[HALO_MAX_SEGS]; // the row block in the caller's array

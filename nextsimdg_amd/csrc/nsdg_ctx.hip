@@ -134,8 +134,6 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy)
     NSDG_CHECK_ARG(nx > 0 && ny > 0, "nx and ny must be positive");
     NSDG_CHECK_ARG(hx > 0 && hy > 0, "cell sizes must be positive");
     NSDG_CHECK_ARG((long)(2 * (long)nx + 1) * (2 * (long)ny + 1) < (1L << 31), "grid too large for 32-bit node indices");
-    ctx->nx = nx;
-    ctx->ny = ny;
     if (ctx->nx != nx || ctx->ny != ny || ctx->hx != hx || ctx->hy != hy)
         ctx->pack_dt = 0.; // packed nodal coefficients belong to the old grid
     ctx->nx = nx;

@@ -15,6 +15,7 @@
 //   What is left of nsub runs as a two-iteration pass and / or single sub-iterations (exchange after each).
 //   Transport: with >= 3 ghost rows per side the first two RK stages also advance 2 / 1 ghost rows and the
 //   advected fields are exchanged once per step; otherwise after every stage.
+#include <cstring>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -45,6 +46,10 @@ int check_geometry(const Geometry& g)
     NSDG_CHECK_ARG(g.j0 == g.gb() && g.j1 == g.ny - g.gt() && g.j0 < g.j1,
         "owned rows must be the local array minus the ghost rows towards existing neighbours");
     NSDG_CHECK_ARG(!g.multi() || (g.depth_below >= 1), "a block with neighbours needs at least one ghost row below");
+    // depth_below element rows travel upwards and depth_above + 1 element rows (2 depth_above + 1 node rows) downwards:
+    // a block with fewer owned rows would pack rows of its own ghost zone, which are stale after the last pass of a group
+    NSDG_CHECK_ARG(!g.multi() || g.j1 - g.j0 >= std::max(g.depth_below, g.depth_above + 1),
+        "a block with neighbours must own at least max(depth_below, depth_above + 1) rows (the rows it sends)");
     return NSDG_OK;
 }
 
@@ -113,15 +118,41 @@ int make_plan(nsdg_ctx* ctx, const Geometry& g, const SegList& L, nsdg_halo** ou
 }
 
 // ---- hipGraph replay of a fixed launch sequence -------------------------------------------------------------
+// A captured launch bakes in the launch constants the kernels take from the context (K = rho beta / dt, 1/alpha,
+// Delta_min^2, the cell size, the strip height, the kernel variant): the cache remembers the values its graphs were
+// recorded with and is dropped when any of them has changed, so a replay never mixes two parameter sets.
+struct GraphStamp {
+    double v[8];
+    int k[6];
+    bool operator==(const GraphStamp& o) const { return std::memcmp(this, &o, sizeof *this) == 0; }
+};
+
+GraphStamp graph_stamp(const nsdg_ctx* c)
+{
+    GraphStamp s;
+    std::memset(&s, 0, sizeof s);
+    const nsdg_mevp_params& P = c->mevp;
+    const double v[8] = { c->pack_dt, P.alpha, P.beta, P.rho_ice, P.fc, P.delta_min, c->hx, c->hy };
+    const int k[6] = { c->strip_rows, c->mevp_variant, c->fused_min_waves, c->nx, c->ny, c->num_cus };
+    std::memcpy(s.v, v, sizeof v);
+    std::memcpy(s.k, k, sizeof k);
+    return s;
+}
+
 struct GraphCache {
     hipStream_t capture = nullptr; // launches are recorded on this stream (the context's own stream may be the null stream)
     hipEvent_t fork = nullptr, join = nullptr;
     std::map<std::tuple<int, int, int, int>, hipGraphExec_t> execs;
-    void destroy()
+    GraphStamp stamp; // launch constants of the recorded graphs
+    void drop_execs()
     {
         for (auto& kv : execs)
             (void)hipGraphExecDestroy(kv.second);
         execs.clear();
+    }
+    void destroy()
+    {
+        drop_execs();
         if (capture)
             (void)hipStreamDestroy(capture);
         if (fork)
@@ -201,6 +232,13 @@ int run_or_replay(nsdg_rb_mevp* p, std::tuple<int, int, int, int> key, F&& body)
         NSDG_CHECK_HIP(hipEventCreateWithFlags(&G.fork, hipEventDisableTiming));
         NSDG_CHECK_HIP(hipEventCreateWithFlags(&G.join, hipEventDisableTiming));
     }
+    const GraphStamp now = graph_stamp(ctx);
+    if (!G.execs.empty() && !(G.stamp == now)) {
+        // parameters, time step, grid or launch geometry changed since the graphs were recorded
+        NSDG_CHECK_HIP(hipStreamSynchronize(G.capture)); // no replay may still be running when its exec is destroyed
+        G.drop_execs();
+    }
+    G.stamp = now;
     auto it = G.execs.find(key);
     if (it == G.execs.end()) {
         hipStream_t user = ctx->stream;
@@ -213,8 +251,12 @@ int run_or_replay(nsdg_rb_mevp* p, std::tuple<int, int, int, int> key, F&& body)
             e = hipStreamEndCapture(G.capture, &graph);
         }
         ctx->stream = user;
-        if (rc != NSDG_OK)
-            return rc;
+        if (rc != NSDG_OK || e != hipSuccess) {
+            if (graph)
+                (void)hipGraphDestroy(graph);
+            if (rc != NSDG_OK)
+                return rc;
+        }
         NSDG_CHECK_HIP(e);
         hipGraphExec_t exec = nullptr;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

@@ -14,7 +14,8 @@
 //     transport (nsdg_comm_init_local) -- devices round-robin over dynamics.devices (default: all on device 0);
 //   * one process per GPU under a launcher that sets WORLD_SIZE / RANK / LOCAL_RANK / MASTER_ADDR / MASTER_PORT
 //     (Rendezvous.hpp): every process owns ONE block, ghost rows over RCCL send/recv (nsdg_comm_init).  Every rank
-//     reads the same initial state and writes the rows it owns to <final_file>.rank<r>.
+//     reads the same initial state; at the end the owned rows of every rank travel to rank 0 (TCP, once per run),
+//     which writes ONE restart file -- the same file a single-process run writes.
 // Configuration keys (all optional):
 //     dynamics.domain_size   side of the square box in m        (512e3)
 //     dynamics.nsub          mEVP sub-iterations per step        (120)
@@ -34,6 +35,7 @@
 #include <vector>
 
 #include "Configured.hpp"
+#include "IStructure.hpp"
 #include "Iterator.hpp"
 
 struct nsdg_ctx;
@@ -67,6 +69,13 @@ public:
 
     //! rows [r0, r1) of block `rank` of `world` (the same split as nextsimdg_amd/rowblock.py split_rows)
     static void splitRows(int ny, int world, int rank, int& r0, int& r1);
+
+    //! The prognostic planes a run changes, in the order they travel to rank 0 for the restart file.
+    static std::vector<std::vector<double>*> restartPlanes(FieldStore& f, bool thermodynamics);
+    //! rows [r0, r1) (nx values each) of every plane, one after the other -- what a rank sends ...
+    static std::vector<double> packRows(FieldStore& f, bool thermodynamics, int nx, int r0, int r1);
+    //! ... and how rank 0 puts it into its structure; throws std::runtime_error when the size is not that of the rows
+    static void placeRows(FieldStore& f, bool thermodynamics, int nx, int r0, int r1, const double* data, std::size_t count);
 
 private:
     void release();

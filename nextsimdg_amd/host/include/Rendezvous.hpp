@@ -5,6 +5,7 @@
 // The reference is a single process; this has no counterpart there.
 #pragma once
 #include <cstddef>
+#include <functional>
 #include <string>
 
 namespace Nextsim {
@@ -20,5 +21,13 @@ struct RankEnvironment {
 //! The server listens on port + 17 (the launcher's own store owns `port`).  Throws std::runtime_error
 //! on any socket error or after `timeoutSeconds`.
 void broadcastFromRankZero(const RankEnvironment& env, void* buffer, std::size_t bytes, int timeoutSeconds = 120);
+
+//! The opposite direction, used once per run for the restart file: every rank r > 0 sends `bytes` bytes of `buffer`
+//! to rank 0, which calls sink(r, data, count) for each of them (in the order they arrive; counts may differ between
+//! ranks).  Rank 0's own buffer is not passed to the sink.  The server listens on port + 18.  A rank that has died
+//! never connects: rank 0 then throws std::runtime_error after `timeoutSeconds` (no partial file is written by the
+//! caller), and a sender whose rank 0 has gone throws in the same way.
+void gatherToRankZero(const RankEnvironment& env, const void* buffer, std::size_t bytes,
+    const std::function<void(int rank, const char* data, std::size_t count)>& sink, int timeoutSeconds = 120);
 
 } // namespace Nextsim

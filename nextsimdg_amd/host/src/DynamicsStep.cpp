@@ -406,8 +406,52 @@ void DynamicsStep::writeRestartFile(const std::string& filePath)
     if (!pStructure)
         throw std::logic_error("DynamicsStep::writeRestartFile: setInitialData() was not called");
     stop(0);
-    // a multi-process run holds only its own rows up to date: every rank writes its own file
-    pStructure->dump(m_world > 1 ? filePath + ".rank" + std::to_string(m_rank) : filePath);
+    if (m_world > 1) {
+        // a rank holds only its own rows up to date: they travel to rank 0, which writes the ONE restart file (every row
+        // of it current).  A rank that has died never delivers: rank 0 throws after the timeout and writes nothing.
+        FieldStore& f = pStructure->fields();
+        const RankEnvironment env = RankEnvironment::fromEnv();
+        int r0, r1;
+        splitRows(nyf, m_world, m_rank, r0, r1);
+        const std::vector<double> mine = m_rank == 0 ? std::vector<double>() : packRows(f, thermo, nxf, r0, r1);
+        gatherToRankZero(env, mine.data(), mine.size() * sizeof(double), [&](int rank, const char* data, std::size_t bytes) {
+            int a, b;
+            splitRows(nyf, m_world, rank, a, b);
+            placeRows(f, thermo, nxf, a, b, reinterpret_cast<const double*>(data), bytes / sizeof(double));
+        });
+        if (m_rank != 0)
+            return;
+    }
+    pStructure->dump(filePath);
+}
+
+std::vector<std::vector<double>*> DynamicsStep::restartPlanes(FieldStore& f, bool thermodynamics)
+{
+    std::vector<std::vector<double>*> planes = { &f.hice, &f.cice };
+    if (thermodynamics)
+        for (auto* p : { &f.hsnow, &f.tice, &f.newice })
+            planes.push_back(p);
+    return planes;
+}
+
+std::vector<double> DynamicsStep::packRows(FieldStore& f, bool thermodynamics, int nx, int r0, int r1)
+{
+    std::vector<double> out;
+    const std::size_t first = (std::size_t)r0 * nx, count = (std::size_t)(r1 - r0) * nx;
+    for (auto* p : restartPlanes(f, thermodynamics))
+        out.insert(out.end(), p->begin() + first, p->begin() + first + count);
+    return out;
+}
+
+void DynamicsStep::placeRows(FieldStore& f, bool thermodynamics, int nx, int r0, int r1, const double* data, std::size_t count)
+{
+    const auto planes = restartPlanes(f, thermodynamics);
+    const std::size_t first = (std::size_t)r0 * nx, rows = (std::size_t)(r1 - r0) * nx;
+    if (count != rows * planes.size())
+        throw std::runtime_error("DynamicsStep: a rank delivered " + std::to_string(count) + " values for its rows, expected "
+            + std::to_string(rows * planes.size()));
+    for (std::size_t k = 0; k < planes.size(); ++k)
+        std::copy(data + k * rows, data + (k + 1) * rows, planes[k]->begin() + first);
 }
 
 } // namespace Nextsim

@@ -6,10 +6,12 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <vector>
 
 namespace Nextsim {
 
@@ -35,7 +37,7 @@ void recvAll(int fd, char* p, std::size_t n)
     while (n > 0) {
         const ssize_t k = ::recv(fd, p, n, 0);
         if (k <= 0)
-            throw std::runtime_error("rendezvous: connection closed before the communicator id arrived");
+            throw std::runtime_error("rendezvous: connection closed or timed out before the data arrived");
         p += k, n -= (std::size_t)k;
     }
 }
@@ -111,6 +113,72 @@ void broadcastFromRankZero(const RankEnvironment& env, void* buffer, std::size_t
         }
         if (std::chrono::steady_clock::now() > deadline)
             throw std::runtime_error("rendezvous: rank 0 did not answer on " + env.masterAddr + ":" + std::to_string(port));
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+}
+
+void gatherToRankZero(const RankEnvironment& env, const void* buffer, std::size_t bytes,
+    const std::function<void(int, const char*, std::size_t)>& sink, int timeoutSeconds)
+{
+    if (env.world <= 1)
+        return;
+    const int port = env.masterPort + 18;
+    sockaddr_in addr;
+    std::memset(&addr, 0, sizeof addr);
+    addr.sin_family = AF_INET;
+    addr.sin_port = htons((unsigned short)port);
+    struct Header {
+        std::int64_t rank, bytes;
+    };
+    if (env.rank == 0) {
+        Socket srv;
+        srv.fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (srv.fd < 0)
+            throw std::runtime_error("gather: socket() failed");
+        const int one = 1;
+        ::setsockopt(srv.fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        addr.sin_addr.s_addr = htonl(INADDR_ANY);
+        if (::bind(srv.fd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) != 0 || ::listen(srv.fd, env.world) != 0)
+            throw std::runtime_error("gather: cannot listen on port " + std::to_string(port));
+        timeval tv = { timeoutSeconds, 0 };
+        ::setsockopt(srv.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        std::vector<bool> seen(env.world, false);
+        std::vector<char> data;
+        for (int k = 1; k < env.world; ++k) {
+            Socket c;
+            c.fd = ::accept(srv.fd, nullptr, nullptr);
+            if (c.fd < 0)
+                throw std::runtime_error("gather: only " + std::to_string(k - 1) + " of " + std::to_string(env.world - 1) + " ranks delivered their rows");
+            ::setsockopt(c.fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+            Header h;
+            recvAll(c.fd, reinterpret_cast<char*>(&h), sizeof h);
+            if (h.rank < 1 || h.rank >= env.world || seen[(std::size_t)h.rank] || h.bytes < 0)
+                throw std::runtime_error("gather: unexpected sender (rank " + std::to_string(h.rank) + ")");
+            seen[(std::size_t)h.rank] = true;
+            data.resize((std::size_t)h.bytes);
+            recvAll(c.fd, data.data(), data.size());
+            sink((int)h.rank, data.data(), data.size());
+        }
+        return;
+    }
+    if (::inet_pton(AF_INET, env.masterAddr.c_str(), &addr.sin_addr) != 1)
+        throw std::runtime_error("gather: MASTER_ADDR must be a dotted IPv4 address, got " + env.masterAddr);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(timeoutSeconds);
+    for (;;) { // rank 0 may not be listening yet
+        Socket c;
+        c.fd = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (c.fd < 0)
+            throw std::runtime_error("gather: socket() failed");
+        if (::connect(c.fd, reinterpret_cast<sockaddr*>(&addr), sizeof addr) == 0) {
+            timeval tv = { timeoutSeconds, 0 };
+            ::setsockopt(c.fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+            const Header h = { env.rank, (std::int64_t)bytes };
+            sendAll(c.fd, reinterpret_cast<const char*>(&h), sizeof h);
+            sendAll(c.fd, static_cast<const char*>(buffer), bytes);
+            return;
+        }
+        if (std::chrono::steady_clock::now() > deadline)
+            throw std::runtime_error("gather: rank 0 did not answer on " + env.masterAddr + ":" + std::to_string(port));
         std::this_thread::sleep_for(std::chrono::milliseconds(100));
     }
 }

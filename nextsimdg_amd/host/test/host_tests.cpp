@@ -17,6 +17,7 @@
 
 #include "Configurator.hpp"
 #include "DynamicsStep.hpp"
+#include "EnumWrapper.hpp"
 #include "Hdf5Subset.hpp"
 #include "Model.hpp"
 #include "ModuleLoader.hpp"
@@ -198,6 +199,45 @@ static void test_configurator()
     addConfig("[a]\nflag = false\n");
     CHECK(Configured<Config1>::getConfiguration<bool>("a.flag", true) == false);
     Configurator::clear();
+}
+
+enum class Colour { red, green, blue }; // core/test/EnumWrapper_test.cpp:20-24
+
+static void test_enum_wrapper()
+{ // core/test/EnumWrapper_test.cpp:26-52: an enum-valued option read from a configuration stream
+    Configurator::clear();
+    const std::string targetColourString = "red";
+    EnumWrap::EnumWrapper<Colour>::setMap({ { targetColourString, Colour::red }, { "green", Colour::green }, { "blue", Colour::blue } });
+    const std::string colourName = "option.colour";
+    addConfig("[option]\ncolour = " + targetColourString + "\n");
+    typedef EnumWrap::EnumWrapper<Colour> Wrapped;
+    Colour col = Configured<Config1>::getConfiguration<Wrapped>(colourName, Wrapped(Colour::blue));
+    CHECK(col == Colour::red);
+    // the other values, the default for an absent key, and the command line overriding the stream
+    CHECK(Colour(Configured<Config1>::getConfiguration<Wrapped>("option.missing", Wrapped(Colour::blue))) == Colour::blue);
+    ArgV a({ "prog", "--option.colour=green" });
+    Configurator::setCommandLine(a.argc(), a());
+    CHECK(Colour(Configured<Config1>::getConfiguration<Wrapped>(colourName, Wrapped(Colour::blue))) == Colour::green);
+    Configurator::clear();
+    // stream extraction and the call operator (EnumWrapper.hpp:68-76,99-111)
+    Wrapped w;
+    std::istringstream is("blue green");
+    is >> w;
+    CHECK(Colour(w) == Colour::blue);
+    is >> w;
+    CHECK(Colour(w) == Colour::green);
+    CHECK(w("red") == Colour::red && Colour(w) == Colour::red);
+    CHECK_THROWS_AS(w("purple"), std::out_of_range); // map.at
+    std::istringstream bad("purple");
+    CHECK_THROWS_AS(bad >> w, EnumWrap::validation_error); // an unknown token is a validation error of the option
+    CHECK_THROWS_AS(bad >> w, std::logic_error); // ... which is a std::logic_error, as boost's validation_error
+    addConfig("[option]\ncolour = mauve\n");
+    CHECK_THROWS_AS(Configured<Config1>::getConfiguration<Wrapped>(colourName, Wrapped(Colour::blue)), EnumWrap::validation_error);
+    Configurator::clear();
+    // setMap replaces the map (EnumWrapper.hpp:84-88); MAP_ENUM is the helper its documentation describes
+    MAP_ENUM(Colour, { "rouge", Colour::red }, { "vert", Colour::green });
+    CHECK(w("vert") == Colour::green);
+    CHECK_THROWS_AS(w("green"), std::out_of_range);
 }
 
 static void test_command_line_parser()
@@ -645,6 +685,7 @@ int main(int argc, char** argv)
             test_configured_module();
             test_configurator();
             test_command_line_parser();
+            test_enum_wrapper();
             test_iterator();
             test_timer();
             test_physics_config();

@@ -120,5 +120,15 @@ def test_parameter_or_grid_change_invalidates_the_packed_coefficients(ctx):
     ctx.mevp_pack_nodal(120.0, *nodal, packed)
     ctx.set_grid(nx, ny, 2.0, 1.0)  # ... and does not invalidate a packing
     ctx.mevp_iterate(0, 0, ny, s, so, (u, v), (un, vn), packed, pg)
+    # another SHAPE with the same cell size: the packed coefficients (and the arrays) belong to the old local array
+    ctx.set_grid(nx, ny - 2, 2.0, 1.0)
+    with pytest.raises(abi.NsdgError, match="pack_nodal was not called"):
+        ctx.mevp_iterate(0, 0, ny - 2, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_grid(nx - 6, ny, 2.0, 1.0)
+    with pytest.raises(abi.NsdgError, match="pack_nodal was not called"):
+        ctx.mevp_iterate3(0, ny, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_grid(nx, ny, 2.0, 1.0)  # back to the first shape: still invalid until repacked
+    with pytest.raises(abi.NsdgError, match="pack_nodal was not called"):
+        ctx.mevp_iterate(0, 0, ny, s, so, (u, v), (un, vn), packed, pg)
     ctx.set_mevp_params(ctx.mevp_default_params())
     torch.cuda.synchronize()
