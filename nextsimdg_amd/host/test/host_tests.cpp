@@ -623,6 +623,79 @@ static void test_rendezvous()
     RankEnvironment lonely; // nobody listens: a clear error after the timeout, not a hang
     lonely.world = 2, lonely.rank = 1, lonely.masterPort = a.masterPort + 100;
     CHECK_THROWS_AS(broadcastFromRankZero(lonely, got, sizeof got, 1), std::runtime_error);
+    // ... and the other way round: rank 0 serves, a rank has died before it connected
+    RankEnvironment server;
+    server.world = 3, server.rank = 0, server.masterPort = a.masterPort + 200;
+    CHECK_THROWS_AS(broadcastFromRankZero(server, sent, sizeof sent, 1), std::runtime_error);
+}
+
+static void test_restart_gather()
+{ // the owned rows of every rank of a multi-process run reach rank 0, which writes the ONE restart file
+    const int nx = 7, ny = 10, world = 3;
+    auto filled = [&](int rank) { // what rank `rank` holds at the end: its own rows current, every other row stale
+        FieldStore f;
+        f.resize((std::size_t)nx * ny, 1);
+        int r0, r1;
+        DynamicsStep::splitRows(ny, world, rank, r0, r1);
+        for (int e = 0; e < nx * ny; ++e) {
+            const bool mine = e / nx >= r0 && e / nx < r1;
+            const double stale = -1000. - rank;
+            f.hice[e] = mine ? 1. + e : stale, f.cice[e] = mine ? 2. + e : stale, f.hsnow[e] = mine ? 3. + e : stale;
+            f.tice[e] = mine ? 4. + e : stale, f.newice[e] = mine ? 5. + e : stale;
+        }
+        return f;
+    };
+    for (bool thermo : { false, true }) {
+        RankEnvironment env[world];
+        const int port = 20000 + (int)(std::hash<std::thread::id>()(std::this_thread::get_id()) % 20000) + (thermo ? 50 : 40);
+        for (int r = 0; r < world; ++r)
+            env[r].world = world, env[r].rank = r, env[r].masterPort = port;
+        FieldStore root = filled(0);
+        std::vector<std::thread> senders;
+        std::exception_ptr err[world];
+        for (int r = 1; r < world; ++r)
+            senders.emplace_back([&, r] {
+                try {
+                    FieldStore f = filled(r);
+                    int r0, r1;
+                    DynamicsStep::splitRows(ny, world, r, r0, r1);
+                    const std::vector<double> rows = DynamicsStep::packRows(f, thermo, nx, r0, r1);
+                    gatherToRankZero(env[r], rows.data(), rows.size() * sizeof(double), nullptr, 20);
+                } catch (...) {
+                    err[r] = std::current_exception();
+                }
+            });
+        int delivered = 0;
+        gatherToRankZero(env[0], nullptr, 0, [&](int rank, const char* data, std::size_t bytes) {
+            int a, b;
+            DynamicsStep::splitRows(ny, world, rank, a, b);
+            DynamicsStep::placeRows(root, thermo, nx, a, b, reinterpret_cast<const double*>(data), bytes / sizeof(double));
+            ++delivered;
+        }, 20);
+        for (auto& t : senders)
+            t.join();
+        CHECK(delivered == world - 1 && !err[1] && !err[2]);
+        bool ok = true;
+        for (int e = 0; e < nx * ny; ++e) {
+            ok = ok && root.hice[e] == 1. + e && root.cice[e] == 2. + e; // every row current, none stale
+            int r0, r1;
+            DynamicsStep::splitRows(ny, world, 0, r0, r1);
+            const bool own = e / nx < r1;
+            // without thermodynamics the column planes do not travel (they never change): rank 0 keeps its own
+            ok = ok && root.hsnow[e] == ((thermo || own) ? 3. + e : -1000.) && root.newice[e] == ((thermo || own) ? 5. + e : -1000.);
+        }
+        CHECK(ok);
+        const std::vector<double> few(5, 0.);
+        CHECK_THROWS_AS(DynamicsStep::placeRows(root, thermo, nx, 0, 3, few.data(), few.size()), std::runtime_error);
+    }
+    // a rank that died before the end never delivers: rank 0 gives up after the timeout instead of hanging
+    RankEnvironment alone;
+    alone.world = 2, alone.rank = 0, alone.masterPort = 20000 + (int)(std::hash<std::thread::id>()(std::this_thread::get_id()) % 20000) + 60;
+    CHECK_THROWS_AS(gatherToRankZero(alone, nullptr, 0, [](int, const char*, std::size_t) {}, 1), std::runtime_error);
+    RankEnvironment orphan = alone; // ... and a sender whose rank 0 has gone
+    orphan.rank = 1, orphan.masterPort += 7;
+    const double x = 1.;
+    CHECK_THROWS_AS(gatherToRankZero(orphan, &x, sizeof x, nullptr, 1), std::runtime_error);
 }
 
 static FieldStore run_dynamics(const std::string& extra, double* umax)
@@ -692,6 +765,7 @@ int main(int argc, char** argv)
             test_structure();
             test_restart_hdf5();
             test_rendezvous();
+            test_restart_gather();
         } else {
             test_hipstep_melting();
             test_model_dev1();

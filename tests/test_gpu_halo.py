@@ -242,3 +242,97 @@ def test_two_row_ranges_in_one_launch_equal_two_launches_bitwise(ctx):
     with pytest.raises(abi.NsdgError, match="disjoint"):
         ctx.mevp_iterate3_pair((10, 40), (30, 60), s, [torch.zeros_like(x) for x in s], (u, v), (torch.zeros_like(u), torch.zeros_like(v)), packed, pg)
     ctx.set_mevp_params(ctx.mevp_default_params())
+
+
+def test_graph_replay_follows_parameter_time_step_and_strip_changes(gpu):
+    """a captured group of launches bakes in the launch constants of the context (K = rho beta / dt, 1 / alpha, Delta_min^2,
+    the strip height): after nsdg_mevp_params_set, a new time step or another strip height the cached graphs must be
+    dropped, not replayed -- the replaying plan follows the same sequence of changes bit for bit as the plain one"""
+    from nextsimdg_amd import rowblock, synthetic
+
+    nx, ny, nsub = 150, 64, 14
+    bt = synthetic.BoxTest(nx, ny)
+    dev = lambda a: torch.from_numpy(a.copy()).cuda()
+    H, A = (dev(x) for x in bt.dg_fields())
+    uo, vo = (dev(x) for x in bt.ocean())
+    ua, va = (dev(3.0 * x) for x in bt.wind(0.0))
+    results = []
+    for use_graph in (False, True):
+        c = abi.Context(gpu)
+        c.set_grid(nx, ny, bt.hx, bt.hy)
+        z = lambda: torch.zeros(2 * ny + 1, 2 * nx + 1, dtype=torch.float64, device="cuda")
+        s2 = ([c.private_zeros(8, ny, nx, "cuda") for _ in range(3)], [c.private_zeros(8, ny, nx, "cuda") for _ in range(3)])
+        uv2 = ((z(), z()), (z(), z()))
+        pg = c.private_zeros(9, ny, nx, "cuda")
+        packed = torch.zeros(8 * uv2[0][0].numel(), dtype=torch.float64, device="cuda")
+        c.ice_strength(H, A, pg)
+        run, per_pass, _ = c.rb_mevp(rowblock.RowBlock(nx, ny, 0, 1), (None, None), nsub, True, use_graph, s2, uv2, packed, pg)
+        assert per_pass == 3
+        par = 0
+        for alpha, beta, dt, strip in ((300.0, 300.0, 120.0, 0), (300.0, 300.0, 120.0, 0), (450.0, 300.0, 120.0, 0), (450.0, 520.0, 120.0, 0),
+                                       (450.0, 520.0, 90.0, 0), (450.0, 520.0, 90.0, 7), (300.0, 300.0, 120.0, 0)):
+            c.set_mevp_params(c.mevp_default_params(alpha=alpha, beta=beta))
+            c.set_mevp_strip_rows(strip)
+            c.mevp_prepare(dt, H, A, (ua, va), (uo, vo), uv2[par], packed)
+            par = run(par)
+        torch.cuda.synchronize()
+        results.append([x.clone() for x in list(s2[par]) + list(uv2[par])])
+        del run
+        c.close()
+    assert float(results[0][3].abs().max()) > 1e-6
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
+def test_block_with_fewer_owned_rows_than_it_sends_is_rejected(ctx):
+    """depth_below element rows travel upwards and depth_above + 1 downwards: a block with neighbours that owns fewer rows
+    would pack rows of its own ghost zone -- nsdg_rb_*_create refuses it (the Python RowBlock refuses such a split too)"""
+    import types
+
+    nx, own, db, da = 70, 5, 6, 5
+    ny = own + db + da
+    ctx.comm_init_local(91, 1, 3)
+    ctx.set_grid(nx, ny, 1.0, 1.0)
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")
+    blk = types.SimpleNamespace(nx=nx, ny=ny, j0=db, j1=ny - da, depth_below=db, depth_above=da)
+    s2 = ([ctx.private_zeros(8, ny, nx, "cuda") for _ in range(3)], [ctx.private_zeros(8, ny, nx, "cuda") for _ in range(3)])
+    uv2 = ((z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)), (z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)))
+    packed, pg = z(8 * (2 * ny + 1) * (2 * nx + 1)), ctx.private_zeros(9, ny, nx, "cuda")
+    with pytest.raises(abi.NsdgError, match="must own at least"):
+        ctx.rb_mevp(blk, (0, 2), 9, True, False, s2, uv2, packed, pg)
+    f = [z(6, ny, nx) for _ in range(3)]
+    adv = (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
+    with pytest.raises(abi.NsdgError, match="must own at least"):
+        ctx.rb_transport(blk, (0, 2), f[0:1], f[1:2], f[2:3], adv)
+    ctx.comm_finalize()
+
+
+@pytest.mark.parametrize("nfields", [3, 4])
+def test_transport_plan_of_an_interior_block_with_four_fields(gpu, nfields):
+    """NSDG_RB_MAX_FIELDS = 4 DG2 fields on an interior block: 6 planes per field and direction = 48 row blocks in one
+    plan (the segment table held 32 in round 2).  In RCCL-free loopback (both neighbours are the rank itself) what goes
+    up must arrive from below, plane by plane"""
+    import types
+
+    nx, own, db, da = 66, 20, 3, 2
+    ny = own + db + da
+    c = abi.Context(gpu)
+    c.comm_init_local(92, 0, 1)
+    c.set_grid(nx, ny, 1.0, 1.0)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    r = lambda *s: torch.rand(*s, dtype=torch.float64, device="cuda", generator=g)
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")
+    blk = types.SimpleNamespace(nx=nx, ny=ny, j0=db, j1=ny - da, depth_below=db, depth_above=da)
+    phi = [r(6, ny, nx) for _ in range(nfields)]
+    t1, t2 = [z(6, ny, nx) for _ in range(nfields)], [z(6, ny, nx) for _ in range(nfields)]
+    adv = (z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))  # velocity zero: a step leaves the owned rows as they are
+    tr = c.rb_transport(blk, (0, 0), phi, t1, t2, adv)
+    assert tr(120.0, 0) == 1
+    torch.cuda.synchronize()
+    for f in range(nfields):
+        assert torch.equal(t1[f][:, db:ny - da], phi[f][:, db:ny - da])
+        # loopback: the top depth_below owned rows arrive as the ghost rows below, the bottom depth_above as those above
+        assert torch.equal(t1[f][:, :db], t1[f][:, ny - da - db:ny - da]), f
+        assert torch.equal(t1[f][:, ny - da:], t1[f][:, db:db + da]), f
+    del tr
+    c.close()

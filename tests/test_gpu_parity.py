@@ -705,3 +705,105 @@ def test_mevp_prepare_equals_separate_kernels_bitwise(ctx):
     p2 = torch.zeros_like(p1)
     ctx.mevp_prepare(120.0, dH, dA, (ua, va), (uo, vo), (u0, v0), p2)
     assert torch.equal(p1, p2)
+
+
+# ------------------------------------------------------------------------------------ frozen oracle outputs (self-fixture)
+def frozen(case):
+    """arrays of one case of tests/golden/dyn_selfcheck_v1 (self-fixture -- NOT reference parity, see tests/dyn_fixture_cases.py)"""
+    import json
+    import os
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    idx = json.load(open(os.path.join(golden, "dyn_selfcheck_v1.json")))
+    data = np.fromfile(os.path.join(golden, idx["data_file"]), dtype="<f8")
+    return {e["name"]: data[e["offset"]:e["offset"] + int(np.prod(e["shape"]))].reshape(e["shape"]) for e in idx["arrays"] if e["case"] == case}
+
+
+@pytest.mark.parametrize("variant", [1, 3])
+def test_hip_path_matches_the_frozen_oracle_outputs(ctx, variant):
+    """The HIP path against the COMMITTED outputs of oracle/dyn_oracle.c (tests/golden/dyn_selfcheck_v1.*), at the
+    tolerances of the live comparisons above: DG0/1/2 transport (3 steps, 70 x 37), one mEVP sub-iteration (67 x 21), the
+    25-sub-iteration cycle (48 x 40), one coupled step (40 x 32).  Self-fixture, not reference parity: it pins the kernels
+    to what the specification computed when the fixture was written, whatever the oracle in the tree computes today."""
+    import dyn_fixture_cases as cases
+
+    ctx.set_mevp_variant(variant)
+    z = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")
+    # ---- transport
+    for order in cases.ORDERS:
+        want = frozen("transport_dg%d" % order)
+        i = cases.inputs_transport(order)
+        nx, ny = i["nx"], i["ny"]
+        ctx.set_grid(nx, ny, i["hx"], i["hy"])
+        adv = adv_on_device(ctx, nx, ny, order, i["u"], i["v"])
+        for a, name in zip(adv, ("vx", "vy", "unx", "uny")):
+            assert_close(host(a), want[name], 1e-13, 1e-14, "frozen %s order %d" % (name, order))
+        phi = [dev(i["phi"])]
+        scratch = z(2 * phi[0].numel())
+        for _ in range(i["nsteps"]):
+            ctx.transport_step(order, i["dt"], phi, adv, scratch)
+        assert_close(host(phi[0]), want["phi"], 1e-12, 1e-13, "frozen transport order %d" % order)
+    # ---- one mEVP sub-iteration
+    want = frozen("mevp_single")
+    b, u, v, s = cases.inputs_mevp_single()
+    nx, ny = b.nx, b.ny
+    ctx.set_mevp_params(ctx.mevp_default_params(**b.params))
+    ctx.set_grid(nx, ny, b.bt.hx, b.bt.hy)
+    pg = ctx.private_zeros(9, ny, nx, "cuda")
+    ctx.ice_strength(dev(b.H), dev(b.A), pg)
+    assert_close(thost(pg, nx), want["pg"], 1e-12, 1e-10, "frozen ice strength")
+    cgh, cga, tax, tay = z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)
+    ctx.dg_to_cg(dev(b.H), cgh)
+    ctx.dg_to_cg(dev(b.A), cga)
+    ctx.wind_stress(dev(b.ua), dev(b.va), tax, tay)
+    for g, name in ((cgh, "cgh"), (cga, "cga")):
+        assert_close(host(g), want[name], 1e-13, 1e-14, "frozen " + name)
+    for g, name in ((tax, "tax"), (tay, "tay")):
+        assert_close(host(g), want[name], 1e-13, 1e-16, "frozen " + name)
+    packed = z(8 * cgh.numel())
+    ctx.mevp_pack_nodal(120.0, (dev(0.9 * u), dev(0.9 * v)), (tax, tay), (dev(b.uo), dev(b.vo)), cgh, cga, packed)
+    ds, dso = [tdev(x) for x in s], [torch.zeros_like(tdev(x)) for x in s]
+    dun, dvn = z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)
+    ctx.mevp_iterate(0, 0, ny, ds, dso, (dev(u), dev(v)), (dun, dvn), packed, pg)
+    for d, name in zip(dso, ("s11", "s12", "s22")):
+        assert_close(thost(d, nx), want[name], 1e-12, 1e-12 * np.max(np.abs(want[name])), "frozen " + name)
+    assert_close(host(dun), want["u"], 1e-11, 1e-13 * np.max(np.abs(want["u"])), "frozen u_new")
+    assert_close(host(dvn), want["v"], 1e-11, 1e-13 * np.max(np.abs(want["v"])), "frozen v_new")
+    # ---- the 25-sub-iteration cycle
+    want = frozen("mevp_cycle")
+    b, nsub = cases.inputs_mevp_cycle()
+    nx, ny = b.nx, b.ny
+    ctx.set_mevp_params(ctx.mevp_default_params(**b.params))
+    ctx.set_grid(nx, ny, b.bt.hx, b.bt.hy)
+    pg = ctx.private_zeros(9, ny, nx, "cuda")
+    ctx.ice_strength(dev(b.H), dev(b.A), pg)
+    cgh, cga, tax, tay = z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)
+    ctx.dg_to_cg(dev(b.H), cgh)
+    ctx.dg_to_cg(dev(b.A), cga)
+    ctx.wind_stress(dev(b.ua), dev(b.va), tax, tay)
+    du, dv = z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1)
+    ds = [ctx.private_zeros(8, ny, nx, "cuda") for _ in range(3)]
+    scratch = z(10 * du.numel() + 3 * ds[0].numel())
+    ctx.mevp_subcycle(120.0, nsub, ds, du, dv, z(2 * ny + 1, 2 * nx + 1), z(2 * ny + 1, 2 * nx + 1), tax, tay, dev(b.uo), dev(b.vo), cgh, cga, pg, scratch)
+    assert np.max(np.abs(want["u"])) > 1e-4
+    assert_close(host(du), want["u"], 1e-9, 1e-11 * np.max(np.abs(want["u"])), "frozen u after the cycle")
+    assert_close(host(dv), want["v"], 1e-9, 1e-11 * np.max(np.abs(want["v"])), "frozen v after the cycle")
+    for d, name in zip(ds, ("s11", "s12", "s22")):
+        assert_close(thost(d, nx), want[name], 1e-9, 1e-10 * np.max(np.abs(want[name])), "frozen %s after the cycle" % name)
+    # ---- one coupled step through the driver (column physics + sub-cycle + transport)
+    want = frozen("coupled_step")
+    c = cases.COUPLED
+    ctx.set_mevp_params(ctx.mevp_default_params(alpha=c["alpha"], beta=c["beta"]))
+    ctx.set_column_params(ctx.column_default_params())
+    core = cases.run_coupled(ctx, torch.device("cuda"), native=(variant == 3))
+    torch.cuda.synchronize()
+    for k in ("H", "A"):
+        assert_close(host(getattr(core, k)), want[k], 1e-10, 1e-12, "frozen coupled " + k)
+    for k in ("u", "v"):
+        assert_close(host(getattr(core, k)), want[k], 1e-9, 1e-11 * np.max(np.abs(want[k])), "frozen coupled " + k)
+    for d, name in zip(core.s, ("s11", "s12", "s22")):
+        assert_close(thost(d, c["nx"]), want[name], 1e-9, 1e-10 * np.max(np.abs(want[name])), "frozen coupled " + name)
+    for k in ("tice0", "hsnow"):
+        assert_close(host(core.col[k]), want[k], 1e-10, 1e-12, "frozen coupled " + k)
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
+    ctx.set_mevp_params(ctx.mevp_default_params())

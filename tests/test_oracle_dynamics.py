@@ -216,3 +216,39 @@ def test_mevp_point_symmetry():
     assert np.max(np.abs(u)) > 1e-5
     np.testing.assert_allclose(u, -u[::-1, ::-1], rtol=0, atol=1e-12 * np.max(np.abs(u)))
     np.testing.assert_allclose(v, -v[::-1, ::-1], rtol=0, atol=1e-12 * np.max(np.abs(v)))
+
+
+# ------------------------------------------------------------------------------------ frozen outputs (self-fixture)
+def test_oracle_reproduces_its_frozen_outputs():
+    """SELF-FIXTURE -- NOT reference parity (the reference has no DG / mEVP code).  The oracle is the
+    specification of the dynamics; tests/golden/dyn_selfcheck_v1.{json,f64} (tools/gen_dyn_fixtures.py) freeze its
+    outputs for DG0/1/2 transport (3 steps, 70 x 37), one mEVP sub-iteration (67 x 21), the 25-sub-iteration cycle
+    (48 x 40) and one coupled step (40 x 32).  Every array must come out bit for bit: a change of a coefficient or of
+    a summation order in oracle/dyn_oracle.c fails here even if the kernels were changed the same way."""
+    import hashlib
+    import json
+    import os
+
+    import dyn_fixture_cases as cases
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    idx = json.load(open(os.path.join(golden, "dyn_selfcheck_v1.json")))
+    data = np.fromfile(os.path.join(golden, idx["data_file"]), dtype="<f8")
+    assert hashlib.sha256(data.tobytes()).hexdigest() == idx["data_sha256"]
+    assert "NOT reference parity" in idx["title"]
+    seen = set()
+    outs = {}
+    for e in idx["arrays"]:
+        if e["case"] not in outs:
+            outs[e["case"]] = cases.CASES[e["case"]]()
+        got = np.ascontiguousarray(outs[e["case"]][e["name"]], dtype="<f8")
+        n = int(np.prod(e["shape"]))
+        want = data[e["offset"]:e["offset"] + n].reshape(e["shape"])
+        assert list(got.shape) == e["shape"], (e["case"], e["name"])
+        assert [float(x).hex() for x in want.reshape(-1)[:4]] == e["first"]  # the index and the data file belong together
+        if hashlib.sha256(got.tobytes()).hexdigest() != e["sha256"]:
+            diff = np.abs(got - want)
+            raise AssertionError("%s/%s is not the frozen output: %d of %d values differ, largest difference %.3e (%.3e relative to the "
+                                 "largest value)" % (e["case"], e["name"], int((got != want).sum()), n, diff.max(), diff.max() / max(np.abs(want).max(), 1e-300)))
+        seen.add(e["case"])
+    assert seen == set(cases.CASES)
