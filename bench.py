@@ -41,6 +41,7 @@ BYTES_PER_ELEM_SUBITER = 896  # byte model of ONE mEVP s
 BYTES_COMPULSORY_PER_PASS = 776  # what a pass of a fused kernel must move per element whatever it computes on chip
 SHADER_CLOCK_PEAK_HZ = 2.4e9  # MI355X_MICROARCH.md: peak engine clock
 BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
+COMM_DEADLINE_S = float(os.environ.get("NSDG_COMM_TIMEOUT_S", "300"))  # a rank that has died must not block the others for ever
 
 
 class stdout_to_stderr:
@@ -81,15 +82,51 @@ def host_cores():
     return n
 
 
+def set_omp_threads(n):
+    """thread count of the OpenMP build of the oracle: a launcher (torch.distributed.run) exports OMP_NUM_THREADS=1 and
+    torch has initialised libgomp with it by the time this runs, so the environment variable alone is too late"""
+    import ctypes
+
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+    return int(n)
+
+
+def copy_peak_gbs(ctx, device, mib=1024, reps=10):
+    """measured device-copy ceiling of THIS box: a 16-byte-per-lane streaming copy (nsdg_copy_f64) of `mib` MiB -- four
+    times the 256 MiB Infinity Cache -- timed with HIP events on the context's stream; GB/s counts read + write"""
+    n = mib * (1 << 20) // 8
+    src = torch.ones(n, dtype=torch.float64, device=device)
+    dst = torch.empty_like(src)
+    for _ in range(3):
+        ctx.copy_f64(dst, src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(ctx.stream)
+    for _ in range(reps):
+        ctx.copy_f64(dst, src)
+    e1.record(ctx.stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ok = bool((dst[::4097] == 1.0).all())
+    del src, dst
+    torch.cuda.empty_cache()
+    if not ok:
+        raise SystemExit("device copy produced wrong values: invalid run")
+    return 2.0 * n * 8 / (ms * 1e-3) / 1e9
+
+
 def cpu_baseline(nsub_full, budget_s=12.0):
     """Time the CPU oracle (tests' checker; here only as the reported baseline) on a bounded sample
     of the same workload: a 192 x 192 box test, a few mEVP sub-iterations and one transport step,
     single thread (the reference itself is single-threaded), then extrapolate
     per element: t_step = nsub * t_subiter + t_transport."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
     import oracle_lib as O
 
+    cores = set_omp_threads(host_cores())
     n = 192
     bt = synthetic.BoxTest(n, n)
     p = O.mevp_params()
@@ -134,7 +171,6 @@ def cpu_baseline(nsub_full, budget_s=12.0):
             O.transport_step(n, n, bt.hx, bt.hy, 2, 120.0, f, adv, omp=omp)
         t_tr = (time.perf_counter() - t0) / (n * n)
         out[omp] = (1.0 / (nsub_full * t_sub + t_tr), 1.0 / t_sub, k)
-    cores = int(os.environ["OMP_NUM_THREADS"])
     res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port", "extrapolated": True,
            "sample": "EXTRAPOLATED, not the 2048x2048 workload itself: oracle/dyn_oracle.c on a 192x192 box test, %d mEVP sub-iterations + "
                      "1 DG2 RK3 transport step of H and A, per-element costs scaled to %d sub-iterations/step; own CPU restatement -- "
@@ -208,8 +244,7 @@ def column_bench(args, device):
         O.column_step(O.column_params(), 600.0, st, fo, ni)
         reps += 1
     cpu = reps * m / (time.perf_counter() - c0)
-    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
-    cores = int(os.environ["OMP_NUM_THREADS"])
+    cores = set_omp_threads(host_cores())
     big = 1 << 24  # large enough for every host core to have work
     st, fo, ni = synthetic.column_fields(big)
     O.column_step(O.column_params(), 600.0, st, fo, ni, omp=True)
@@ -341,7 +376,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            import datetime
+
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=COMM_DEADLINE_S))
             dist.barrier()  # the first collective creates torch's communicator (and waits for rank 0's build)
             torch.cuda.synchronize()
 
@@ -387,35 +424,59 @@ def main():
 
     def sync():
         # drain this rank's own work first: the ghost exchanges run on the library's RCCL communicator, the barrier on
-        # torch's -- two communicators are never given work at the same time
+        # torch's -- two communicators are never given work at the same time.  With neighbours the drain is BOUNDED
+        # (nsdg_ctx_synchronize polls the streams against the communicator's deadline): a rank whose neighbour has died
+        # leaves with a non-zero status instead of waiting in ncclRecv for ever; the launcher then ends the others.
+        if exchanger is not None:
+            try:
+                ctx.synchronize()
+            except abi.NsdgError as e:
+                sys.stderr.write("bench.py rank %d: %s\n" % (rank, e))
+                sys.stderr.flush()
+                os._exit(3)  # no destructors: they would synchronise a device that cannot drain
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if exchanger is not None and hasattr(ctx, "comm_deadline"):
+        ctx.comm_deadline(COMM_DEADLINE_S)
     for _ in range(args.warmup):
         core.step()
     sync()
+    exchange_stats(core, reset=True)  # count the exchanges of the timed region only
     # Timed region: EXACTLY what core.step() does (column thermodynamics when coupled, per-step preparation, the
     # sub-cycle, transport), with HIP events on the context's stream around the sub-cycle for the dominant kernel
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
+        ev[k][0].record(ctx.stream)
         core._set_grid()
         if coupled:
             core.thermodynamics()
         core.prepare()
-        ev[k][0].record(ctx.stream)
-        core.subcycle()
         ev[k][1].record(ctx.stream)
+        core.subcycle()
+        ev[k][2].record(ctx.stream)
         core.transport()
+        ev[k][3].record(ctx.stream)
     sync()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
-    cycle_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))  # one sub-cycle (nsub sub-iterations), this rank
+    cycle_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))  # one sub-cycle (nsub sub-iterations), this rank
+    rank_report = {"rank": rank, "rows_owned": blk.r1 - blk.r0, "rows_local": blk.ny, "ghost_rows_below": blk.gb, "ghost_rows_above": blk.gt,
+                   "cycle_ms": cycle_ms, "prepare_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
+                   "transport_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev])),
+                   "step_gpu_ms": float(np.mean([e[0].elapsed_time(e[3]) for e in ev])), "step_wall_ms": 1e3 * own_elapsed / args.steps}
+    rank_report.update(exchange_stats(core, steps=args.steps))
+    reports = [rank_report]
+    if use_dist:
+        reports = [None] * world
+        dist.all_gather_object(reports, rank_report)
 
     # ---- validity of the run: finite, non-trivial, and the fused pass still equals single sub-iterations bit for bit
     ok = torch.tensor([float(bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())), float(core.u.abs().max())],
@@ -446,8 +507,12 @@ def main():
         compulsory = own_elems * BYTES_COMPULSORY_PER_PASS
         achieved = compulsory / (launch_ms * 1e-3) / 1e9
         off = offline_counters(nx, ny, fused_kernel) if world == 1 else None
+        copy_peak = copy_peak_gbs(ctx, device)
         roof = {"bound": "hbm", "kernel": fused_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "copy_peak_GBs": copy_peak, "frac_of_copy_peak": achieved / copy_peak,
+                "copy_peak_note": "measured in this run on this box: nsdg_copy_f64, 16 bytes per lane, 1 GiB read + 1 GiB written per launch "
+                                  "(SURVEY.md 8(d): 'additionally against a measured device-copy peak on the box')",
                 "traffic": off["traffic"] if off else None,
                 "traffic_source": (off["source"] + (" -- STALE: kernel sources changed since" if off["stale"] else "")) if off else None,
                 "algorithmic_bytes_per_launch": compulsory,
@@ -480,6 +545,15 @@ def main():
             "roofline": roof,
             "mevp_element_subiters_per_s": own_elems * nsub / (cycle_ms * 1e-3),
         }
+        if world > 1:
+            cyc = [r["cycle_ms"] for r in reports]
+            line["ranks"] = {"cycle_ms_min": min(cyc), "cycle_ms_max": max(cyc), "step_gpu_ms_max": max(r["step_gpu_ms"] for r in reports),
+                             "exchange_ms_per_step_max": max((r.get("mevp_exchange_ms_per_step") or 0.0) + (r.get("transport_exchange_ms_per_step") or 0.0)
+                                                             for r in reports),
+                             "note": "per rank: GPU time of a step and of its parts (HIP events on the rank's stream), and the ghost exchanges -- "
+                                     "time on the communication stream from 'data ready' to 'ghost rows written' (pack + transfer + unpack + "
+                                     "waiting for a late neighbour; it overlaps with the interior launch of the overlap split)",
+                             "per_rank": reports}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nsub)
         print(json.dumps(line), flush=True)
@@ -488,6 +562,23 @@ def main():
     ctx.close()  # the library's communicator goes before torch's process group
     if use_dist:
         dist.destroy_process_group()
+
+
+def exchange_stats(core, steps=None, reset=False):
+    """ghost-exchange statistics of the native row-block drivers (nsdg_rb_*_stats): per model step when `steps` is given"""
+    out = {}
+    for name, run in (("mevp", getattr(core, "_run_mevp", None)), ("transport", getattr(core, "_run_transport", None))):
+        st = getattr(run, "stats", None)
+        if st is None:
+            continue
+        d = st(reset)
+        if steps and d["exchanges"]:
+            out["%s_exchanges_per_step" % name] = d["exchanges"] / steps
+            out["%s_exchange_ms_per_step" % name] = d["ms"] / steps
+            out["%s_exchange_ms_each" % name] = d["ms"] / max(d["exchanges"] - d["untimed"], 1)
+            out["%s_exchange_bytes_sent" % name] = d["bytes_sent"]
+            out["%s_exchanges_untimed" % name] = d["untimed"]
+    return out
 
 
 def plan_blocks(variant, passes_per_exchange, nx, ny, rank, world):

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define NSDG_ABI_VERSION 2
+#define NSDG_ABI_VERSION 3
 
 typedef enum {
     NSDG_OK = 0,
@@ -74,7 +74,17 @@ int nsdg_abi_version(void);
 const char* nsdg_last_error(void);
 int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out);
 int nsdg_ctx_destroy(nsdg_ctx* ctx);
+/* Waits for everything enqueued on the context's stream (and its communication stream).  On a context with a
+ * communicator the wait is BOUNDED by the communicator's deadline (nsdg_comm_deadline_set): if the streams have not
+ * drained by then -- a neighbour rank that died leaves ncclRecv waiting for ever -- it returns NSDG_ERR_COMM, the
+ * communicator is marked broken (nsdg_comm_finalize then aborts it instead of draining it) and the caller should
+ * leave the process with a non-zero status without synchronising the device again. */
 int nsdg_ctx_synchronize(nsdg_ctx* ctx);
+
+/* Measurement aid: streaming device copy of n doubles, 16 bytes per lane and access -- the "device-copy peak" that
+ * SURVEY.md section 8(d) asks the roofline fraction to be quoted against, measured on the box the bench runs on
+ * (bench.py: roofline.copy_peak_GBs).  dst and src 16-byte aligned, not overlapping. */
+int nsdg_copy_f64(nsdg_ctx* ctx, double* dst, const double* src, int64_t n);
 
 /* ---- column physics (the reference's per-element step) ---------------------------------------- */
 enum { NSDG_ALBEDO_SMU = 0, NSDG_ALBEDO_SMU2 = 1, NSDG_ALBEDO_CCSM = 2 }; /* physics/src/modules/modules.json:4-8 */
@@ -291,6 +301,10 @@ int nsdg_comm_init(nsdg_ctx* ctx, int32_t rank, int32_t world, const void* id);
 int nsdg_comm_init_local(nsdg_ctx* ctx, int64_t group, int32_t rank, int32_t world);
 int nsdg_comm_finalize(nsdg_ctx* ctx);
 int nsdg_comm_rank(nsdg_ctx* ctx, int32_t* rank, int32_t* world);
+/* Upper bound in seconds on any wait for a neighbour: the host-side hand-shake of the local transport and the drain in
+ * nsdg_ctx_synchronize (RCCL: a dead peer never answers).  0 = wait for ever.  Default: the environment variable
+ * NSDG_COMM_TIMEOUT_S, else 300.  May be called before or after nsdg_comm_init*. */
+int nsdg_comm_deadline_set(nsdg_ctx* ctx, double seconds);
 
 /* A plan fixes what ONE kind of exchange moves: for each of the four directions a list of contiguous blocks of
  * doubles in the caller's arrays (row blocks: ghost rows are contiguous in every layout of this ABI).  up_send
@@ -317,6 +331,19 @@ int nsdg_halo_counts(const nsdg_halo* plan, int64_t* up, int64_t* down, int64_t*
  * the two calls overlap with the exchange; they must not write the send blocks nor touch the receive blocks. */
 int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* plan);
 int nsdg_halo_finish(nsdg_ctx* ctx, nsdg_halo* plan);
+
+/* What the exchanges of a plan (or of all plans of a row-block driver) cost, measured with events on the communication
+ * stream: `ms` is the time from "the data to send is ready" (the compute stream has reached nsdg_halo_start) to "the
+ * ghost rows are written" (the unpack kernel has finished), summed over `exchanges` exchanges -- it contains the pack
+ * and unpack kernels, the transfer and any wait for a neighbour that is late, and it overlaps with whatever the
+ * compute stream does between start and finish.  `untimed` exchanges could not be timed (events recycled before they
+ * completed).  The call waits for the last exchange of the plan(s) to finish; reset != 0 zeroes the counters. */
+typedef struct {
+    int64_t exchanges, untimed;
+    double ms;
+    int64_t bytes_sent, bytes_received; /* per exchange */
+} nsdg_halo_stats;
+int nsdg_halo_stats_get(nsdg_ctx* ctx, nsdg_halo* plan, nsdg_halo_stats* out, int32_t reset);
 
 /* ---- row-block drivers: one call per model step for the sub-cycle and for the transport of a rank's block ------
  * The sequence of kernel passes and ghost exchanges that a multi-rank model step (IModelStep::iterate,
@@ -349,6 +376,8 @@ int nsdg_rb_mevp_info(const nsdg_rb_mevp* plan, int32_t* per_pass, int32_t* grou
 /* nsub sub-iterations; `parity` = which of the ping-pong buffers holds the current iterate (ghost rows valid),
  * *parity_out = which one holds the result (ghost rows refreshed) */
 int nsdg_rb_mevp_run(nsdg_ctx* ctx, nsdg_rb_mevp* plan, int32_t parity, int32_t* parity_out);
+/* exchange statistics summed over the plan's ghost exchanges (bytes: of its largest exchange) */
+int nsdg_rb_mevp_stats(nsdg_ctx* ctx, nsdg_rb_mevp* plan, nsdg_halo_stats* out, int32_t reset);
 
 #define NSDG_RB_MAX_FIELDS 4
 typedef struct nsdg_rb_transport nsdg_rb_transport;
@@ -368,6 +397,7 @@ int nsdg_rb_transport_destroy(nsdg_rb_transport* plan);
 /* one SSP-RK3 step.  parity 0: the state is in phi[], the new state (ghost rows refreshed) is written to t1[];
  * parity 1: the other way round; *parity_out = 1 - parity */
 int nsdg_rb_transport_run(nsdg_ctx* ctx, nsdg_rb_transport* plan, double dt, int32_t parity, int32_t* parity_out);
+int nsdg_rb_transport_stats(nsdg_ctx* ctx, nsdg_rb_transport* plan, nsdg_halo_stats* out, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,13 @@ class HaloSeg(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("count", C.c_int64)]
 
 
+class HaloStats(C.Structure):
+    _fields_ = [("exchanges", C.c_int64), ("untimed", C.c_int64), ("ms", C.c_double), ("bytes_sent", C.c_int64), ("bytes_received", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 COMM_ID_BYTES = 128
 RB_MAX_FIELDS = 4
 
@@ -68,6 +75,7 @@ SYMBOLS = {
     "nsdg_ctx_create": (C.c_int, [C.c_int, VP, C.POINTER(VP)]),
     "nsdg_ctx_destroy": (C.c_int, [VP]),
     "nsdg_ctx_synchronize": (C.c_int, [VP]),
+    "nsdg_copy_f64": (C.c_int, [VP, VP, VP, I64]),
     "nsdg_column_default_params": (None, [C.POINTER(ColumnParams)]),
     "nsdg_column_params_set": (C.c_int, [VP, C.POINTER(ColumnParams)]),
     "nsdg_column_step": (C.c_int, [VP, I64, D] + [VP] * 16),
@@ -103,19 +111,23 @@ SYMBOLS = {
     "nsdg_comm_init_local": (C.c_int, [VP, I64, I32, I32]),
     "nsdg_comm_finalize": (C.c_int, [VP]),
     "nsdg_comm_rank": (C.c_int, [VP, C.POINTER(I32), C.POINTER(I32)]),
+    "nsdg_comm_deadline_set": (C.c_int, [VP, D]),
     "nsdg_halo_plan_create": (C.c_int, [VP, I32, I32, I32, C.POINTER(HaloSeg), I32, C.POINTER(HaloSeg), I32, C.POINTER(HaloSeg), I32,
                                         C.POINTER(HaloSeg), C.POINTER(VP)]),
     "nsdg_halo_plan_destroy": (C.c_int, [VP]),
     "nsdg_halo_counts": (C.c_int, [VP] + [C.POINTER(I64)] * 4),
     "nsdg_halo_start": (C.c_int, [VP, VP]),
     "nsdg_halo_finish": (C.c_int, [VP, VP]),
+    "nsdg_halo_stats_get": (C.c_int, [VP, VP, C.POINTER(HaloStats), I32]),
     "nsdg_rb_mevp_create": (C.c_int, [VP, C.POINTER(RbMevpDesc), C.POINTER(VP)]),
     "nsdg_rb_mevp_destroy": (C.c_int, [VP]),
     "nsdg_rb_mevp_info": (C.c_int, [VP, C.POINTER(I32), C.POINTER(I32)]),
     "nsdg_rb_mevp_run": (C.c_int, [VP, VP, I32, C.POINTER(I32)]),
+    "nsdg_rb_mevp_stats": (C.c_int, [VP, VP, C.POINTER(HaloStats), I32]),
     "nsdg_rb_transport_create": (C.c_int, [VP, C.POINTER(RbTransportDesc), C.POINTER(VP)]),
     "nsdg_rb_transport_destroy": (C.c_int, [VP]),
     "nsdg_rb_transport_run": (C.c_int, [VP, VP, D, I32, C.POINTER(I32)]),
+    "nsdg_rb_transport_stats": (C.c_int, [VP, VP, C.POINTER(HaloStats), I32]),
 }
 
 _lib = None
@@ -236,6 +248,12 @@ class HaloPlanHandle:
 
         self.start, self.finish = start, finish
 
+    def stats(self, reset=False):
+        """what the exchanges of this plan cost so far (nsdg_halo_stats_get)"""
+        st = HaloStats()
+        self.ctx._call(self.ctx.lib.nsdg_halo_stats_get(self.ctx.h, self.h, C.byref(st), int(reset)))
+        return st.as_dict()
+
     def counts(self):
         c = [I64() for _ in range(4)]
         self.ctx._call(self.ctx.lib.nsdg_halo_counts(self.h, *[C.byref(x) for x in c]))
@@ -289,7 +307,19 @@ class Context:
             pass
 
     def synchronize(self):
+        """drains the context's streams; with a communicator the wait is bounded by its deadline (NsdgError on expiry)"""
         self._call(self.lib.nsdg_ctx_synchronize(self.h))
+
+    def copy_f64(self, dst, src):
+        """streaming device copy, 16 bytes per lane (the measured copy ceiling of the roofline)"""
+        _check_f64(dst, src)
+        if dst.numel() != src.numel():
+            raise NsdgError("copy_f64: sizes differ")
+        self._call(self.lib.nsdg_copy_f64(self.h, dst.data_ptr(), src.data_ptr(), src.numel()))
+
+    def comm_deadline(self, seconds):
+        """upper bound on any wait for a neighbour rank (0 = for ever)"""
+        self._call(self.lib.nsdg_comm_deadline_set(self.h, float(seconds)))
 
     def num_cus(self):
         import torch
@@ -353,8 +383,14 @@ class Context:
                 self._call(rc)
             return out.value
 
+        def stats(reset=False):
+            st = HaloStats()
+            self._call(self.lib.nsdg_rb_mevp_stats(ch, h, C.byref(st), int(reset)))
+            return st.as_dict()
+
         run.keep = ts
         run.handle = h
+        run.stats = stats
         return run, per_pass.value, group.value
 
     def rb_transport(self, blk, peers, phi, t1, t2, adv):
@@ -377,8 +413,14 @@ class Context:
                 self._call(rc)
             return out.value
 
+        def stats(reset=False):
+            st = HaloStats()
+            self._call(self.lib.nsdg_rb_transport_stats(ch, h, C.byref(st), int(reset)))
+            return st.as_dict()
+
         run.keep = ts
         run.handle = h
+        run.stats = stats
         return run
 
     # ---- arrays private to the mEVP sub-cycle (stress, ice strength) live in the tiled layout

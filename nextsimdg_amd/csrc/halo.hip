@@ -32,6 +32,7 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -45,6 +46,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -81,6 +83,7 @@ int rccl_load()
     NSDG_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
     NSDG_RCCL_SYM(CommInitRank, "ncclCommInitRank")
     NSDG_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    NSDG_RCCL_SYM(CommAbort, "ncclCommAbort")
     NSDG_RCCL_SYM(GroupStart, "ncclGroupStart")
     NSDG_RCCL_SYM(GroupEnd, "ncclGroupEnd")
     NSDG_RCCL_SYM(Send, "ncclSend")
@@ -124,15 +127,19 @@ struct LocalGroup {
 
 std::mutex g_groups_mutex;
 std::map<int64_t, LocalGroup*> g_groups;
-constexpr int LOCAL_TIMEOUT_S = 120;
 
 // pops the oldest entry of map[key], waiting for it; the map is only touched under the group's mutex
 template <class M>
-bool local_wait_pop(LocalGroup* g, M& map, const typename M::key_type& key, typename M::mapped_type::value_type& out)
+bool local_wait_pop(LocalGroup* g, M& map, const typename M::key_type& key, typename M::mapped_type::value_type& out, double deadline_s)
 {
     std::unique_lock<std::mutex> lock(g->m);
     auto& queue = map[key];
-    const bool ok = g->cv.wait_for(lock, std::chrono::seconds(LOCAL_TIMEOUT_S), [&] { return g->failed || !queue.empty(); });
+    const auto ready = [&] { return g->failed || !queue.empty(); };
+    bool ok = true;
+    if (deadline_s > 0.)
+        ok = g->cv.wait_for(lock, std::chrono::duration<double>(deadline_s), ready);
+    else
+        g->cv.wait(lock, ready);
     if (!ok || g->failed) {
         g->failed = true;
         g->cv.notify_all();
@@ -151,6 +158,7 @@ struct nsdg_comm {
     LocalGroup* local = nullptr; // local transport
     hipStream_t stream = nullptr; // communication stream
     int nplans = 0; // plans created so far (their indices match across the ranks of a group)
+    bool broken = false; // a wait ran into the deadline: the streams may never drain, abort instead of draining
 };
 
 // ---------------------------------------------------------------------------------------------- plans
@@ -180,6 +188,14 @@ struct nsdg_halo {
     hipEvent_t ev_ack[2] = { nullptr, nullptr }; // local transport: "I have copied your buffer" for from-above / from-below
     bool local_sent[2] = { false, false }; // an acknowledgement is outstanding for up / down
     bool started = false;
+    // exchange timing (nsdg_halo_stats_get): a ring of event pairs on the communication stream -- the host runs many
+    // exchanges ahead of the device, so a pair is read when the ring comes round to it again (or at the query)
+    static constexpr int RING = 32;
+    hipEvent_t t0[RING] = {}, t1[RING] = {};
+    bool pending[RING] = {};
+    int slot = 0;
+    long n_timed = 0, n_untimed = 0;
+    double ms_total = 0.;
 };
 
 namespace {
@@ -234,11 +250,26 @@ __global__ void halo_delay_kernel(long ticks)
 }
 long halo_delay_ticks()
 {
-    static const long ticks = [] {
-        const char* v = std::getenv("NSDG_HALO_DELAY_US");
-        return (v && *v) ? 100L * std::atol(v) : 0L;
-    }();
-    return ticks;
+    const char* v = std::getenv("NSDG_HALO_DELAY_US"); // read at every exchange: tests switch it on and off
+    return (v && *v) ? 100L * std::atol(v) : 0L;
+}
+
+// adds the time of the exchange recorded in ring slot k to the plan's totals; wait: block until it has finished
+void harvest_slot(nsdg_halo* p, int k, bool wait)
+{
+    if (!p->pending[k])
+        return;
+    if (wait)
+        (void)hipEventSynchronize(p->t1[k]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p->t0[k], p->t1[k]) == hipSuccess) {
+        p->ms_total += ms;
+        ++p->n_timed;
+    } else {
+        (void)hipGetLastError(); // not ready: give the slot up
+        ++p->n_untimed;
+    }
+    p->pending[k] = false;
 }
 
 int launch_copy(bool pack, const SegTable& T, long longest, double* buf0, double* buf1, hipStream_t stream)
@@ -362,9 +393,14 @@ int nsdg_comm_finalize(nsdg_ctx* ctx)
     if (!c)
         return NSDG_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(c->stream);
-    if (c->nccl)
-        (void)g_rccl.CommDestroy(c->nccl);
+    if (!c->broken)
+        (void)hipStreamSynchronize(c->stream);
+    if (c->nccl) {
+        if (c->broken)
+            (void)g_rccl.CommAbort(c->nccl); // ends the transfers a dead neighbour never answers
+        else
+            (void)g_rccl.CommDestroy(c->nccl);
+    }
     if (c->local) {
         std::lock_guard<std::mutex> lock(g_groups_mutex);
         if (--c->local->refs == 0) {
@@ -429,6 +465,8 @@ int nsdg_halo_plan_create(nsdg_ctx* ctx, int32_t rank_below, int32_t rank_above,
         && alloc(&p->b_above, p->n_above) == hipSuccess && alloc(&p->b_below, p->n_below) == hipSuccess;
     for (hipEvent_t* e : { &p->ev_ready, &p->ev_packed, &p->ev_arrived, &p->ev_done, &p->ev_ack[0], &p->ev_ack[1] })
         ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < nsdg_halo::RING; ++k)
+        ok = ok && hipEventCreate(&p->t0[k]) == hipSuccess && hipEventCreate(&p->t1[k]) == hipSuccess;
     if (!ok) {
         nsdg_halo_plan_destroy(p);
         nsdg_set_error("nsdg_halo_plan_create: device allocation failed");
@@ -443,8 +481,20 @@ int nsdg_halo_plan_destroy(nsdg_halo* p)
     if (!p)
         return NSDG_OK;
     (void)hipSetDevice(p->ctx->device);
+    if (p->ctx->comm && p->ctx->comm->broken) {
+        // the communication stream may never drain: hipFree would wait for it.  The buffers and events are left to the
+        // process exit that follows a broken communicator.
+        delete p;
+        return NSDG_OK;
+    }
     if (p->ctx->comm)
         (void)hipStreamSynchronize(p->ctx->comm->stream);
+    for (int k = 0; k < nsdg_halo::RING; ++k) {
+        if (p->t0[k])
+            (void)hipEventDestroy(p->t0[k]);
+        if (p->t1[k])
+            (void)hipEventDestroy(p->t1[k]);
+    }
     for (double* b : { p->b_up, p->b_down, p->b_above, p->b_below })
         if (b)
             (void)hipFree(b);
@@ -479,14 +529,16 @@ int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* p)
     // the exchange sees everything the compute stream has been given so far
     NSDG_CHECK_HIP(hipEventRecord(p->ev_ready, ctx->stream));
     NSDG_CHECK_HIP(hipStreamWaitEvent(c->stream, p->ev_ready, 0));
+    harvest_slot(p, p->slot, true); // the ring has come round (32 exchanges ago: long finished)
+    NSDG_CHECK_HIP(hipEventRecord(p->t0[p->slot], c->stream)); // "the data to send is ready"
     if (c->local && !p->loopback) {
         // the neighbours must have copied the previous contents of the send buffers out
         const int peers[2] = { p->above, p->below };
         for (int d = 0; d < 2; ++d)
             if (p->local_sent[d]) {
                 hipEvent_t ack;
-                if (!local_wait_pop(c->local, c->local->ack, std::make_tuple(c->rank, peers[d], p->index), ack)) {
-                    nsdg_set_error("nsdg_halo_start: a rank of the local group failed or timed out");
+                if (!local_wait_pop(c->local, c->local->ack, std::make_tuple(c->rank, peers[d], p->index), ack, ctx->comm_deadline_s)) {
+                    nsdg_set_error("nsdg_halo_start: a rank of the local group failed or did not answer within %g s", ctx->comm_deadline_s);
                     return NSDG_ERR_COMM;
                 }
                 NSDG_CHECK_HIP(hipStreamWaitEvent(c->stream, ack, 0));
@@ -564,8 +616,8 @@ int nsdg_halo_finish(nsdg_ctx* ctx, nsdg_halo* p)
             if (!counts[d])
                 continue;
             LocalMsg msg;
-            if (!local_wait_pop(g, g->box, std::make_tuple(peers[d], c->rank, p->index), msg)) {
-                nsdg_set_error("nsdg_halo_finish: a rank of the local group failed or timed out");
+            if (!local_wait_pop(g, g->box, std::make_tuple(peers[d], c->rank, p->index), msg, ctx->comm_deadline_s)) {
+                nsdg_set_error("nsdg_halo_finish: a rank of the local group failed or did not answer within %g s", ctx->comm_deadline_s);
                 return NSDG_ERR_COMM;
             }
             if (msg.count != counts[d]) {
@@ -588,7 +640,86 @@ int nsdg_halo_finish(nsdg_ctx* ctx, nsdg_halo* p)
         return rc;
     NSDG_CHECK_HIP(hipEventRecord(p->ev_done, c->stream));
     NSDG_CHECK_HIP(hipStreamWaitEvent(ctx->stream, p->ev_done, 0));
+    NSDG_CHECK_HIP(hipEventRecord(p->t1[p->slot], c->stream)); // "the ghost rows are written"
+    p->pending[p->slot] = true;
+    p->slot = (p->slot + 1) % nsdg_halo::RING;
+    return NSDG_OK;
+}
+
+int nsdg_halo_stats_get(nsdg_ctx* ctx, nsdg_halo* p, nsdg_halo_stats* out, int32_t reset)
+{
+    NSDG_CHECK_ARG(ctx && p && p->ctx == ctx && out, "plan does not belong to this context");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!(ctx->comm && ctx->comm->broken))
+        for (int k = 0; k < nsdg_halo::RING; ++k)
+            harvest_slot(p, k, true);
+    out->exchanges = p->n_timed + p->n_untimed;
+    out->untimed = p->n_untimed;
+    out->ms = p->ms_total;
+    out->bytes_sent = (p->n_up + p->n_down) * (int64_t)sizeof(double);
+    out->bytes_received = (p->n_above + p->n_below) * (int64_t)sizeof(double);
+    if (reset) {
+        p->n_timed = p->n_untimed = 0;
+        p->ms_total = 0.;
+    }
+    return NSDG_OK;
+}
+
+int nsdg_comm_deadline_set(nsdg_ctx* ctx, double seconds)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(seconds >= 0., "the deadline must be >= 0 (0 = wait for ever)");
+    ctx->comm_deadline_s = seconds;
     return NSDG_OK;
 }
 
 } // extern "C"
+
+// Drains the context's compute and communication streams, but not for longer than the communicator's deadline: with a
+// neighbour rank gone, an ncclRecv (or a kernel ordered behind it) never completes and a plain hipStreamSynchronize
+// would block this rank for ever.  On expiry the communicator is marked broken and NSDG_ERR_COMM is returned.
+int nsdg_comm_bounded_drain(nsdg_ctx* ctx)
+{
+    nsdg_comm* c = ctx->comm;
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (c->broken) {
+        nsdg_set_error("nsdg_ctx_synchronize: the communicator is broken (an earlier wait ran into the deadline)");
+        return NSDG_ERR_COMM;
+    }
+    if (ctx->comm_deadline_s <= 0.) {
+        NSDG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        NSDG_CHECK_HIP(hipStreamSynchronize(c->stream));
+        return NSDG_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t streams[2] = { ctx->stream, c->stream };
+    for (hipStream_t st : streams) {
+        for (long spins = 0;; ++spins) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess)
+                break;
+            if (e != hipErrorNotReady) {
+                nsdg_set_error("nsdg_ctx_synchronize: hipStreamQuery failed: %s", hipGetErrorString(e));
+                return NSDG_ERR_HIP;
+            }
+            (void)hipGetLastError();
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (waited > ctx->comm_deadline_s) {
+                c->broken = true;
+                if (c->local) {
+                    std::lock_guard<std::mutex> lock(c->local->m);
+                    c->local->failed = true;
+                    c->local->cv.notify_all();
+                }
+                nsdg_set_error("nsdg_ctx_synchronize: the streams of rank %d did not drain within %g s -- a neighbour rank has probably died; "
+                               "the communicator is broken, leave the process without synchronising the device",
+                    c->rank, ctx->comm_deadline_s);
+                return NSDG_ERR_COMM;
+            }
+            // short waits spin (a step is a few ms), long ones sleep
+            if (spins > 2000)
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    return NSDG_OK;
+}

@@ -1,4 +1,7 @@
 // nsdg_ctx.hip -- context, parameters and error reporting of libnsdg.so.
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "nsdg_internal.h"
@@ -90,6 +93,12 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     c->d_ptrs = nullptr;
     c->comm = nullptr;
     c->comm_group = 0;
+    {
+        const char* v = std::getenv("NSDG_COMM_TIMEOUT_S");
+        c->comm_deadline_s = (v && *v) ? std::atof(v) : 300.;
+        if (!(c->comm_deadline_s >= 0.))
+            c->comm_deadline_s = 300.;
+    }
     *out = c;
     return NSDG_OK;
 }
@@ -106,7 +115,36 @@ int nsdg_ctx_destroy(nsdg_ctx* ctx)
 int nsdg_ctx_synchronize(nsdg_ctx* ctx)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    if (ctx->comm) // a dead neighbour must not block this rank for ever
+        return nsdg_comm_bounded_drain(ctx);
     NSDG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return NSDG_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void copy16_kernel(double2* __restrict__ dst, const double2* __restrict__ src, long n2)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride)
+        dst[i] = src[i];
+}
+} // namespace
+
+int nsdg_copy_f64(nsdg_ctx* ctx, double* dst, const double* src, int64_t n)
+{
+    NSDG_CHECK_ARG(ctx && dst && src && n >= 0, "null pointer or negative count");
+    NSDG_CHECK_ARG(((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0, "dst and src must be 16-byte aligned");
+    NSDG_CHECK_ARG(dst + n <= src || src + n <= dst, "dst and src must not overlap");
+    if (n == 0)
+        return NSDG_OK;
+    const long n2 = n >> 1;
+    // a few resident workgroups per CU, each lane streaming 16-byte accesses with a grid stride
+    const int blocks = (int)std::min<long>(std::max<long>((n2 + 255) / 256, 1), 16L * ctx->num_cus);
+    if (n2)
+        hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(dst), reinterpret_cast<const double2*>(src), n2);
+    if (n & 1)
+        NSDG_CHECK_HIP(hipMemcpyAsync(dst + n - 1, src + n - 1, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }
 

@@ -27,9 +27,11 @@ struct nsdg_ctx {
     double** d_ptrs;
     nsdg_comm* comm; // row-block communicator (halo.hip), null until nsdg_comm_init*
     int64_t comm_group; // id of the local group the communicator belongs to
+    double comm_deadline_s; // upper bound on any wait for a neighbour (0 = for ever)
 };
 
 void nsdg_set_error(const char* fmt, ...);
+int nsdg_comm_bounded_drain(nsdg_ctx* ctx); // halo.hip: drain the context's streams within the communicator's deadline
 
 #define NSDG_CHECK_ARG(cond, msg)                                        \
     do {                                                                 \

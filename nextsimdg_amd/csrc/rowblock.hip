@@ -15,7 +15,9 @@
 //   What is left of nsub runs as a two-iteration pass and / or single sub-iterations (exchange after each).
 //   Transport: with >= 3 ghost rows per side the first two RK stages also advance 2 / 1 ghost rows and the
 //   advected fields are exchanged once per step; otherwise after every stage.
+#include <algorithm>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -355,6 +357,29 @@ int nsdg_rb_mevp_info(const nsdg_rb_mevp* p, int32_t* per_pass, int32_t* group_p
     return NSDG_OK;
 }
 
+static int sum_stats(nsdg_ctx* ctx, std::initializer_list<nsdg_halo*> plans, nsdg_halo_stats* out, int32_t reset)
+{
+    std::memset(out, 0, sizeof *out);
+    for (nsdg_halo* h : plans) {
+        if (!h)
+            continue;
+        nsdg_halo_stats one;
+        const int rc = nsdg_halo_stats_get(ctx, h, &one, reset);
+        if (rc != NSDG_OK)
+            return rc;
+        out->exchanges += one.exchanges, out->untimed += one.untimed, out->ms += one.ms;
+        out->bytes_sent = std::max(out->bytes_sent, one.bytes_sent);
+        out->bytes_received = std::max(out->bytes_received, one.bytes_received);
+    }
+    return NSDG_OK;
+}
+
+int nsdg_rb_mevp_stats(nsdg_ctx* ctx, nsdg_rb_mevp* p, nsdg_halo_stats* out, int32_t reset)
+{
+    NSDG_CHECK_ARG(ctx && p && p->ctx == ctx && out, "plan does not belong to this context");
+    return sum_stats(ctx, { p->rows_plan[0], p->rows_plan[1], p->node_plan[0], p->node_plan[1] }, out, reset);
+}
+
 int nsdg_rb_mevp_run(nsdg_ctx* ctx, nsdg_rb_mevp* p, int32_t parity, int32_t* parity_out)
 {
     NSDG_CHECK_ARG(ctx && p && p->ctx == ctx && parity_out, "plan does not belong to this context");
@@ -526,6 +551,12 @@ int nsdg_rb_transport_destroy(nsdg_rb_transport* p)
     nsdg_halo_plan_destroy(p->t2_plan);
     delete p;
     return NSDG_OK;
+}
+
+int nsdg_rb_transport_stats(nsdg_ctx* ctx, nsdg_rb_transport* p, nsdg_halo_stats* out, int32_t reset)
+{
+    NSDG_CHECK_ARG(ctx && p && p->ctx == ctx && out, "plan does not belong to this context");
+    return sum_stats(ctx, { p->new_plan[0], p->new_plan[1], p->t2_plan }, out, reset);
 }
 
 int nsdg_rb_transport_run(nsdg_ctx* ctx, nsdg_rb_transport* p, double dt, int32_t parity, int32_t* parity_out)

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <sstream>
@@ -20,8 +22,17 @@
 namespace Nextsim {
 
 namespace {
+bool g_multiProcess = false; // one row block per process, ghost rows over RCCL
 void check(int rc, const char* what)
 {
+    if (rc == NSDG_ERR_COMM && g_multiProcess) {
+        // a neighbour rank has died (the bounded wait of nsdg_ctx_synchronize ran out): the device streams of this rank may
+        // never drain, so no destructor may run (hipFree synchronises the device) -- leave at once with a non-zero
+        // status; the launcher ends the remaining ranks
+        std::fprintf(stderr, "nextsim_amd rank: %s: %s\n", what, nsdg_last_error());
+        std::fflush(stderr);
+        std::_Exit(3);
+    }
     if (rc != NSDG_OK)
         throw std::runtime_error(std::string(what) + ": " + nsdg_last_error());
 }
@@ -127,6 +138,7 @@ void DynamicsStep::init()
     configure();
     const RankEnvironment env = RankEnvironment::fromEnv();
     m_world = env.world, m_rank = env.rank;
+    g_multiProcess = m_world > 1;
     if (m_world > 1 && (rowBlocks > 1 || loopbackWorld))
         throw std::invalid_argument("a multi-process run (WORLD_SIZE > 1) owns one row block per process: leave dynamics.row_blocks / loopback_world unset");
     if (rowBlocks > 1 && loopbackWorld)

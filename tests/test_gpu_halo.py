@@ -336,3 +336,92 @@ def test_transport_plan_of_an_interior_block_with_four_fields(gpu, nfields):
         assert torch.equal(t1[f][:, ny - da:], t1[f][:, db:db + da]), f
     del tr
     c.close()
+
+
+def test_a_rank_that_exits_early_does_not_block_its_neighbours(gpu):
+    """three thread-ranks on the in-process transport with the native row-block driver; rank 1 leaves after its first
+    model step (as a process that died would).  Its neighbours must not wait for ever: within the communicator's
+    deadline (2 s here) their next exchange reports NSDG_ERR_COMM, and so does every later call on the broken group."""
+    import threading
+    import time
+
+    from nextsimdg_amd import rowblock
+    from thread_ranks import fields
+
+    nx, ny, nsub, world, group_id = 100, 96, 6, 3, 4242
+    data = fields(nx, ny)
+    bt = data[0]
+    out, t_fail = {}, {}
+    barrier = threading.Barrier(world)
+
+    def rank_main(rank):
+        try:
+            c = abi.Context(torch.device("cuda:0"))
+            c.set_mevp_params(c.mevp_default_params(alpha=300.0, beta=300.0))
+            blk = rowblock.RowBlock(nx, ny, rank, world, 3, 2)
+            ex = rowblock.NativeHaloExchanger(c, blk, local_group=group_id)
+            c.comm_deadline(2.0)
+            core = rowblock.DynamicsCore(c, blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cuda"), exchanger=ex, native=True)
+            core.load_global(*data[1:])
+            core.step()
+            c.synchronize()
+            barrier.wait(timeout=60)  # everybody has finished step 1
+            if rank == 1:
+                out[rank] = "left"
+                return  # "dies": never posts another exchange
+            t0 = time.perf_counter()
+            try:
+                for _ in range(3):
+                    core.step()
+                c.synchronize()
+                out[rank] = "no error"
+            except abi.NsdgError as e:
+                t_fail[rank] = time.perf_counter() - t0
+                out[rank] = str(e)
+        except BaseException as e:  # noqa: BLE001
+            out[rank] = e
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a rank is still blocked"
+    assert out[1] == "left"
+    for r in (0, 2):
+        assert isinstance(out[r], str) and ("did not answer within" in out[r] or "failed" in out[r]), out[r]
+        assert t_fail[r] < 30.0, t_fail
+
+
+def test_bounded_drain_reports_a_stalled_communication_stream(ctx, monkeypatch):
+    """nsdg_ctx_synchronize on a context with a communicator polls the streams against the deadline instead of blocking:
+    with the communication stream held up (the rehearsal aid NSDG_HALO_DELAY_US spins for 3 s where a transfer would be --
+    the stand-in for an ncclRecv whose sender has died; it ends by itself, nothing is left hanging) and a 0.5 s deadline the
+    call returns NSDG_ERR_COMM in time, the communicator is marked broken, and finalising it does not wait either"""
+    import time
+
+    ctx.comm_init_local(93, 0, 1)
+    x = rnd(4096, seed=9)
+    plan = ctx.halo_plan(0, 0, [x[0:1024]], [], [], [x[2048:3072]])
+    plan.start()
+    plan.finish()
+    ctx.synchronize()  # a healthy exchange drains at once
+    assert torch.equal(x[2048:3072], x[0:1024])
+    assert plan.stats()["exchanges"] == 1 and plan.stats()["ms"] > 0
+    ctx.comm_deadline(0.5)
+    monkeypatch.setenv("NSDG_HALO_DELAY_US", "3000000")
+    plan.start()
+    plan.finish()
+    monkeypatch.delenv("NSDG_HALO_DELAY_US")
+    t0 = time.perf_counter()
+    with pytest.raises(abi.NsdgError, match="did not drain within 0.5 s"):
+        ctx.synchronize()
+    waited = time.perf_counter() - t0
+    assert 0.4 < waited < 2.0, waited
+    with pytest.raises(abi.NsdgError, match="broken"):
+        ctx.synchronize()
+    t0 = time.perf_counter()
+    plan.close()
+    ctx.comm_finalize()  # does not drain a broken communicator
+    assert time.perf_counter() - t0 < 1.0
+    torch.cuda.synchronize()  # the stand-in ends by itself: the device is clean for the next test
