@@ -408,7 +408,8 @@ int nsdg_comm_finalize(nsdg_ctx* ctx)
             delete c->local;
         }
     }
-    (void)hipStreamDestroy(c->stream);
+    if (!c->broken) // hipStreamDestroy waits for the stream's work: a broken communicator's stream is left to the process exit
+        (void)hipStreamDestroy(c->stream);
     delete c;
     ctx->comm = nullptr;
     return NSDG_OK;

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(NodalConsts K, int n
         return;
     const int ntx = tiles_per_row(nx);
     const int nn = 2 * nx + 1;
+    const long nplane = nodal_plane((long)nn * (2 * ny + 1));
     const double iarea = 1. / (hx * hy);
     double s11[8], s12[8], s22[8];
     double cx, cy;
@@ -107,24 +108,24 @@ __global__ __launch_bounds__(256) void mevp_velocity_kernel(NodalConsts K, int n
     double un, vn, c[6];
     // inverse lumped masses: 4, 2, 2, 1 adjacent elements times LUMP = 1/36, 1/9, 1/9, 4/9 of the cell area
     if (hasL && hasB) { // vertex
-        load_nodal(packed, nV, c);
+        load_nodal(packed, nplane, nV, c);
         node_update_packed(K, c, u_old[nV], v_old[nV], vx_, vy_, 9. * iarea, un, vn);
     } else
         un = vn = 0.;
     u_new[nV] = un, v_new[nV] = vn;
     if (hasB) { // bottom edge-mid
-        load_nodal(packed, nV + 1, c);
+        load_nodal(packed, nplane, nV + 1, c);
         node_update_packed(K, c, u_old[nV + 1], v_old[nV + 1], exx, exy, 4.5 * iarea, un, vn);
     } else
         un = vn = 0.;
     u_new[nV + 1] = un, v_new[nV + 1] = vn;
     if (hasL) { // left edge-mid
-        load_nodal(packed, nV + nn, c);
+        load_nodal(packed, nplane, nV + nn, c);
         node_update_packed(K, c, u_old[nV + nn], v_old[nV + nn], eyx, eyy, 4.5 * iarea, un, vn);
     } else
         un = vn = 0.;
     u_new[nV + nn] = un, v_new[nV + nn] = vn;
-    load_nodal(packed, nV + nn + 1, c); // centre
+    load_nodal(packed, nplane, nV + nn + 1, c); // centre
     node_update_packed(K, c, u_old[nV + nn + 1], v_old[nV + nn + 1], ccx, ccy, 2.25 * iarea, un, vn);
     u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
     // right column / top row of the local lattice are boundary nodes (v = 0)
@@ -178,16 +179,14 @@ __device__ __forceinline__ double node_average(int nx, int ny, int nc, const dou
 
 // per-step momentum coefficients of one node, 6 doubles (layout: mevp_common.h)
 __device__ __forceinline__ void pack_node(const nsdg_mevp_params& P, double dt, double u0, double v0, double tax, double tay,
-    double uoc, double voc, double cgh, double cga, double* __restrict__ dst)
+    double uoc, double voc, double cgh, double cga, double* __restrict__ packed, long plane, long n)
 {
     const double h = fmax(cgh, P.h_min);
     const double a = fmin(fmax(cga, 0.), 1.);
     const double mdt = P.rho_ice * h / dt;
     const double cor = P.rho_ice * h * P.fc;
-    double2* out = reinterpret_cast<double2*>(dst);
-    out[0] = make_double2(h, a * (P.c_ocean * P.rho_ocean));
-    out[1] = make_double2(mdt * u0 + a * tax - cor * voc, mdt * v0 + a * tay + cor * uoc);
-    out[2] = make_double2(uoc, voc);
+    const double c[6] = { h, a * (P.c_ocean * P.rho_ocean), mdt * u0 + a * tax - cor * voc, mdt * v0 + a * tay + cor * uoc, uoc, voc };
+    store_nodal(packed, plane, n, c);
 }
 
 __device__ __forceinline__ void wind_tau(double f_atm, double ua, double va, double& tax, double& tay)
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(256) void mevp_pack_nodal_kernel(nsdg_mevp_params P
     const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nnodes)
         return;
-    pack_node(P, dt, u0[n], v0[n], tax[n], tay[n], uo[n], vo[n], cgh[n], cga[n], packed + n * NODAL_STRIDE);
+    pack_node(P, dt, u0[n], v0[n], tax[n], tay[n], uo[n], vo[n], cgh[n], cga[n], packed, nodal_plane(nnodes), n);
 }
 
 // node_average() on a tile of DG coefficients staged in LDS: tile[c][iy - ey0][ix - ex0]; same loops, same order of
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(256) void mevp_prepare_kernel(nsdg_mevp_params P, i
     const double cgh = node_average_tile(nx, ny, tile[0], ex0, ey0, gx, gy), cga = node_average_tile(nx, ny, tile[1], ex0, ey0, gx, gy);
     double tax, tay;
     wind_tau(P.c_atm * P.rho_atm, ua[n], va[n], tax, tay);
-    pack_node(P, dt, u0[n], v0[n], tax, tay, uo[n], vo[n], cgh, cga, packed + n * NODAL_STRIDE);
+    pack_node(P, dt, u0[n], v0[n], tax, tay, uo[n], vo[n], cgh, cga, packed, nodal_plane((long)nn * nm), n);
 }
 
 // one lane per CG2 node

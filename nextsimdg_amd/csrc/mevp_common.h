@@ -408,7 +408,7 @@ __device__ __forceinline__ void node_contrib(const double (&s11)[8], const doubl
 }
 
 // Per-step coefficients of the momentum update, packed once per time step by
-// mevp_pack_nodal_kernel as 6 consecutive doubles per CG2 node (read with three 16-byte loads).
+// mevp_pack_nodal_kernel / mevp_prepare_kernel as 6 doubles per CG2 node, read with three 16-byte loads.
 // With h' = max(cgH,h_min), m = rho_ice*h', a = clamp(cgA,0,1), cor = m*f_c:
 //   [0] h'                                      [3] c3 = (m/dt)*v0 + a*tau_y + cor*u_ocean
 //   [1] cd = a * C_o * rho_o                    [4] u_ocean
@@ -417,7 +417,21 @@ __device__ __forceinline__ void node_contrib(const double (&s11)[8], const doubl
 // the update of DESIGN.md section 3.2 reads
 //   drag = cd*|v_o - v|;  u' = (K1 h' u + c2 + drag*u_o + K3 h' v + div_x/M) / (K2 h' + drag)
 //                         v' = (K1 h' v + c3 + drag*v_o - K3 h' u + div_y/M) / (K2 h' + drag)
+// Layout (round 3): three PAIR PLANES -- pair k = (c[2k], c[2k+1]) of node n at packed[k * 2 NN + 2 n], NN = number
+// of nodes of the local array -- instead of six consecutive doubles per node.  A lane of the marching kernels reads the
+// nodes 2 ix and 2 ix + 1 of a node row: with the planes its 16-byte accesses have a lane stride of 32 bytes (a
+// wave-instruction touches 16 lines of 128 bytes, each of them completely used by the two instructions of the row),
+// with the node-major layout 96 bytes (48 lines per instruction, a sixth of each used): 86 against 74 cycles per
+// instruction in profiles/r01_vmem_issue_microbench.txt.  The packers write perfectly coalesced 16-byte stores.
+// -DNSDG_NODAL_AOS restores the node-major layout (A/B builds).
+#ifdef NSDG_NODAL_AOS
 constexpr int NODAL_STRIDE = 6;
+__host__ __device__ __forceinline__ long nodal_plane(long nnodes) { return 2; } // pair k at + 2 k
+__host__ __device__ __forceinline__ long nodal_node(long n) { return n * NODAL_STRIDE; }
+#else
+__host__ __device__ __forceinline__ long nodal_plane(long nnodes) { return 2 * nnodes; } // doubles between two pair planes
+__host__ __device__ __forceinline__ long nodal_node(long n) { return 2 * n; }
+#endif
 
 struct NodalConsts {
     double k1, k2, k3;
@@ -434,15 +448,24 @@ __device__ __forceinline__ void node_update_packed(const NodalConsts& K, const d
     vn = denom * (c1 * vv + c[3] + drag * c[5] - cor * uu + divy * ilumped);
 }
 
-__device__ __forceinline__ void load_nodal(const double* __restrict__ packed, long n, double (&c)[6])
+// plane = nodal_plane(number of nodes of the local array)
+__device__ __forceinline__ void load_nodal(const double* __restrict__ packed, long plane, long n, double (&c)[6])
 {
-    const double2* p = reinterpret_cast<const double2*>(packed + n * NODAL_STRIDE);
+    const double* p = packed + nodal_node(n);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double2 t = p[k];
+        const double2 t = *reinterpret_cast<const double2*>(p + k * plane);
         c[2 * k] = t.x;
         c[2 * k + 1] = t.y;
     }
+}
+
+__device__ __forceinline__ void store_nodal(double* __restrict__ packed, long plane, long n, const double (&c)[6])
+{
+    double* p = packed + nodal_node(n);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        *reinterpret_cast<double2*>(p + k * plane) = make_double2(c[2 * k], c[2 * k + 1]);
 }
 
 } // namespace nsdg_mevp_detail

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
     const bool hasL = ix > 0;
     const int ntx = tiles_per_row(nx);
     const int nn = 2 * nx + 1;
+    const long nplane = nodal_plane((long)nn * (2 * ny + 1));
     const double ihx = 1. / hx, ihy = 1. / hy, iarea = ihx * ihy;
 
     // contributions of the row below to its top-row nodes: b6 (top-left), b7 (top-mid) of my column and
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
             double un, vn, c[6];
             // vertex: below-left + below + left + own (the oracle's summation order)
             if (hasL && hasB) {
-                load_nodal(packed, nV, c);
+                load_nodal(packed, nplane, nV, c);
                 node_update_packed(K, c, ul[0], vl[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea, un, vn);
             } else
                 un = vn = 0.;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
                 u_new[nV] = un, v_new[nV] = vn;
             // bottom edge-mid: below + own
             if (hasB) {
-                load_nodal(packed, nV + 1, c);
+                load_nodal(packed, nplane, nV + 1, c);
                 node_update_packed(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, un, vn);
             } else
                 un = vn = 0.;
@@ -125,14 +126,14 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
                 u_new[nV + 1] = un, v_new[nV + 1] = vn;
             // left edge-mid: left + own
             if (hasL) {
-                load_nodal(packed, nV + nn, c);
+                load_nodal(packed, nplane, nV + nn, c);
                 node_update_packed(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, un, vn);
             } else
                 un = vn = 0.;
             if (own)
                 u_new[nV + nn] = un, v_new[nV + nn] = vn;
             // centre: own
-            load_nodal(packed, nV + nn + 1, c);
+            load_nodal(packed, nplane, nV + nn + 1, c);
             node_update_packed(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, un, vn);
             if (own) {
                 u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;

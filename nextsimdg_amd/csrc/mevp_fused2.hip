@@ -53,6 +53,7 @@ struct RowCarry {
 struct MarchConst {
     NodalConsts K;
     int nx, ny, y0, y1, tbeg, tend, ix, ntx, nn;
+    long nplane; // doubles between two pair planes of the packed nodal coefficients
     bool own, hasL, lastcol;
     double hx, hy, ihx, ihy, iarea, ialpha, dmin2;
 };
@@ -84,10 +85,10 @@ __device__ __forceinline__ void march_step(const MarchConst& M, int t, RowCarry&
         tile_load8(S.i11, ts, cur.s11);
         tile_load8(S.i12, ts, cur.s12);
         tile_load8(S.i22, ts, cur.s22);
-        load_nodal(packed, nV, cur.c[0]);
-        load_nodal(packed, nV + 1, cur.c[1]);
-        load_nodal(packed, nV + nn, cur.c[2]);
-        load_nodal(packed, nV + nn + 1, cur.c[3]);
+        load_nodal(packed, M.nplane, nV, cur.c[0]);
+        load_nodal(packed, M.nplane, nV + 1, cur.c[1]);
+        load_nodal(packed, M.nplane, nV + nn, cur.c[2]);
+        load_nodal(packed, M.nplane, nV + nn + 1, cur.c[3]);
         NSDG_STAMP(1);
         stress_update(ul, vl, cur.P, M.ihx, M.ihy, M.ialpha, M.dmin2, cur.s11, cur.s12, cur.s22);
         NSDG_STAMP(2);
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void mevp_fused2_kernel(NodalConsts K, int nx,
     M.hasL = M.ix > 0, M.lastcol = M.ix == nx - 1;
     M.ntx = tiles_per_row(nx);
     M.nn = 2 * nx + 1;
+    M.nplane = nodal_plane((long)M.nn * (2 * ny + 1));
     M.hx = hx, M.hy = hy, M.ihx = 1. / hx, M.ihy = 1. / hy, M.iarea = M.ihx * M.ihy;
     M.ialpha = ialpha, M.dmin2 = dmin2;
     M.tbeg = max(M.y0 - 2, 0), M.tend = min(M.y1, ny - 1); // A runs on rows tbeg .. tend

@@ -44,6 +44,7 @@ struct RowCarry3 {
 struct MarchConst3 {
     NodalConsts K;
     int nx, ny, y0, y1, tbeg, tendA, tendB, ix, ntx, nn, lane;
+    long nplane; // doubles between two pair planes of the packed nodal coefficients
     bool own, hasL, lastcol;
     double hx, hy, ihx, ihy, iarea, ialpha, dmin2;
 };
@@ -108,21 +109,35 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         const long ts = tile_off(ix, t, M.ntx, 8), tp = tile_off(ix, t, M.ntx, 9);
         const long nV = (long)(2 * t) * nn + 2 * ix;
         double ul[9], vl[9];
+#ifdef NSDG_EXP_UVPAIR
+        // TIMING-ONLY experiment (wrong values; tools/ab_build.sh uvpair -DNSDG_EXP_UVPAIR, bench.py --no-guard with
+        // NSDG_EXP_UVPAIR=1 so that [u | v] is one allocation): what a (u, v)-interleaved nodal lattice would cost --
+        // the 18 strided 8-byte loads of A become 6 16-byte loads and three DPP columns, the 8 stores of C become 4
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double2 a = *reinterpret_cast<const double2*>(u_old + 2 * (nV + r * nn));
+            const double2 b = *reinterpret_cast<const double2*>(u_old + 2 * (nV + r * nn + 1));
+            ul[3 * r] = a.x, vl[3 * r] = a.y, ul[3 * r + 1] = b.x, vl[3 * r + 1] = b.y;
+            const double cu = lane_from_right(a.x), cv = lane_from_right(a.y);
+            ul[3 * r + 2] = M.lastcol ? 0. : cu, vl[3 * r + 2] = M.lastcol ? 0. : cv;
+        }
+#else
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
             const long n = nV + (a / 3) * nn + a % 3;
             ul[a] = u_old[n];
             vl[a] = v_old[n];
         }
+#endif
         double PA[9];
         tile_load9(pg, tp, ix & 63, PA);
         tile_load8(S.i11, ts, cur.s11);
         tile_load8(S.i12, ts, cur.s12);
         tile_load8(S.i22, ts, cur.s22);
-        load_nodal(packed, nV, cur.c[0]);
-        load_nodal(packed, nV + 1, cur.c[1]);
-        load_nodal(packed, nV + nn, cur.c[2]);
-        load_nodal(packed, nV + nn + 1, cur.c[3]);
+        load_nodal(packed, M.nplane, nV, cur.c[0]);
+        load_nodal(packed, M.nplane, nV + 1, cur.c[1]);
+        load_nodal(packed, M.nplane, nV + nn, cur.c[2]);
+        load_nodal(packed, M.nplane, nV + nn + 1, cur.c[3]);
         NSDG_STAMP(1);
         stress_update(ul, vl, PA, M.ihx, M.ihy, M.ialpha, M.dmin2, cur.s11, cur.s12, cur.s22);
         NSDG_STAMP(2);
@@ -193,10 +208,10 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         const long nV = (long)(2 * q) * nn + 2 * ix;
         double P[9], c[4][6];
         tile_load9(pg, tp, ix & 63, P);
-        load_nodal(packed, nV, c[0]);
-        load_nodal(packed, nV + 1, c[1]);
-        load_nodal(packed, nV + nn, c[2]);
-        load_nodal(packed, nV + nn + 1, c[3]);
+        load_nodal(packed, M.nplane, nV, c[0]);
+        load_nodal(packed, M.nplane, nV + 1, c[1]);
+        load_nodal(packed, M.nplane, nV + nn, c[2]);
+        load_nodal(packed, M.nplane, nV + nn + 1, c[3]);
         double ul[9], vl[9];
         gather_nodes(M, qu, bu[0], bu[1], ul);
         gather_nodes(M, qv, bv[0], bv[1], vl);
@@ -217,10 +232,17 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
             double un[4], vn[4];
             owned_node_updates(M, q > 0, c, qu, qv, cc, cx, cy, un, vn);
             if (store) {
+#ifdef NSDG_EXP_UVPAIR
+                *reinterpret_cast<double2*>(u_new + 2 * nV) = make_double2(un[0], vn[0]);
+                *reinterpret_cast<double2*>(u_new + 2 * (nV + 1)) = make_double2(un[1], vn[1]);
+                *reinterpret_cast<double2*>(u_new + 2 * (nV + nn)) = make_double2(un[2], vn[2]);
+                *reinterpret_cast<double2*>(u_new + 2 * (nV + nn + 1)) = make_double2(un[3], vn[3]);
+#else
                 u_new[nV] = un[0], v_new[nV] = vn[0];
                 u_new[nV + 1] = un[1], v_new[nV + 1] = vn[1];
                 u_new[nV + nn] = un[2], v_new[nV + nn] = vn[2];
                 u_new[nV + nn + 1] = un[3], v_new[nV + nn + 1] = vn[3];
+#endif
                 if (M.lastcol) {
                     u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
                     u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
@@ -259,15 +281,24 @@ __global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, 
     if (M.y0 >= j1)
         return; // wave-uniform
     M.y1 = min(M.y0 + R, j1);
+#ifdef NSDG_EXP_NOHALO
+    const int ixr = cw * 64 + lane; // TIMING-ONLY: no redundant lanes at all (upper bound of what sharing halo columns between waves could gain)
+#else
     const int ixr = cw * 59 - 3 + lane;
+#endif
     const bool valid = ixr >= 0 && ixr < nx;
     M.K = K;
     M.nx = nx, M.ny = ny, M.lane = lane;
+#ifdef NSDG_EXP_NOHALO
+    M.own = valid;
+#else
     M.own = valid && lane >= 3 && lane <= 61;
+#endif
     M.ix = min(max(ixr, 0), nx - 1);
     M.hasL = M.ix > 0, M.lastcol = M.ix == nx - 1;
     M.ntx = tiles_per_row(nx);
     M.nn = 2 * nx + 1;
+    M.nplane = nodal_plane((long)M.nn * (2 * ny + 1));
     M.hx = hx, M.hy = hy, M.ihx = 1. / hx, M.ihy = 1. / hy, M.iarea = M.ihx * M.ihy;
     M.ialpha = ialpha, M.dmin2 = dmin2;
     M.tbeg = max(M.y0 - 3, 0);
@@ -317,7 +348,11 @@ int nsdg_launch_mevp_fused3_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg)
 {
+#ifdef NSDG_EXP_NOHALO
+    const int ncw = nsdg_div_up(ctx->nx, 64);
+#else
     const int ncw = nsdg_div_up(ctx->nx, 59); // 59 owned columns per wave
+#endif
     const int rowsB = j0b < j1b ? j1b - j0b : 0;
     int R = ctx->strip_rows;
     if (R <= 0) {

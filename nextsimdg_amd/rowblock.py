@@ -26,6 +26,8 @@ arrays) is packed into one buffer and sent with one P2P op (HaloExchanger).
 The numerical kernels are reached through an `ops` object with the method names of
 nextsimdg_amd.abi.Context (the C-ABI binding).  Nothing here computes on the host.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -292,7 +294,10 @@ class DynamicsCore:
         self.s = [ops.private_zeros(8, ny, nx, device) for _ in range(3)]
         self.sb = [ops.private_zeros(8, ny, nx, device) for _ in range(3)]
         self.pg = ops.private_zeros(9, ny, nx, device)
-        self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
+        if os.environ.get("NSDG_EXP_UVPAIR"):  # timing experiment only (csrc/mevp_fused3.hip): [u | v] of a buffer in ONE allocation
+            (self.u, self.v), (self.ub, self.vb) = z(2, *nodal).unbind(0), z(2, *nodal).unbind(0)
+        else:
+            self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
         self.ua, self.va = z(*nodal), z(*nodal)
         self.uo, self.vo = z(*nodal), z(*nodal)
         self.packed = z(nodal[0] * nodal[1] * 8)  # per-step momentum coefficients, 8 per node

@@ -330,7 +330,7 @@ def test_transport_plan_of_an_interior_block_with_four_fields(gpu, nfields):
     assert tr(120.0, 0) == 1
     torch.cuda.synchronize()
     for f in range(nfields):
-        assert torch.equal(t1[f][:, db:ny - da], phi[f][:, db:ny - da])
+        assert torch.allclose(t1[f][:, db:ny - da], phi[f][:, db:ny - da], rtol=1e-14, atol=0)  # (1/3) x + (2/3) x: round-off only
         # loopback: the top depth_below owned rows arrive as the ghost rows below, the bottom depth_above as those above
         assert torch.equal(t1[f][:, :db], t1[f][:, ny - da - db:ny - da]), f
         assert torch.equal(t1[f][:, ny - da:], t1[f][:, db:db + da]), f

@@ -153,8 +153,9 @@ def test_column_zero_denominators_follow_the_reference_arithmetic(ctx, dt):
     hi += (newice - hi del_c) / (c + del_c) (NextsimPhysics.cpp:257-260,278), cancels a true thickness h = H / c of
     up to 1e13 m down to O(1), so one ulp of h -- the difference between two correctly-working divisions, or between
     two libm exp -- is up to 1e-3 of the result.  The thickness and snow results are therefore compared to
-    1e-11 |want| + 8 ulp(h_in) c_new (8 ulp(hs_in) c_new for the snow); for c >= 1e-6 that band is below 1e-11 |want|
-    and changes nothing.  The cut-off DECISION (c_new < min_conc, NextsimPhysics.cpp:211) never differs: `cice` must
+    1e-11 |want| + 32 ulp(h_in) c_new (32 ulp(hs_in) c_new for the snow: H_new = hi_new c_new is the difference of two
+    products of size h c_new, each rounded three or four times on either side); for c >= 1e-5 that band is below
+    1e-11 |want| and changes nothing.  The cut-off DECISION (c_new < min_conc, NextsimPhysics.cpp:211) never differs: `cice` must
     agree exactly in being zero or not."""
     n = 4096
     state, forcing, newice = synthetic.column_fields(n, seed=99)
@@ -171,9 +172,9 @@ def test_column_zero_denominators_follow_the_reference_arithmetic(ctx, dt):
     ctx.set_column_params(ctx.column_default_params())
     ds, df, dn = {k: dev(v) for k, v in state.items()}, {k: dev(v) for k, v in forcing.items()}, dev(newice)
     diag = torch.zeros(abi.NDIAG, n, dtype=torch.float64, device="cuda")
-    def ulps8(x):  # 8 ulp of the true thickness that updateThickness cancels (0 where there is none)
+    def ulps8(x):  # 32 ulp of the true thickness that updateThickness cancels (0 where there is none)
         with np.errstate(all="ignore"):
-            return np.nan_to_num(8 * np.spacing(np.abs(x)), nan=0.0, posinf=0.0)
+            return np.nan_to_num(32 * np.spacing(np.abs(x)), nan=0.0, posinf=0.0)
 
     for step in range(3):
         with np.errstate(all="ignore"):

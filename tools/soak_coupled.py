@@ -2,6 +2,12 @@
 n x n box, with the device-side forcing providers -- cyclone wind moving with model time (nsdg_boxtest_forcing), winter
 thermodynamic forcing with a diurnal short-wave cycle (nsdg_column_forcing) and the column wind speed taken from the
 dynamics' wind (nsdg_column_wind) -- on the native row-block driver.  Prints ranges every `every` steps and the wall time.
+
+Concentration overshoot: neither process that changes A has a cap in the reference or here -- the column step's Hibler
+freeze (HiblerConcentration.cpp:32-38: del_c = newice / h0, no limit at 1) and the unlimited DG2 transport (convergent flow
+piles concentration up; no limiter exists in the scheme).  The run therefore books, per step and on the device, the
+EXCESS E = sum over elements of max(A - 1, 0) (cell means) before the column step, after it and after the transport, and
+reports which of the two produced it (cumulative, and over the last reporting interval), with the maxima of A after each.
 usage: python tools/soak_coupled.py [steps=720] [n=512] [forcing=winter|dummy|host]"""
 import os
 import sys
@@ -34,9 +40,27 @@ m0 = float(core.H[0].sum())
 every = int(os.environ.get("NSDG_SOAK_EVERY", max(1, steps // 12)))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+excess = lambda: (core.A[0] - 1.0).clamp_min(0.0).sum()
+zero = lambda: torch.zeros((), dtype=torch.float64, device=dev)
+made = {"column": zero(), "transport": zero()}  # excess produced by each process (device scalars: no host sync per step)
+amax = {"column": zero(), "transport": zero()}  # largest A seen right after each process
+last = {"column": 0.0, "transport": 0.0}
 for step in range(steps):
     core.device_wind(L, step * dt)  # the cyclone moves
-    core.step()
+    # core.step(), with the excess booked between its parts
+    core._set_grid()
+    core.external_forcing()
+    e0 = excess()
+    core.thermodynamics()
+    e1 = excess()
+    amax["column"] = torch.maximum(amax["column"], core.A[0].max())
+    core.momentum()
+    core.transport()
+    core.time += core.dt
+    e2 = excess()
+    amax["transport"] = torch.maximum(amax["transport"], core.A[0].max())
+    made["column"] += e1 - e0
+    made["transport"] += e2 - e1
     if step % every == 0 or step == steps - 1:
         fin = all(bool(torch.isfinite(f).all()) for f in (core.u, core.v, core.H, core.A, core.col["hsnow"], core.col["tice0"]))
         print("step %4d  t = %5.2f h  finite %s  umax %.3g  H [%.4f, %.4f]  A [%.4f, %.4f]  tice [%.2f, %.2f]  hsnow [%.3f, %.3f]  wind max %.1f  qsw max %.0f  newice max %.2e"
@@ -44,6 +68,12 @@ for step in range(steps):
                  float(core.A[0].min()), float(core.A[0].max()), float(core.col["tice0"].min()), float(core.col["tice0"].max()),
                  float(core.col["hsnow"].min()), float(core.col["hsnow"].max()), float(core.col["wind"].max()), float(core.col["qsw"].max()),
                  float(core.newice.max())), flush=True)
+        tot = {k: float(v) for k, v in made.items()}
+        print("           A > 1: excess sum(max(A - 1, 0)) = %.4e; produced so far by the column step (uncapped Hibler freeze) %.4e, by the DG2 "
+              "transport (no limiter) %.4e; since the last report %.3e / %.3e; max A right after the column step %.6f, after the transport %.6f"
+              % (float(excess()), tot["column"], tot["transport"], tot["column"] - last["column"], tot["transport"] - last["transport"],
+                 float(amax["column"]), float(amax["transport"])), flush=True)
+        last = tot
         if not fin or float(core.u.abs().max()) > 5.0:
             raise SystemExit("the coupled run left the physical range")
 torch.cuda.synchronize()
