@@ -239,19 +239,25 @@ __global__ __launch_bounds__(256) void halo_copy_kernel(SegTable T, double* __re
     }
 }
 
-// Rehearsal aid (tools/rank_share_timing.py --wire-us N): a loopback exchange on one GPU has no wire time, so a kernel
-// that spins for N microseconds can be put between pack and transport to see how much of a real transfer the overlap
-// with the interior launch would hide.  Never active unless NSDG_HALO_DELAY_US is set in the environment.
+// Rehearsal aid (tools/rank_share_timing.py): a loopback exchange on one GPU has no wire time, so a kernel that spins
+// for the time a real transfer would take can be put between pack and transport to see how much of it the overlap with
+// the interior launch hides.  NSDG_HALO_DELAY_US = fixed time per exchange (latency); NSDG_HALO_SIM_GBS = link bandwidth
+// per direction in GB/s, the time of the LARGER of the two directions is added (the two directions use different links).
+// Never active unless one of the two is set in the environment.
 __global__ void halo_delay_kernel(long ticks)
 {
     const long t0 = (long)__builtin_amdgcn_s_memrealtime(); // 100 MHz
     while ((long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
     }
 }
-long halo_delay_ticks()
+long halo_delay_ticks(long bytes_up, long bytes_down)
 {
     const char* v = std::getenv("NSDG_HALO_DELAY_US"); // read at every exchange: tests switch it on and off
-    return (v && *v) ? 100L * std::atol(v) : 0L;
+    const char* b = std::getenv("NSDG_HALO_SIM_GBS");
+    double us = (v && *v) ? std::atof(v) : 0.;
+    if (b && *b && std::atof(b) > 0.)
+        us += 1e-3 * (double)std::max(bytes_up, bytes_down) / std::atof(b); // bytes / (GB/s) = ns
+    return (long)(100. * us);
 }
 
 // adds the time of the exchange recorded in ring slot k to the plan's totals; wait: block until it has finished
@@ -549,8 +555,11 @@ int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* p)
     int rc = launch_copy(true, p->send, p->max_send, p->b_up, p->b_down, c->stream);
     if (rc != NSDG_OK)
         return rc;
-    if (halo_delay_ticks() > 0 && (p->n_up || p->n_down)) // rehearsal only: simulated transfer time
-        hipLaunchKernelGGL(halo_delay_kernel, dim3(1), dim3(1), 0, c->stream, halo_delay_ticks());
+    if (p->n_up || p->n_down) { // rehearsal only: simulated transfer time
+        const long ticks = halo_delay_ticks(p->n_up * (long)sizeof(double), p->n_down * (long)sizeof(double));
+        if (ticks > 0)
+            hipLaunchKernelGGL(halo_delay_kernel, dim3(1), dim3(1), 0, c->stream, ticks);
+    }
     if (c->nccl) {
         NSDG_CHECK_RCCL(g_rccl.GroupStart());
         ncclResult_t r = ncclSuccess;
