@@ -274,6 +274,8 @@ def transport_bench(args, device):
     order = args.order
     n = args.nx
     ctx = abi.Context(device)
+    if args.transport_variant is not None:
+        ctx.set_transport_variant(args.transport_variant)
     ctx.set_grid(n, n, 1.0 / n, 1.0 / n)
     phi, u, v, _ = synthetic.rotating_patch(n, n, order)
     nc, ng = {0: 1, 1: 3, 2: 6}[order], order + 1
@@ -340,6 +342,7 @@ def main():
     ap.add_argument("--nsub", type=int, default=120)
     ap.add_argument("--variant", type=int, default=None, help="mEVP kernel variant (default: library default)")
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
+    ap.add_argument("--transport-variant", type=int, default=None, help="transport stage kernel: 0 gather, 1 march, 2 two elements per lane (default: library default)")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
     ap.add_argument("--passes-per-exchange", type=int, default=8,
                     help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows)")
@@ -397,6 +400,8 @@ def main():
         ctx.set_mevp_strip_rows(args.strip_rows)
     if args.occupancy is not None:
         ctx.set_mevp_occupancy(args.occupancy)
+    if args.transport_variant is not None:
+        ctx.set_transport_variant(args.transport_variant)
     bt = synthetic.BoxTest(nx, ny, L)
     alpha = bt.stable_alpha(dt)  # alpha = beta from the linear-stability bound of the sub-cycle on this mesh
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))

@@ -55,18 +55,23 @@ __device__ __forceinline__ double kelvin(double c) { return c + WATER_TF; } // c
 // or a difference of data -- the concentration and the true thickness, the mixed-layer heat capacity (mld), deltaTml,
 // the slab conductance and the surface-temperature Newton step, and dt -- are IEEE divisions, so that mld == 0, dt == 0 or a vanishing flux
 // give the reference's Inf / 0 / NaN, bit for bit (tests: zero-denominator cases against the oracle).
+#ifdef NSDG_COLUMN_NO_FIXUP // A/B builds only: the round-2 form without the special-case fix-up (what it costs)
+#define NSDG_DIV_FIXUP(q, b, a) (q)
+#else
+#define NSDG_DIV_FIXUP(q, b, a) __builtin_amdgcn_div_fixup((q), (b), (a))
+#endif
 __device__ __forceinline__ double qdiv(double a, double b)
 {
     double r = __builtin_amdgcn_rcp(b);
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
     const double q = a * r;
-    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-b, q, a), r, q), b, a);
+    return NSDG_DIV_FIXUP(__builtin_fma(__builtin_fma(-b, q, a), r, q), b, a);
 }
 __device__ __forceinline__ double rdiv(double a, double b, double rb)
 {
     const double q = a * rb;
-    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-b, q, a), rb, q), b, a);
+    return NSDG_DIV_FIXUP(__builtin_fma(__builtin_fma(-b, q, a), rb, q), b, a);
 }
 #define CDIV(a, c) rdiv((a), (c), 1.0 / (c)) /* c is a compile-time constant: 1/c is folded */
 

@@ -417,14 +417,15 @@ __device__ __forceinline__ void node_contrib(const double (&s11)[8], const doubl
 // the update of DESIGN.md section 3.2 reads
 //   drag = cd*|v_o - v|;  u' = (K1 h' u + c2 + drag*u_o + K3 h' v + div_x/M) / (K2 h' + drag)
 //                         v' = (K1 h' v + c3 + drag*v_o - K3 h' u + div_y/M) / (K2 h' + drag)
-// Layout (round 3): three PAIR PLANES -- pair k = (c[2k], c[2k+1]) of node n at packed[k * 2 NN + 2 n], NN = number
-// of nodes of the local array -- instead of six consecutive doubles per node.  A lane of the marching kernels reads the
-// nodes 2 ix and 2 ix + 1 of a node row: with the planes its 16-byte accesses have a lane stride of 32 bytes (a
-// wave-instruction touches 16 lines of 128 bytes, each of them completely used by the two instructions of the row),
-// with the node-major layout 96 bytes (48 lines per instruction, a sixth of each used): 86 against 74 cycles per
-// instruction in profiles/r01_vmem_issue_microbench.txt.  The packers write perfectly coalesced 16-byte stores.
-// -DNSDG_NODAL_AOS restores the node-major layout (A/B builds).
-#ifdef NSDG_NODAL_AOS
+// Layout: six consecutive doubles per node (node-major), read with three 16-byte loads at a lane stride of 96 bytes.
+// Round 3 measured the alternative the round-2 review asked for -- three PAIR PLANES, pair k = (c[2k], c[2k+1]) of node n
+// at packed[k * 2 NN + 2 n], lane stride 32 bytes, every touched line completely used by the two instructions of a
+// node row (86 against 74 cycles per instruction in profiles/r01_vmem_issue_microbench.txt) -- and found it 0.4 % SLOWER
+// in the three-iteration kernel (0.7716 against 0.7682 ms per pass, three alternating runs on one box,
+// profiles/r03_fused3_levers.md): the node-major form keeps the 48 bytes of a node in ONE 128-byte line (one line per
+// lane and node, three loads that hit it), the planes spread them over three lines in three distant streams.  The plane
+// layout stays available as -DNSDG_NODAL_PLANES (A/B builds); both are bit-identical in their results.
+#ifndef NSDG_NODAL_PLANES
 constexpr int NODAL_STRIDE = 6;
 __host__ __device__ __forceinline__ long nodal_plane(long nnodes) { return 2; } // pair k at + 2 k
 __host__ __device__ __forceinline__ long nodal_node(long n) { return n * NODAL_STRIDE; }

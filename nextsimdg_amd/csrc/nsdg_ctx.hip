@@ -122,11 +122,19 @@ int nsdg_ctx_synchronize(nsdg_ctx* ctx)
 }
 
 namespace {
+// four independent 16-byte loads in flight per lane, then four stores; one workgroup per 16 KB, no loop
 __global__ __launch_bounds__(256) void copy16_kernel(double2* __restrict__ dst, const double2* __restrict__ src, long n2)
 {
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride)
-        dst[i] = src[i];
+    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    double2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + 256 * k < n2)
+            v[k] = src[i0 + 256 * k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + 256 * k < n2)
+            dst[i0 + 256 * k] = v[k];
 }
 } // namespace
 
@@ -138,8 +146,8 @@ int nsdg_copy_f64(nsdg_ctx* ctx, double* dst, const double* src, int64_t n)
     if (n == 0)
         return NSDG_OK;
     const long n2 = n >> 1;
-    // a few resident workgroups per CU, each lane streaming 16-byte accesses with a grid stride
-    const int blocks = (int)std::min<long>(std::max<long>((n2 + 255) / 256, 1), 16L * ctx->num_cus);
+    NSDG_CHECK_ARG(n2 < (1L << 40), "count too large");
+    const unsigned blocks = (unsigned)((n2 + 1023) / 1024);
     if (n2)
         hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(dst), reinterpret_cast<const double2*>(src), n2);
     if (n & 1)

@@ -13,6 +13,8 @@
 // quadrature points are compile-time constants (tools/gen_tables.py) folded into the instruction
 // stream by full unrolling; zero entries cost nothing.  HBM-bound: 1008 B / element-step for
 // DG2 x 2 fields x RK3.
+#include <cstdint>
+
 #include "dg_tables.h"
 #include "nsdg_internal.h"
 
@@ -253,6 +255,103 @@ __global__ __launch_bounds__(256, NSDG_TR_WAVES) void transport_stage_kernel(int
     }
 }
 
+// Two-elements-per-lane stage kernel (nsdg_transport_variant_set(ctx, 2, rows); needs an even nx and 16-byte aligned
+// arrays, the launcher falls back to the gather kernel otherwise): a lane owns the elements (ix, ix + 1), ix even.
+// Every coefficient plane of the pair -- own, below, above, phi0, the DG velocity, the horizontal-edge velocities -- is one
+// 16-byte access per lane instead of two 8-byte ones, the neighbour across the inner edge comes from the lane's own
+// registers, and only the outer left / right neighbours and the three vertical-edge velocities stay 8-byte accesses:
+// 99 vector-memory instructions per pair and two fields against 192 for the two lanes of the gather kernel.  The
+// arithmetic per element is the very transport_rhs() of the other kernels: bit-identical results.
+template <int ORDER>
+__global__ __launch_bounds__(256, 2) void transport_pair_kernel(int nx, int ny, int j0, int j1, int nfields, double ihx, double ihy, double dt,
+    double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg, const double* __restrict__ un_x,
+    const double* __restrict__ un_y)
+{
+    constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
+    const int ix = 2 * (blockIdx.x * 64 + threadIdx.x); // first element of the pair
+    const int iy = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix >= nx || iy >= j1)
+        return;
+    const long N = (long)nx * ny;
+    const long e = (long)iy * nx + ix;
+    const bool hasL = ix > 0, hasR = ix + 2 < nx, hasB = iy > 0, hasT = iy + 1 < ny;
+    auto ld2 = [](const double* p) { return *reinterpret_cast<const double2*>(p); };
+
+    double vx0[NC], vy0[NC], vx1[NC], vy1[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        if (ORDER > 0) {
+            const double2 x = ld2(vx_dg + k * N + e), y = ld2(vy_dg + k * N + e);
+            vx0[k] = x.x * ihx, vx1[k] = x.y * ihx, vy0[k] = y.x * ihy, vy1[k] = y.y * ihy;
+        } else
+            vx0[k] = vx1[k] = vy0[k] = vy1[k] = 0.;
+    }
+    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
+    const long exl = (long)iy * (nx + 1) + ix; // left vertical edge of the first element; + 1 the inner edge; + 2 the right edge of the second
+    EdgeVel<NG> E0, E1;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const double l = un_x[g * NEX + exl], m = un_x[g * NEX + exl + 1], r = un_x[g * NEX + exl + 2];
+        const double2 bt = ld2(un_y + g * NEY + e), tp = ld2(un_y + g * NEY + e + nx);
+        E0.l[g] = l, E0.r[g] = m, E1.l[g] = m, E1.r[g] = r;
+        E0.b[g] = bt.x, E1.b[g] = bt.y, E0.t[g] = tp.x, E1.t[g] = tp.y;
+    }
+    for (int f = 0; f < nfields; ++f) {
+        const double* __restrict__ phis = fp.phis[f];
+        const double* __restrict__ phi0 = fp.phi0[f];
+        double* __restrict__ out = fp.out[f];
+        double c0[NC], c1[NC];
+        NbTrace<NG> nb0, nb1;
+        {
+            double w0[NC], w1[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                w0[k] = hasL ? phis[k * N + e - 1] : 0.;
+            trace_of_left<ORDER>(w0, nb0.l);
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                w1[k] = hasR ? phis[k * N + e + 2] : 0.;
+            trace_of_right<ORDER>(w1, nb1.r);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const double2 t = hasB ? ld2(phis + k * N + e - nx) : make_double2(0., 0.);
+                w0[k] = t.x, w1[k] = t.y;
+            }
+            trace_of_bottom<ORDER>(w0, nb0.b);
+            trace_of_bottom<ORDER>(w1, nb1.b);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const double2 t = hasT ? ld2(phis + k * N + e + nx) : make_double2(0., 0.);
+                w0[k] = t.x, w1[k] = t.y;
+            }
+            trace_of_top<ORDER>(w0, nb0.t);
+            trace_of_top<ORDER>(w1, nb1.t);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const double2 t = ld2(phis + k * N + e);
+            c0[k] = t.x, c1[k] = t.y;
+        }
+        trace_of_right<ORDER>(c1, nb0.r); // across the inner edge: the partner element's coefficients are in registers
+        trace_of_left<ORDER>(c0, nb1.l);
+        double r0[NC], r1[NC];
+        transport_rhs<ORDER>(c0, nb0, vx0, vy0, E0, ihx, ihy, r0);
+        transport_rhs<ORDER>(c1, nb1, vx1, vy1, E1, ihx, ihy, r1);
+        if (a != 0.) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const double2 p = ld2(phi0 + i * N + e);
+                *reinterpret_cast<double2*>(out + i * N + e)
+                    = make_double2(a * p.x + b * (c0[i] + dt * IMASS[i] * r0[i]), a * p.y + b * (c1[i] + dt * IMASS[i] * r1[i]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                *reinterpret_cast<double2*>(out + i * N + e) = make_double2(b * (c0[i] + dt * IMASS[i] * r0[i]), b * (c1[i] + dt * IMASS[i] * r1[i]));
+        }
+    }
+}
+
 // Alternative stage kernel (nsdg_transport_variant_set(ctx, 1, rows)): a wave owns 64 columns x R rows of one field and marches bottom to top with a
 // three-row window of coefficients in registers, so every row of phi is read from HBM once (plus 2/R for
 // the window start) instead of up to three times;  measured at 2048^2 DG2 it is not faster than the gather
@@ -395,7 +494,19 @@ template <int ORDER>
 int launch_stage(nsdg_ctx* ctx, int j0, int j1, double dt, double a, double b, int nfields, const FieldPtrs& fp,
     const double* vx, const double* vy, const double* unx, const double* uny)
 {
-    if (ctx->transport_variant == 0) {
+    bool pairs = ctx->transport_variant == 2 && ctx->nx % 2 == 0;
+    if (pairs) { // 16-byte accesses: every array 16-byte aligned (plane and row offsets are even because nx is)
+        uintptr_t bits = (uintptr_t)vx | (uintptr_t)vy | (uintptr_t)uny;
+        for (int f = 0; f < nfields; ++f)
+            bits |= (uintptr_t)fp.phi0[f] | (uintptr_t)fp.phis[f] | (uintptr_t)fp.out[f];
+        pairs = (bits & 15) == 0;
+    }
+    if (pairs) {
+        const int br = ctx->transport_rows > 0 ? ctx->transport_rows : 4;
+        const dim3 block(64, br), grid(nsdg_div_up(ctx->nx / 2, 64), nsdg_div_up(j1 - j0, br));
+        hipLaunchKernelGGL(transport_pair_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, nfields, 1. / ctx->hx, 1. / ctx->hy, dt, a,
+            b, fp, vx, vy, unx, uny);
+    } else if (ctx->transport_variant != 1) {
         // rows per workgroup: the rows above / below a workgroup's band are read a second time by the neighbouring
         // workgroup, so taller bands mean fewer redundant reads (band + 2 rows read per band)
         const int br = ctx->transport_rows > 0 ? ctx->transport_rows : 4;
@@ -432,9 +543,9 @@ extern "C" {
 int nsdg_transport_variant_set(nsdg_ctx* ctx, int32_t variant, int32_t strip_rows)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
-    NSDG_CHECK_ARG(variant == 0 || variant == 1, "variant must be 0 (gather) or 1 (march)");
+    NSDG_CHECK_ARG(variant >= 0 && variant <= 2, "variant must be 0 (gather), 1 (march) or 2 (two elements per lane)");
     NSDG_CHECK_ARG(strip_rows >= 0 && strip_rows <= 4096, "strip rows must be in 0..4096 (0 = default)");
-    NSDG_CHECK_ARG(variant != 0 || strip_rows <= 4, "the gather kernel takes at most 4 rows per workgroup");
+    NSDG_CHECK_ARG(variant == 1 || strip_rows <= 4, "the gather kernels take at most 4 rows per workgroup");
     ctx->transport_variant = variant;
     ctx->transport_rows = strip_rows;
     return NSDG_OK;

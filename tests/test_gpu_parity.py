@@ -664,30 +664,33 @@ def test_mevp_two_per_pass_row_block_equals_full_domain_bitwise(ctx):
         assert torch.equal(full[k][2 * r0:2 * r1], part[k][4:4 + 2 * (r1 - r0)])
 
 
+@pytest.mark.parametrize("nx", [131, 132, 2])
 @pytest.mark.parametrize("order", [0, 1, 2])
-def test_transport_march_equals_gather_kernel_bitwise(ctx, order):
-    """the marching stage kernel (three-row register window) and the one-lane-per-element gather kernel
-    run the same transport_rhs arithmetic: bit-identical for any strip height, ragged sizes, row ranges"""
-    nx, ny = 131, 37
+def test_transport_march_and_pair_kernels_equal_gather_kernel_bitwise(ctx, order, nx):
+    """the marching stage kernel (three-row register window), the two-elements-per-lane kernel (16-byte accesses, even nx;
+    an odd nx falls back) and the one-lane-per-element gather kernel run the same transport_rhs arithmetic:
+    bit-identical for any strip height, ragged sizes, row ranges, one to three fields"""
+    ny = 37
     rng = np.random.default_rng(61 + order)
     ctx.set_grid(nx, ny, 0.01, 0.02)
     u = rng.uniform(-1, 1, (2 * ny + 1, 2 * nx + 1))
     v = rng.uniform(-1, 1, (2 * ny + 1, 2 * nx + 1))
     adv = adv_on_device(ctx, nx, ny, order, u, v)
     nc = basis.NCOEF[order]
-    phi0 = [dev(rng.uniform(0, 1, (nc, ny, nx))) for _ in range(2)]
-    phis = [dev(rng.uniform(0, 1, (nc, ny, nx))) for _ in range(2)]
+    phi0 = [dev(rng.uniform(0, 1, (nc, ny, nx))) for _ in range(3)]
+    phis = [dev(rng.uniform(0, 1, (nc, ny, nx))) for _ in range(3)]
     outs = []
-    for variant, rows in ((0, 0), (1, 0), (1, 1), (1, 5), (1, 64)):
+    for variant, rows in ((0, 0), (1, 0), (1, 1), (1, 5), (1, 64), (2, 0), (2, 1), (2, 3)):
         ctx.set_transport_variant(variant, rows)
-        out = [torch.full((nc, ny, nx), -3.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+        out = [torch.full((nc, ny, nx), -3.0, dtype=torch.float64, device="cuda") for _ in range(3)]
         ctx.transport_stage(order, 0, ny, 1e-3, 0.75, 0.25, phi0, phis, out, adv)
-        ctx.transport_stage(order, 4, 29, 2e-3, 0.0, 1.0, phi0, phis, out, adv)  # overwrite a row range
+        ctx.transport_stage(order, 4, 29, 2e-3, 0.0, 1.0, phi0[:2], phis[:2], out[:2], adv)  # overwrite a row range of two fields
+        ctx.transport_stage(order, 30, 31, 3e-3, 1.0 / 3.0, 2.0 / 3.0, phi0[2:], phis[2:], out[2:], adv)  # ... and one row of the third
         outs.append(out)
     for o in outs[1:]:
         for a, c in zip(outs[0], o):
             assert torch.equal(a, c)
-    ctx.set_transport_variant(0, 0)
+    ctx.set_transport_variant(abi.DEFAULT_TRANSPORT_VARIANT, 0)
 
 
 def test_mevp_prepare_equals_separate_kernels_bitwise(ctx):
