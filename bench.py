@@ -344,7 +344,7 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
     ap.add_argument("--transport-variant", type=int, default=None, help="transport stage kernel: 0 gather, 1 march, 2 two elements per lane (default: library default)")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
-    ap.add_argument("--passes-per-exchange", type=int, default=8,
+    ap.add_argument("--passes-per-exchange", type=int, default=3,
                     help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["native", "torch"], default="native",

@@ -67,7 +67,7 @@ class NsdgError(RuntimeError):
 # name -> (restype, argtypes); kept in one table so tests can check every declared symbol exists
 VP = C.c_void_p
 I32, I64, D = C.c_int32, C.c_int64, C.c_double
-DEFAULT_TRANSPORT_VARIANT = 0  # nsdg_ctx_create's default transport stage kernel (csrc/nsdg_ctx.hip)
+DEFAULT_TRANSPORT_VARIANT = 2  # nsdg_ctx_create's default transport stage kernel (csrc/nsdg_ctx.hip)
 DEFAULT_MEVP_VARIANT = 3  # nsdg_ctx_create's default: three sub-iterations per kernel pass (csrc/mevp_fused3.hip)
 
 SYMBOLS = {

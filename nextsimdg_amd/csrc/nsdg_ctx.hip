@@ -87,7 +87,9 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
         c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     c->fused_min_waves = 1;
-    c->transport_variant = 0; // measured (2048^2 DG2, 2 fields): gather 1.55 ms per RK3 step, march 1.51-1.76 ms
+    // measured (2048^2 DG2): gather 0.802-0.806 ms per RK3 step of one field, two elements per lane 0.770-0.786 ms
+    // (profiles/r03_transport_ab.log; bit-identical); march 1.51-1.76 against 1.55 ms for two fields in round 1
+    c->transport_variant = 2;
     c->transport_rows = 0;
     c->pack_dt = 0.;
     c->d_ptrs = nullptr;

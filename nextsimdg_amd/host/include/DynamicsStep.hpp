@@ -23,7 +23,7 @@
 //     dynamics.thermodynamics  run the column physics first       (false)
 //     dynamics.forcing       thermodynamic forcing: host (the structure's planes, constant in time) | dummy | winter
 //                            (generated on the device at every step's model time, wind speed from the dynamics' wind)
-//     dynamics.row_blocks, dynamics.devices, dynamics.passes_per_exchange (8), dynamics.overlap (true),
+//     dynamics.row_blocks, dynamics.devices, dynamics.passes_per_exchange (3), dynamics.overlap (true),
 //     dynamics.graph (false), dynamics.loopback_world (0: off; N: rehearse an interior block of N on one GPU with
 //     real RCCL send/recv to the rank itself -- values wrap around, for timing and call-path checks only)
 // The structure's cell means initialise the DG fields: H <- hice, A <- cice (coefficient 0; higher coefficients
@@ -84,7 +84,7 @@ private:
     std::vector<std::unique_ptr<DynamicsBlock>> m_blocks;
     int nxf = 0, nyf = 0; // fast / slow grid dimensions as the dynamics ABI names them
     double L = 512e3, alpha = 0, beta = 0;
-    int nsub = 120, rowBlocks = 1, passesPerExchange = 8, loopbackWorld = 0;
+    int nsub = 120, rowBlocks = 1, passesPerExchange = 3, loopbackWorld = 0;
     bool thermo = false, overlap = true, graph = false, m_inited = false;
     std::string forcing = "host", devices;
     int m_world = 1, m_rank = 0; // multi-process run (one block per process)

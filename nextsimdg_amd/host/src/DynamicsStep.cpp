@@ -119,7 +119,7 @@ void DynamicsStep::configure()
     beta = getConfiguration(keyMap.at(3), 0.);
     thermo = getConfiguration(keyMap.at(4), false);
     rowBlocks = getConfiguration(keyMap.at(5), 1);
-    passesPerExchange = getConfiguration(keyMap.at(6), 8);
+    passesPerExchange = getConfiguration(keyMap.at(6), 3);
     overlap = getConfiguration(keyMap.at(7), true);
     graph = getConfiguration(keyMap.at(8), false);
     forcing = getConfiguration(keyMap.at(9), std::string("host"));
