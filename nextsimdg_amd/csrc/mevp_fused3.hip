@@ -304,6 +304,18 @@ __global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, 
     M.tbeg = max(M.y0 - 3, 0);
     M.tendA = min(M.y1 + 1, ny - 1), M.tendB = min(M.y1, ny - 1); // A runs on rows tbeg .. tendA, B up to tendB
 
+#ifdef NSDG_EXP_STAGGER
+    // EXPERIMENT (tools/ab_build.sh stagger -DNSDG_EXP_STAGGER=cycles): the four waves of a CU start their marches
+    // simd_id x NSDG_EXP_STAGGER shader cycles apart, so that on a SHORT march (a row block of an 8-way decomposition: 15
+    // steps) the load burst that opens a step of one wave falls into the arithmetic of the other three instead of all
+    // waves of the chip loading and computing in lockstep
+    {
+        const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // HW_REG_HW_ID bits 5:4
+        const long until = (long)__builtin_amdgcn_s_memtime() + (long)simd * (NSDG_EXP_STAGGER);
+        while ((long)__builtin_amdgcn_s_memtime() < until)
+            __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     RowCarry3 X, Y; // alternate between "written by A" and "read by B": no copies when the march advances
 #pragma unroll
     for (int k = 0; k < 4; ++k)

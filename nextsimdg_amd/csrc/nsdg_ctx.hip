@@ -124,19 +124,14 @@ int nsdg_ctx_synchronize(nsdg_ctx* ctx)
 }
 
 namespace {
-// four independent 16-byte loads in flight per lane, then four stores; one workgroup per 16 KB, no loop
+// one 16-byte access per lane, one workgroup per 4 KB, no loop: the fastest of the copies compared in
+// tools/microbench/copy_peak.hip on the MI355X (profiles/r03_copy_peak.txt: 6.23 TB/s read + write; two / four / eight accesses
+// in flight per lane 6.0 / 5.8 / 3.7, grid-stride loops 5.4-5.6, hipMemcpyAsync 5.0-5.5, non-temporal x 4 6.1-6.3)
 __global__ __launch_bounds__(256) void copy16_kernel(double2* __restrict__ dst, const double2* __restrict__ src, long n2)
 {
-    const long i0 = (long)blockIdx.x * 1024 + threadIdx.x;
-    double2 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (i0 + 256 * k < n2)
-            v[k] = src[i0 + 256 * k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (i0 + 256 * k < n2)
-            dst[i0 + 256 * k] = v[k];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n2)
+        dst[i] = src[i];
 }
 } // namespace
 
@@ -148,8 +143,8 @@ int nsdg_copy_f64(nsdg_ctx* ctx, double* dst, const double* src, int64_t n)
     if (n == 0)
         return NSDG_OK;
     const long n2 = n >> 1;
-    NSDG_CHECK_ARG(n2 < (1L << 40), "count too large");
-    const unsigned blocks = (unsigned)((n2 + 1023) / 1024);
+    NSDG_CHECK_ARG(n2 < (1L << 39), "count too large");
+    const unsigned blocks = (unsigned)((n2 + 255) / 256);
     if (n2)
         hipLaunchKernelGGL(copy16_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<double2*>(dst), reinterpret_cast<const double2*>(src), n2);
     if (n & 1)
