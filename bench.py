@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--nsub", type=int, default=120)
     ap.add_argument("--variant", type=int, default=None, help="mEVP kernel variant (default: library default)")
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
-    ap.add_argument("--transport-variant", type=int, default=None, help="transport stage kernel: 0 gather, 1 march, 2 two elements per lane (default: library default)")
+    ap.add_argument("--transport-variant", type=int, default=None, help="transport stage kernel: 0 one element per lane, 2 two elements per lane (default: library default = 2)")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
     ap.add_argument("--passes-per-exchange", type=int, default=3,
                     help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows)")
@@ -550,15 +550,8 @@ def main():
             "roofline": roof,
             "mevp_element_subiters_per_s": own_elems * nsub / (cycle_ms * 1e-3),
         }
-        if world > 1:
-            cyc = [r["cycle_ms"] for r in reports]
-            line["ranks"] = {"cycle_ms_min": min(cyc), "cycle_ms_max": max(cyc), "step_gpu_ms_max": max(r["step_gpu_ms"] for r in reports),
-                             "exchange_ms_per_step_max": max((r.get("mevp_exchange_ms_per_step") or 0.0) + (r.get("transport_exchange_ms_per_step") or 0.0)
-                                                             for r in reports),
-                             "note": "per rank: GPU time of a step and of its parts (HIP events on the rank's stream), and the ghost exchanges -- "
-                                     "time on the communication stream from 'data ready' to 'ghost rows written' (pack + transfer + unpack + "
-                                     "waiting for a late neighbour; it overlaps with the interior launch of the overlap split)",
-                             "per_rank": reports}
+        if use_dist:  # N > 1 (and the one-rank rehearsal NSDG_FORCE_DIST, which exercises the same gather)
+            line["ranks"] = ranks_summary(reports)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nsub)
         print(json.dumps(line), flush=True)
@@ -567,6 +560,19 @@ def main():
     ctx.close()  # the library's communicator goes before torch's process group
     if use_dist:
         dist.destroy_process_group()
+
+
+def ranks_summary(reports):
+    """the `ranks` object of an N-GPU line: where each rank's time went, so that a SCALE record explains itself"""
+    cyc = [r["cycle_ms"] for r in reports]
+    exch = [(r.get("mevp_exchange_ms_per_step") or 0.0) + (r.get("transport_exchange_ms_per_step") or 0.0) for r in reports]
+    return {"cycle_ms_min": min(cyc), "cycle_ms_max": max(cyc), "step_gpu_ms_min": min(r["step_gpu_ms"] for r in reports),
+            "step_gpu_ms_max": max(r["step_gpu_ms"] for r in reports), "exchange_ms_per_step_max": max(exch),
+            "slowest_rank": max(reports, key=lambda r: r["step_gpu_ms"])["rank"],
+            "note": "per rank: GPU time of a step and of its parts (HIP events on the rank's stream), and the ghost exchanges -- "
+                    "time on the communication stream from 'data ready' to 'ghost rows written' (pack + transfer + unpack + "
+                    "waiting for a late neighbour; it overlaps with the interior launch of the overlap split)",
+            "per_rank": sorted(reports, key=lambda r: r["rank"])}
 
 
 def exchange_stats(core, steps=None, reset=False):

@@ -162,11 +162,10 @@ int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
 int nsdg_prepare_advection(nsdg_ctx* ctx, int32_t order, const double* u, const double* v, double* vx_dg,
     double* vy_dg, double* un_x, double* un_y);
 
-/* transport stage kernel: 0 = one lane per element gathering all neighbours from memory, 1 = marching
- * kernel with a three-row register window (reads each row once; measured no faster at 2048^2, kept as an
- * option), 2 = two elements per lane (16-byte accesses, the inner neighbour from registers; falls back to 0 for an
- * odd nx or arrays that are not 16-byte aligned).  All three give bit-identical results.
- * strip_rows: rows per strip of the marching kernel / rows per workgroup (<= 4) of the others, 0 = default. */
+/* transport stage kernel: 0 = one lane per element gathering all neighbours from memory, 2 (default) = two elements per
+ * lane (16-byte accesses, the inner neighbour from registers; falls back to 0 for an odd nx or arrays that are not
+ * 16-byte aligned).  Bit-identical results.  (1 was the marching kernel of rounds 1-2: never faster, removed.)
+ * strip_rows: rows per workgroup (<= 4), 0 = default. */
 int nsdg_transport_variant_set(nsdg_ctx* ctx, int32_t variant, int32_t strip_rows);
 
 /* one Runge-Kutta stage on element rows [j0, j1) for nfields fields advected by the same velocity:

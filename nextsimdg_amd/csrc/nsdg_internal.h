@@ -21,7 +21,7 @@ struct nsdg_ctx {
     int strip_rows; // rows per strip of the fused marching kernel (0 = chosen per launch)
     int num_cus;
     double pack_dt; // time step the packed nodal coefficients were built for (0 = never packed)
-    int transport_variant, transport_rows; // transport stage kernel: 0 gather / 1 march, rows per strip
+    int transport_variant, transport_rows; // transport stage kernel: 0 one element per lane / 2 two elements per lane; rows per workgroup
     int fused_min_waves; // register budget of the fused kernel: 1 or 2 waves per SIMD
     // device scratch for small host->device tables (field pointer lists of the transport stage)
     double** d_ptrs;

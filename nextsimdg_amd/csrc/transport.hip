@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, NSDG_TR_WAVES) void transport_stage_kernel(int
 // 16-byte access per lane instead of two 8-byte ones, the neighbour across the inner edge comes from the lane's own
 // registers, and only the outer left / right neighbours and the three vertical-edge velocities stay 8-byte accesses:
 // 99 vector-memory instructions per pair and two fields against 192 for the two lanes of the gather kernel.  The
-// arithmetic per element is the very transport_rhs() of the other kernels: bit-identical results.
+// arithmetic per element is the very transport_rhs() of the gather kernel: bit-identical results.
 template <int ORDER>
 __global__ __launch_bounds__(256, 2) void transport_pair_kernel(int nx, int ny, int j0, int j1, int nfields, double ihx, double ihy, double dt,
     double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg, const double* __restrict__ un_x,
@@ -352,90 +352,6 @@ __global__ __launch_bounds__(256, 2) void transport_pair_kernel(int nx, int ny, 
     }
 }
 
-// Alternative stage kernel (nsdg_transport_variant_set(ctx, 1, rows)): a wave owns 64 columns x R rows of one field and marches bottom to top with a
-// three-row window of coefficients in registers, so every row of phi is read from HBM once (plus 2/R for
-// the window start) instead of up to three times;  measured at 2048^2 DG2 it is not faster than the gather
-// kernel (1.51-1.76 ms vs 1.55 ms per RK3 step of two fields: fewer, longer waves), so it is not the default; the left/right neighbours are re-read through L1 (same cache
-// lines as the wave's own row).  The horizontal-edge velocities of the row's bottom are the previous row's
-// top and stay in registers too.  Same arithmetic (transport_rhs) as the reference form: bit-identical.
-template <int ORDER>
-__global__ __launch_bounds__(256) void transport_march_kernel(int nx, int ny, int j0, int j1, int R, int ncw, double ihx, double ihy,
-    double dt, double a, double b, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg,
-    const double* __restrict__ un_x, const double* __restrict__ un_y)
-{
-    constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int strip = wave / ncw, cw = wave - strip * ncw;
-    const int y0 = j0 + strip * R;
-    if (y0 >= j1)
-        return; // wave-uniform
-    const int y1 = min(y0 + R, j1);
-    const int ix = cw * 64 + lane;
-    if (ix >= nx)
-        return; // no cross-lane operation below: inactive lanes may leave
-    const double* __restrict__ phis = fp.phis[blockIdx.y];
-    const double* __restrict__ phi0 = fp.phi0[blockIdx.y];
-    double* __restrict__ out = fp.out[blockIdx.y];
-    const long N = (long)nx * ny;
-    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
-    const bool hasL = ix > 0, hasR = ix + 1 < nx;
-
-    double cb[NC], c[NC], ct[NC];
-    EdgeVel<NG> E;
-    {
-        const long e = (long)y0 * nx + ix;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            c[k] = phis[k * N + e];
-            cb[k] = y0 > 0 ? phis[k * N + e - nx] : 0.;
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            E.t[g] = un_y[g * NEY + (long)y0 * nx + ix]; // becomes the bottom edge of row y0
-    }
-    for (int t = y0; t < y1; ++t) {
-        const long e = (long)t * nx + ix;
-        double cl[NC], cr[NC], vx[NC], vy[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            ct[k] = t + 1 < ny ? phis[k * N + e + nx] : 0.;
-            cl[k] = hasL ? phis[k * N + e - 1] : 0.;
-            cr[k] = hasR ? phis[k * N + e + 1] : 0.;
-            vx[k] = ORDER > 0 ? vx_dg[k * N + e] * ihx : 0.;
-            vy[k] = ORDER > 0 ? vy_dg[k * N + e] * ihy : 0.;
-        }
-        const long exl = (long)t * (nx + 1) + ix;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            E.b[g] = E.t[g];
-            E.l[g] = un_x[g * NEX + exl], E.r[g] = un_x[g * NEX + exl + 1];
-            E.t[g] = un_y[g * NEY + e + nx];
-        }
-        double rhs[NC];
-        NbTrace<NG> nb;
-        trace_of_left<ORDER>(cl, nb.l);
-        trace_of_right<ORDER>(cr, nb.r);
-        trace_of_bottom<ORDER>(cb, nb.b);
-        trace_of_top<ORDER>(ct, nb.t);
-        transport_rhs<ORDER>(c, nb, vx, vy, E, ihx, ihy, rhs);
-        if (a != 0.) {
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                out[i * N + e] = a * phi0[i * N + e] + b * (c[i] + dt * IMASS[i] * rhs[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                out[i * N + e] = b * (c[i] + dt * IMASS[i] * rhs[i]);
-        }
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            cb[k] = c[k];
-            c[k] = ct[k];
-        }
-    }
-}
-
 // CG2 nodal velocity -> DG velocity (L2 projection) per element, and edge-normal velocities at the
 // edge Gauss points.  One lane per element; the lane also owns its left and bottom edge, the last
 // column / row additionally writes the right / top boundary edge.
@@ -506,21 +422,13 @@ int launch_stage(nsdg_ctx* ctx, int j0, int j1, double dt, double a, double b, i
         const dim3 block(64, br), grid(nsdg_div_up(ctx->nx / 2, 64), nsdg_div_up(j1 - j0, br));
         hipLaunchKernelGGL(transport_pair_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, nfields, 1. / ctx->hx, 1. / ctx->hy, dt, a,
             b, fp, vx, vy, unx, uny);
-    } else if (ctx->transport_variant != 1) {
+    } else {
         // rows per workgroup: the rows above / below a workgroup's band are read a second time by the neighbouring
         // workgroup, so taller bands mean fewer redundant reads (band + 2 rows read per band)
         const int br = ctx->transport_rows > 0 ? ctx->transport_rows : 4;
         const dim3 block(64, br), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, br));
         hipLaunchKernelGGL(transport_stage_kernel<ORDER>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, nfields, 1. / ctx->hx,
             1. / ctx->hy, dt, a, b, fp, vx, vy, unx, uny);
-    } else {
-        // strip height: enough waves to fill the chip several times over (the kernel is light: ~8 waves/SIMD),
-        // few enough rows of window start-up; 16 rows = 12 % extra reads of phi
-        const int ncw = nsdg_div_up(ctx->nx, 64);
-        const int R = ctx->transport_rows > 0 ? ctx->transport_rows : 16;
-        const long nwaves = (long)ncw * nsdg_div_up(j1 - j0, R);
-        hipLaunchKernelGGL(transport_march_kernel<ORDER>, dim3(nsdg_div_up(nwaves, 4), nfields), dim3(256), 0, ctx->stream, ctx->nx,
-            ctx->ny, j0, j1, R, ncw, 1. / ctx->hx, 1. / ctx->hy, dt, a, b, fp, vx, vy, unx, uny);
     }
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
@@ -543,9 +451,9 @@ extern "C" {
 int nsdg_transport_variant_set(nsdg_ctx* ctx, int32_t variant, int32_t strip_rows)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
-    NSDG_CHECK_ARG(variant >= 0 && variant <= 2, "variant must be 0 (gather), 1 (march) or 2 (two elements per lane)");
-    NSDG_CHECK_ARG(strip_rows >= 0 && strip_rows <= 4096, "strip rows must be in 0..4096 (0 = default)");
-    NSDG_CHECK_ARG(variant == 1 || strip_rows <= 4, "the gather kernels take at most 4 rows per workgroup");
+    NSDG_CHECK_ARG(variant == 0 || variant == 2,
+        "variant must be 0 (one element per lane) or 2 (two elements per lane); 1, the marching kernel of rounds 1-2, was removed: never faster");
+    NSDG_CHECK_ARG(strip_rows >= 0 && strip_rows <= 4, "rows per workgroup must be in 0..4 (0 = default)");
     ctx->transport_variant = variant;
     ctx->transport_rows = strip_rows;
     return NSDG_OK;

@@ -45,3 +45,18 @@ def test_without_a_gpu_the_real_bench_fails_loudly():
         return
     p = run_bench("--gpus", "1", "--steps", "1", "--warmup", "0")
     assert p.returncode != 0 and b"no CPU fallback" in p.stderr + p.stdout
+
+
+def test_ranks_summary_of_an_n_gpu_line():
+    """the `ranks` object that makes a SCALE record self-explaining: min / max over ranks, the slowest rank, reports in rank order"""
+    import bench
+
+    reports = [{"rank": r, "rows_owned": 256, "rows_local": 273, "ghost_rows_below": 9, "ghost_rows_above": 8, "cycle_ms": 5.0 + 0.1 * r,
+                "prepare_ms": 0.1, "transport_ms": 0.3, "step_gpu_ms": 6.0 + (0.5 if r == 2 else 0.0), "step_wall_ms": 6.6,
+                "mevp_exchange_ms_per_step": 1.0 + 0.2 * r, "transport_exchange_ms_per_step": 0.05} for r in (3, 0, 2, 1)]
+    s = bench.ranks_summary(reports)
+    assert [r["rank"] for r in s["per_rank"]] == [0, 1, 2, 3]
+    assert s["cycle_ms_min"] == 5.0 and abs(s["cycle_ms_max"] - 5.3) < 1e-12 and s["slowest_rank"] == 2
+    assert s["step_gpu_ms_max"] == 6.5 and s["step_gpu_ms_min"] == 6.0 and abs(s["exchange_ms_per_step_max"] - 1.65) < 1e-12
+    # a rank without native-driver statistics (python driver / torch halo) still summarises
+    assert bench.ranks_summary([{"rank": 0, "cycle_ms": 1.0, "step_gpu_ms": 2.0}])["exchange_ms_per_step_max"] == 0.0
