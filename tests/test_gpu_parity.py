@@ -729,7 +729,7 @@ def frozen(case):
     return {e["name"]: data[e["offset"]:e["offset"] + int(np.prod(e["shape"]))].reshape(e["shape"]) for e in idx["arrays"] if e["case"] == case}
 
 
-@pytest.mark.parametrize("variant", [1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_hip_path_matches_the_frozen_oracle_outputs(ctx, variant):
     """The HIP path against the COMMITTED outputs of oracle/dyn_oracle.c (tests/golden/dyn_selfcheck_v1.*), at the
     tolerances of the live comparisons above: DG0/1/2 transport (3 steps, 70 x 37), one mEVP sub-iteration (67 x 21), the
@@ -805,7 +805,7 @@ def test_hip_path_matches_the_frozen_oracle_outputs(ctx, variant):
     c = cases.COUPLED
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=c["alpha"], beta=c["beta"]))
     ctx.set_column_params(ctx.column_default_params())
-    core = cases.run_coupled(ctx, torch.device("cuda"), native=(variant == 3))
+    core = cases.run_coupled(ctx, torch.device("cuda"), native=(variant >= 2))  # variants 0 / 1: the Python sequence of single sub-iterations
     torch.cuda.synchronize()
     for k in ("H", "A"):
         assert_close(host(getattr(core, k)), want[k], 1e-10, 1e-12, "frozen coupled " + k)

@@ -1,0 +1,14 @@
+# BASELINE config 5 as a run through the C++ host: 4096 x 4096 DG2 dynamics + column thermodynamics, ONE MODEL DAY (720 steps),
+# once as a single block and once as 8 row blocks (threads of one process, in-process transport, one GPU): the two restart
+# files must be identical byte for byte.  usage: bash tools/r03_config5_day.sh [n=4096] [stop=86400]
+set -o pipefail
+N=${1:-4096}; STOP=${2:-86400}
+BIN=nextsimdg_amd/host/build/nextsim_amd
+COMMON="--Modules.Nextsim::IModelStep=Nextsim::DynamicsStep --model.structure=rectgrid --model.init_file= --rectgrid.nx=$N --rectgrid.ny=$N --init.hice=0.3 --init.cice=0.9 --init.sst=-1.76 --init.hsnow=0.05 --init.tice=-8 --dynamics.thermodynamics=true --dynamics.forcing=winter --model.start=0 --model.stop=$STOP --model.time_step=120 --model.timing=true"
+for B in 1 8; do
+  echo "=== row_blocks = $B"
+  /usr/bin/time -f "wall %e s" $BIN $COMMON --dynamics.row_blocks=$B --model.final_file=/tmp/nsdg_cfg5_rb$B.nsdg 2>&1 | grep -v "^ *[│├└]" | tail -12 || exit 1
+done
+ls -l /tmp/nsdg_cfg5_rb1.nsdg /tmp/nsdg_cfg5_rb8.nsdg
+if cmp /tmp/nsdg_cfg5_rb1.nsdg /tmp/nsdg_cfg5_rb8.nsdg; then echo "restart files of 1 block and 8 blocks: IDENTICAL byte for byte"; else echo "restart files DIFFER"; exit 1; fi
+rm -f /tmp/nsdg_cfg5_rb1.nsdg /tmp/nsdg_cfg5_rb8.nsdg
