@@ -252,3 +252,82 @@ def test_oracle_reproduces_its_frozen_outputs():
                                  "largest value)" % (e["case"], e["name"], int((got != want).sum()), n, diff.max(), diff.max() / max(np.abs(want).max(), 1e-300)))
         seen.add(e["case"])
     assert seen == set(cases.CASES)
+
+
+# ------------------------------------------------------------------------------------ operators against independent quadrature
+def _lagrange(s):
+    """quadratic Lagrange functions and derivatives on [0, 1] (nodes 0, 1/2, 1) at the points s"""
+    s = np.asarray(s, dtype=float)
+    L = np.stack([2 * (s - 0.5) * (s - 1), -4 * s * (s - 1), 2 * s * (s - 0.5)])
+    dL = np.stack([4 * s - 3, -8 * s + 4, 4 * s - 1])
+    return L, dL
+
+
+def test_strain_projection_is_pointwise_exact_for_biquadratic_velocities():
+    """The DG8 strain coefficients are an L2 projection that loses nothing: the derivatives of a biquadratic CG2 function lie in
+    the 8-space.  Checked against an independent numpy evaluation of grad w at random points of every element, through the only
+    door the oracle has (the stress update): with alpha = 1, Delta_min = D huge and P = 2 D everywhere the new stress is
+    Proj(1.25 e11 + 0.75 e22) - D, Proj(e12 / 2), Proj(1.25 e22 + 0.75 e11) - D."""
+    nx, ny, hx, hy = 5, 4, 2.0, 3.0
+    rng = np.random.default_rng(8)
+    D = 1e8
+    p = O.mevp_params(alpha=1.0, delta_min=D)
+    u, v = rng.standard_normal((2 * ny + 1, 2 * nx + 1)), rng.standard_normal((2 * ny + 1, 2 * nx + 1))
+    s = [rng.standard_normal((8, ny, nx)) for _ in range(3)]  # alpha = 1 forgets the old stress
+    O.mevp_stress(nx, ny, 0, ny, hx, hy, p, u, v, np.full((9, ny, nx), 2 * D), *s)
+    pts = rng.random((7, 2))
+    Lx, dLx = _lagrange(pts[:, 0])
+    Ly, dLy = _lagrange(pts[:, 1])
+    worst12 = worst11 = 0.0
+    for iy in range(ny):
+        for ix in range(nx):
+            ul, vl = u[2 * iy:2 * iy + 3, 2 * ix:2 * ix + 3], v[2 * iy:2 * iy + 3, 2 * ix:2 * ix + 3]  # [ay, ax]
+            ux = np.einsum("yx,xp,yp->p", ul, dLx, Ly) / hx
+            uy = np.einsum("yx,xp,yp->p", ul, Lx, dLy) / hy
+            vx = np.einsum("yx,xp,yp->p", vl, dLx, Ly) / hx
+            vy = np.einsum("yx,xp,yp->p", vl, Lx, dLy) / hy
+            psi = np.array([basis.psi(i, pts[:, 0] - 0.5, pts[:, 1] - 0.5) for i in range(8)])  # [i, p]
+            got12 = s[1][:, iy, ix] @ psi
+            got11 = s[0][:, iy, ix] @ psi + D
+            got22 = s[2][:, iy, ix] @ psi + D
+            worst12 = max(worst12, np.max(np.abs(got12 - 0.25 * (uy + vx))))
+            worst11 = max(worst11, np.max(np.abs(got11 - (1.25 * ux + 0.75 * vy))), np.max(np.abs(got22 - (1.25 * vy + 0.75 * ux))))
+    assert worst12 < 1e-13  # values O(1): round-off only
+    assert worst11 < 1e-6  # the constant D = 1e8 that was subtracted costs 8 digits
+
+
+def test_nodal_divergence_is_the_weak_divergence_of_the_dg_stress():
+    """-(sigma, grad phi_n) at every interior CG2 node, for a random DG8 stress, against numpy quadrature with explicitly written
+    Lagrange functions (4 x 4 Gauss points: exact for the degree-5 integrands) -- and the lumped mass against int phi_n.  The
+    oracle's divergence is read off the velocity update with everything else switched off: u_new = (div_x / M_n) / (rho h (1 + beta) / dt)."""
+    nx, ny, hx, hy, dt = 5, 4, 2.0, 3.0, 120.0
+    rng = np.random.default_rng(9)
+    p = O.mevp_params(c_ocean=0.0, fc=0.0, beta=3.0)
+    s = [rng.standard_normal((8, ny, nx)) for _ in range(3)]
+    N = (2 * ny + 1, 2 * nx + 1)
+    z, h = np.zeros(N), 0.4
+    un, vn = np.zeros(N), np.zeros(N)
+    O.mevp_velocity(nx, ny, 0, ny, hx, hy, dt, p, s, (z, z), (un, vn), (z, z), (z, z), (z, z), np.full(N, h), np.ones(N))
+    g, w = basis.gauss(4)  # on [-1/2, 1/2]
+    L, dL = _lagrange(g + 0.5)
+    divx, divy, lump = np.zeros(N), np.zeros(N), np.zeros(N)
+    psi = np.array([[[basis.psi(i, g[qx], g[qy]) for qx in range(4)] for qy in range(4)] for i in range(8)])  # [i, qy, qx]
+    W = np.outer(w, w)  # [qy, qx]
+    for iy in range(ny):
+        for ix in range(nx):
+            S11, S12, S22 = (np.tensordot(c[:, iy, ix], psi, axes=1) for c in s)  # values at the Gauss points [qy, qx]
+            for ay in range(3):
+                for ax in range(3):
+                    phix = np.outer(L[ay], dL[ax]) / hx  # d phi / dx at [qy, qx]
+                    phiy = np.outer(dL[ay], L[ax]) / hy
+                    n = (2 * iy + ay, 2 * ix + ax)
+                    divx[n] -= hx * hy * np.sum(W * (S11 * phix + S12 * phiy))
+                    divy[n] -= hx * hy * np.sum(W * (S12 * phix + S22 * phiy))
+                    lump[n] += hx * hy * np.sum(W * np.outer(L[ay], L[ax]))
+    scale = p.rho_ice * h * (1.0 + p.beta) / dt
+    inner = (slice(1, -1), slice(1, -1))
+    assert np.max(np.abs(divx[inner])) > 0.1
+    np.testing.assert_allclose(un[inner] * scale * lump[inner], divx[inner], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(vn[inner] * scale * lump[inner], divy[inner], rtol=1e-12, atol=1e-12)
+    for a in (un, vn):  # Dirichlet walls
+        assert np.all(a[0] == 0) and np.all(a[-1] == 0) and np.all(a[:, 0] == 0) and np.all(a[:, -1] == 0)
