@@ -30,8 +30,15 @@ ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
 blk = rowblock.RowBlock(nx, ny, 0, 1)
 core = rowblock.CoupledCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, native=True, forcing=None if forcing == "host" else forcing)
 cs, cf = synthetic.column_fields_smooth(nx, ny, L)  # initial snow / ice temperature; sst at the freezing point (see the docstring there)
-core.load_column({**cs, **cf})
 H, A = bt.dg_fields()
+if os.environ.get("NSDG_SOAK_INIT") == "const":  # the constant initial state of the C++ host's [init] keys (tools/r03_config5_day.sh)
+    import numpy as np
+
+    H[:], A[:] = 0.0, 0.0
+    H[0], A[0] = 0.3, 0.9
+    cs = {"hsnow": np.full((ny, nx), 0.05), "tice0": np.full((ny, nx), -8.0)}
+    cf["sst"], cf["sss"] = np.full((ny, nx), -1.76), np.full((ny, nx), 32.0)
+core.load_column({**cs, **cf})
 uo, vo = bt.ocean()
 ua, va = bt.wind(0.0)
 core.load_global(H, A, uo, vo, ua, va)
@@ -63,6 +70,12 @@ for step in range(steps):
     made["transport"] += e2 - e1
     if step % every == 0 or step == steps - 1:
         fin = all(bool(torch.isfinite(f).all()) for f in (core.u, core.v, core.H, core.A, core.col["hsnow"], core.col["tice0"]))
+        if not fin:
+            for name, f in (("u", core.u), ("v", core.v), ("H", core.H), ("A", core.A), ("hsnow", core.col["hsnow"]), ("tice0", core.col["tice0"])):
+                bad = ~torch.isfinite(f)
+                if bool(bad.any()):
+                    idx = bad.nonzero()[:5].tolist()
+                    print("           non-finite %s: %d entries, first at %s" % (name, int(bad.sum()), idx), flush=True)
         print("step %4d  t = %5.2f h  finite %s  umax %.3g  H [%.4f, %.4f]  A [%.4f, %.4f]  tice [%.2f, %.2f]  hsnow [%.3f, %.3f]  wind max %.1f  qsw max %.0f  newice max %.2e"
               % (step, (step + 1) * dt / 3600.0, fin, float(core.u.abs().max()), float(core.H[0].min()), float(core.H[0].max()),
                  float(core.A[0].min()), float(core.A[0].max()), float(core.col["tice0"].min()), float(core.col["tice0"].max()),
