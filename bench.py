@@ -344,8 +344,9 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
     ap.add_argument("--transport-variant", type=int, default=None, help="transport stage kernel: 0 one element per lane, 2 two elements per lane (default: library default = 2)")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
-    ap.add_argument("--passes-per-exchange", type=int, default=3,
-                    help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows)")
+    ap.add_argument("--passes-per-exchange", type=int, default=0,
+                    help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows); "
+                         "0 (default) = try 3 and 8 during the warm-up and keep the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["native", "torch"], default="native",
                     help="N > 1: ghost-row exchange through the C ABI (nsdg_halo_*, RCCL calls and pack kernels in libnsdg.so) or through torch.distributed P2P ops")
@@ -393,48 +394,63 @@ def main():
     nx, ny, nsub = args.nx, args.ny, args.nsub
     L = 512e3
     dt = 120.0
-    ctx = abi.Context(device)
-    if args.variant is not None:
-        ctx.set_mevp_variant(args.variant)
-    if args.strip_rows is not None:
-        ctx.set_mevp_strip_rows(args.strip_rows)
-    if args.occupancy is not None:
-        ctx.set_mevp_occupancy(args.occupancy)
-    if args.transport_variant is not None:
-        ctx.set_transport_variant(args.transport_variant)
     bt = synthetic.BoxTest(nx, ny, L)
     alpha = bt.stable_alpha(dt)  # alpha = beta from the linear-stability bound of the sub-cycle on this mesh
-    ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
-    blk, depth = plan_blocks(ctx.mevp_variant, args.passes_per_exchange, nx, ny, rank, world)
     coupled = args.workload == "coupled"
-    exchanger = None
-    if world > 1 or os.environ.get("NSDG_FORCE_DIST"):
-        with stdout_to_stderr():  # the library's own RCCL communicator
-            exchanger = make_exchanger(args.halo, ctx, blk, device)
-    native = args.driver == "native" and (exchanger is None or isinstance(exchanger, rowblock.NativeHaloExchanger))
-    core = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(ctx, blk, L / nx, L / ny, dt, nsub, device, exchanger=exchanger,
-                                                                        native=native, use_graph=args.graph)
+    # One-GPU rehearsal of the WHOLE N-rank code path (NSDG_BENCH_LOOPBACK_WORLD=W): this process plays the interior block W/2
+    # of W, both neighbours are the rank itself, every exchange a real RCCL send/recv group -- the values wrap around, so
+    # the line carries timings and the `ranks` object but NO metric value.
+    loop_world = int(os.environ.get("NSDG_BENCH_LOOPBACK_WORLD", "0"))
+    if loop_world and (world != 1 or loop_world < 3):
+        raise SystemExit("NSDG_BENCH_LOOPBACK_WORLD needs a single process and a world of at least 3 (an interior block)")
+    eff_world, eff_rank = (loop_world, loop_world // 2) if loop_world else (world, rank)
+    H, A = bt.dg_fields()
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    column = None
     if coupled:
         # thermodynamic forcing held constant in time: smooth analytic fields in the ranges of SURVEY.md section 8(d)
         # with the mixed layer at the freezing point (synthetic.column_fields_smooth explains why not the per-element
         # random fields of the column-kernel bench: those blow the coupled model up within ~10 steps)
         cs, cf = synthetic.column_fields_smooth(nx, ny, L)
-        core.load_column({**cs, **cf})
+        column = {**cs, **cf}
         del cs, cf
-    H, A = bt.dg_fields()
-    uo, vo = bt.ocean()
-    ua, va = bt.wind(0.0)
-    core.load_global(H, A, uo, vo, ua, va)
-    del H, A, uo, vo, ua, va
 
-    def sync():
+    def build_core(kpass):
+        """context, row block, exchanger and driver for `kpass` passes per exchange, fields loaded"""
+        c = abi.Context(device)
+        if args.variant is not None:
+            c.set_mevp_variant(args.variant)
+        if args.strip_rows is not None:
+            c.set_mevp_strip_rows(args.strip_rows)
+        if args.occupancy is not None:
+            c.set_mevp_occupancy(args.occupancy)
+        if args.transport_variant is not None:
+            c.set_transport_variant(args.transport_variant)
+        c.set_mevp_params(c.mevp_default_params(alpha=alpha, beta=alpha))
+        b, d = plan_blocks(c.mevp_variant, kpass, nx, ny, eff_rank, eff_world)
+        ex = None
+        if eff_world > 1 or os.environ.get("NSDG_FORCE_DIST"):
+            with stdout_to_stderr():  # the library's own RCCL communicator
+                ex = make_exchanger(args.halo, c, b, device, loopback=bool(loop_world))
+            if hasattr(c, "comm_deadline"):
+                c.comm_deadline(COMM_DEADLINE_S)
+        nat = args.driver == "native" and (ex is None or isinstance(ex, rowblock.NativeHaloExchanger))
+        co = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(c, b, L / nx, L / ny, dt, nsub, device, exchanger=ex, native=nat,
+                                                                          use_graph=args.graph)
+        if coupled:
+            co.load_column(column)
+        co.load_global(H, A, uo, vo, ua, va)
+        return c, b, d, ex, nat, co
+
+    def drain(c, ex):
         # drain this rank's own work first: the ghost exchanges run on the library's RCCL communicator, the barrier on
         # torch's -- two communicators are never given work at the same time.  With neighbours the drain is BOUNDED
         # (nsdg_ctx_synchronize polls the streams against the communicator's deadline): a rank whose neighbour has died
         # leaves with a non-zero status instead of waiting in ncclRecv for ever; the launcher then ends the others.
-        if exchanger is not None:
+        if ex is not None:
             try:
-                ctx.synchronize()
+                c.synchronize()
             except abi.NsdgError as e:
                 sys.stderr.write("bench.py rank %d: %s\n" % (rank, e))
                 sys.stderr.flush()
@@ -444,8 +460,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if exchanger is not None and hasattr(ctx, "comm_deadline"):
-        ctx.comm_deadline(COMM_DEADLINE_S)
+    # Passes per exchange.  How many kernel passes should run between two ghost exchanges depends on what a transfer costs
+    # on the machine the job runs on -- mostly latency (few, large exchanges win: 8 passes) or mostly bandwidth (small, hidden
+    # exchanges and fewer redundant ghost rows win: 3 passes) -- and that is only known on the real
+    # links.  With --passes-per-exchange 0 (the default) an N-rank run therefore TRIES both during the warm-up, two
+    # un-timed steps each, and keeps the faster one (max over ranks); the timed region then runs K steps of that choice.
+    tune = None
+    kpass = args.passes_per_exchange
+    if eff_world > 1 and kpass == 0:
+        tune = {}
+        for cand in (3, 8):
+            c_, b_, d_, ex_, nat_, co_ = build_core(cand)
+            if d_ in [t["ghost_depth"] for t in tune.values()]:  # short blocks cap the depth: both candidates are the same plan
+                co_.close()
+                co_ = ex_ = None
+                c_.close()
+                continue
+            co_.step()
+            drain(c_, ex_)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                co_.step()
+            drain(c_, ex_)
+            tt = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device=device)
+            if use_dist:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tune[cand] = {"ms_per_step": 1e3 * float(tt[0]), "ghost_depth": d_}
+            co_.close()  # driver plans first, then the context with the library's communicator
+            co_ = ex_ = None
+            c_.close()
+        kpass = min(tune, key=lambda k_: tune[k_]["ms_per_step"])
+    elif kpass == 0:
+        kpass = 3
+    ctx, blk, depth, exchanger, native, core = build_core(kpass)
+    del H, A, uo, vo, ua, va, column
+
+    def sync():
+        drain(ctx, exchanger)
+
     for _ in range(args.warmup):
         core.step()
     sync()
@@ -473,7 +525,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t[0])
     cycle_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))  # one sub-cycle (nsub sub-iterations), this rank
-    rank_report = {"rank": rank, "rows_owned": blk.r1 - blk.r0, "rows_local": blk.ny, "ghost_rows_below": blk.gb, "ghost_rows_above": blk.gt,
+    rank_report = {"rank": eff_rank, "rows_owned": blk.r1 - blk.r0, "rows_local": blk.ny, "ghost_rows_below": blk.gb, "ghost_rows_above": blk.gt,
                    "cycle_ms": cycle_ms, "prepare_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
                    "transport_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev])),
                    "step_gpu_ms": float(np.mean([e[0].elapsed_time(e[3]) for e in ev])), "step_wall_ms": 1e3 * own_elapsed / args.steps}
@@ -511,7 +563,7 @@ def main():
         launch_ms = cycle_ms * per_launch / nsub
         compulsory = own_elems * BYTES_COMPULSORY_PER_PASS
         achieved = compulsory / (launch_ms * 1e-3) / 1e9
-        off = offline_counters(nx, ny, fused_kernel) if world == 1 else None
+        off = offline_counters(nx, ny, fused_kernel) if eff_world == 1 else None
         copy_peak = copy_peak_gbs(ctx, device)
         roof = {"bound": "hbm", "kernel": fused_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
@@ -533,15 +585,18 @@ def main():
                               "note": "one-pass-per-sub-iteration byte model of SURVEY.md 8(d); the fused kernel keeps the intermediate stress and "
                                       "velocity of %d sub-iterations on chip, so this ratio is NOT a roofline fraction (it may exceed 1)" % per_launch}}
         line = {
-            "metric": "element-steps/sec (dynamics+transport)", "value": value, "unit": "element-steps/s",
+            "metric": "element-steps/sec (dynamics+transport)", "value": None if loop_world else value, "unit": "element-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("column thermodynamics + " if coupled else "") + "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
                                    "512 km box test, dt=120 s, alpha=beta=%.0f (the linear-stability bound of the sub-cycle on this mesh; SURVEY 8(d) "
                                    "names 1500, which is unstable here; with %d sub-iterations the stress is under-converged towards the VP state -- "
                                    "flops and bytes do not depend on alpha)" % (nx, ny, nsub, alpha, nsub),
-                       "decomposition": "%d row block(s), ghost-row send/recv" % world + (
-                           ", ghost depth %d/%d rows, one exchange per %d mEVP passes, halo=%s" % (depth[0], depth[1], core.group_passes, args.halo) if world > 1 else ""),
+                       "decomposition": "%d row block(s), ghost-row send/recv" % eff_world + (
+                           ", ghost depth %d/%d rows, one exchange per %d mEVP passes%s, halo=%s" % (
+                               depth[0], depth[1], core.group_passes,
+                               " (chosen in the warm-up: %s)" % ", ".join("%d passes %.3f ms/step" % (k_, t_["ms_per_step"]) for k_, t_ in sorted(tune.items())) if tune else "",
+                               args.halo) if eff_world > 1 else ""),
                        "mevp_passes": "%s sub-iteration%s per kernel pass" % ({3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
                        "mevp_variant": args.variant if args.variant is not None else "default",
                        "driver": ("native (nsdg_rb_mevp_run / nsdg_rb_transport_run)" + (" + hipGraph replay" if args.graph else "")) if native else "python sequence",
@@ -550,12 +605,16 @@ def main():
             "roofline": roof,
             "mevp_element_subiters_per_s": own_elems * nsub / (cycle_ms * 1e-3),
         }
-        if use_dist:  # N > 1 (and the one-rank rehearsal NSDG_FORCE_DIST, which exercises the same gather)
+        if use_dist or loop_world:  # N > 1 (and the one-rank rehearsals, which exercise the same code)
             line["ranks"] = ranks_summary(reports)
-        if world == 1 and not args.no_cpu_baseline:
+        if loop_world:
+            line["rehearsal"] = ("NOT A MEASUREMENT OF THE METRIC: one GPU plays the interior block %d of %d, both neighbours are the rank itself (real "
+                                 "RCCL send/recv groups, values wrap around); ms_per_step is this block's share of the step" % (eff_rank, eff_world))
+        if eff_world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(nsub)
         print(json.dumps(line), flush=True)
     sync()
+    core.close()
     core = exchanger = None
     ctx.close()  # the library's communicator goes before torch's process group
     if use_dist:
@@ -601,8 +660,8 @@ def plan_blocks(variant, passes_per_exchange, nx, ny, rank, world):
     return rowblock.RowBlock(nx, ny, rank, world, *depth), depth
 
 
-def make_exchanger(kind, ctx, blk, device):
-    loop = bool(os.environ.get("NSDG_FORCE_DIST")) and blk.world == 1
+def make_exchanger(kind, ctx, blk, device, loopback=False):
+    loop = loopback or (bool(os.environ.get("NSDG_FORCE_DIST")) and blk.world == 1)
     if kind == "native":
         return rowblock.NativeHaloExchanger(ctx, blk, device, loopback=loop)
     return rowblock.HaloExchanger(blk, loopback=loop)
@@ -661,7 +720,7 @@ def dry_run(args, rank, world):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29512")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    blk, depth = plan_blocks(abi.DEFAULT_MEVP_VARIANT, args.passes_per_exchange, args.nx, args.ny, rank, world)
+    blk, depth = plan_blocks(abi.DEFAULT_MEVP_VARIANT, args.passes_per_exchange or 3, args.nx, args.ny, rank, world)  # 0 = chosen in the warm-up of a real run
     rows = torch.tensor([float(blk.r1 - blk.r0)], dtype=torch.float64)
     dist.all_reduce(rows, op=dist.ReduceOp.SUM)
     dist.barrier()

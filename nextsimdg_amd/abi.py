@@ -389,9 +389,15 @@ class Context:
             self._call(self.lib.nsdg_rb_mevp_stats(ch, h, C.byref(st), int(reset)))
             return st.as_dict()
 
+        def close():  # destroys the plan (its halo plans, packed buffers and events); idempotent, before the context goes
+            if run.handle is not None and self.h:
+                self.lib.nsdg_rb_mevp_destroy(run.handle)
+            run.handle = None
+
         run.keep = ts
         run.handle = h
         run.stats = stats
+        run.close = close
         return run, per_pass.value, group.value
 
     def rb_transport(self, blk, peers, phi, t1, t2, adv):
@@ -419,9 +425,15 @@ class Context:
             self._call(self.lib.nsdg_rb_transport_stats(ch, h, C.byref(st), int(reset)))
             return st.as_dict()
 
+        def close():
+            if run.handle is not None and self.h:
+                self.lib.nsdg_rb_transport_destroy(run.handle)
+            run.handle = None
+
         run.keep = ts
         run.handle = h
         run.stats = stats
+        run.close = close
         return run
 
     # ---- arrays private to the mEVP sub-cycle (stress, ice strength) live in the tiled layout

@@ -319,6 +319,15 @@ class DynamicsCore:
         self._fbuf, self._tpar = ((self.H, self.A), (self.t1[0], self.t1[1])), 0
         self._run_transport = self.ops.rb_transport(b, peers, self._fbuf[0], self._fbuf[1], self.t2, self.adv)
 
+    def close(self):
+        """releases the native driver plans (device buffers and events of their ghost exchanges); call it before the
+        context is closed"""
+        for name in ("_run_mevp", "_run_transport"):
+            run = getattr(self, name, None)
+            if run is not None and hasattr(run, "close"):
+                run.close()
+            setattr(self, name, None)
+
     def load_global(self, H, A, uo, vo, ua, va, u=None, v=None):
         """fill the local arrays (ghost rows included) from global numpy arrays"""
         es, ns = self.blk.elem_slice(), self.blk.node_slice()
