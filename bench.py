@@ -19,7 +19,8 @@ Prints ONE JSON line on rank 0 (contract in the task description) with `roofline
 of the fused mEVP kernel, HIP-event timed in this run; `frac` is bounded by 1: the kernel's own compulsory
 bytes per pass against 8 TB/s -- the unfused accounting of SURVEY.md section 8(d), 896 B per element and
 sub-iteration, is reported beside it as `survey_8d` and is NOT a roofline fraction) and `cpu_baseline` (the CPU
-oracle = this repo's own restatement, "port", timed on a bounded sample and extrapolated per element).
+oracle = this repo's own restatement, "port", timed on a bounded sample of the same 2048 x 2048 workload: a few of the
+step's 120 sub-iterations and its transport step).
 """
 import argparse
 import json
@@ -118,66 +119,55 @@ def copy_peak_gbs(ctx, device, mib=1024, reps=10):
     return 2.0 * n * 8 / (ms * 1e-3) / 1e9
 
 
-def cpu_baseline(nsub_full, budget_s=12.0):
-    """Time the CPU oracle (tests' checker; here only as the reported baseline) on a bounded sample
-    of the same workload: a 192 x 192 box test, a few mEVP sub-iterations and one transport step,
-    single thread (the reference itself is single-threaded), then extrapolate
-    per element: t_step = nsub * t_subiter + t_transport."""
+def cpu_baseline(nsub_full, nx, ny, budget_s=12.0):
+    """Time the CPU oracle (the tests' checker; here only as the reported baseline) on a BOUNDED sample of the SAME workload: the
+    nx x ny box test of the bench (capped at 2048 x 2048), as many of the step's mEVP sub-iterations as fit into the budget (at
+    least two) and one DG2 RK3 transport step of H and A, single thread (the reference itself is single-threaded, SURVEY.md
+    section 5); the step's cost is t_step = nsub * t_subiteration + t_transport.  Then the same with the OpenMP build on the
+    host cores the box grants."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
     cores = set_omp_threads(host_cores())
-    n = 192
-    bt = synthetic.BoxTest(n, n)
+    nx, ny = min(nx, 2048), min(ny, 2048)
+    bt = synthetic.BoxTest(nx, ny)
     p = O.mevp_params()
     H, A = bt.dg_fields()
-    pg = O.ice_strength(n, n, p, H, A)
-    cgh, cga = O.dg_to_cg(n, n, H), O.dg_to_cg(n, n, A)
+    pg = O.ice_strength(nx, ny, p, H, A)
+    cgh, cga = O.dg_to_cg(nx, ny, H), O.dg_to_cg(nx, ny, A)
     uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
     ua, va = [np.ascontiguousarray(a) for a in bt.wind(0.0)]
     tax, tay = O.wind_stress(p, ua, va)
     u, v = np.zeros_like(uo), np.zeros_like(uo)
-    s = [np.zeros((8, n, n)) for _ in range(3)]
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    n_el = nx * ny
     out = {}
     for omp in (False, True):
         try:
             O.lib(omp)
         except Exception:
             continue
-        if omp and n == 192:
-            # the all-cores figure needs enough rows for every thread: re-build the sample at 768 x 768
-            n = 768
-            bt = synthetic.BoxTest(n, n)
-            H, A = bt.dg_fields()
-            pg = O.ice_strength(n, n, p, H, A)
-            cgh, cga = O.dg_to_cg(n, n, H), O.dg_to_cg(n, n, A)
-            uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
-            ua, va = [np.ascontiguousarray(a) for a in bt.wind(0.0)]
-            tax, tay = O.wind_stress(p, ua, va)
-            u, v = np.zeros_like(uo), np.zeros_like(uo)
-            s = [np.zeros((8, n, n)) for _ in range(3)]
-        O.mevp_subcycle(n, n, bt.hx, bt.hy, 120.0, 1, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg, omp=omp)
+        share = 0.6 if not omp else 0.15  # of the budget: sub-iterations; the transport step comes on top
         t0 = time.perf_counter()
         k = 0
-        while True:
-            O.mevp_subcycle(n, n, bt.hx, bt.hy, 120.0, 2, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg, omp=omp)
-            k += 2
-            if time.perf_counter() - t0 > budget_s * (0.8 if not omp else 0.2):
-                break
-        t_sub = (time.perf_counter() - t0) / (k * n * n)
-        adv = O.prepare_advection(n, n, 2, u, v)
+        while k < 2 or time.perf_counter() - t0 < budget_s * share:
+            O.mevp_subcycle(nx, ny, bt.hx, bt.hy, 120.0, 1, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg, omp=omp)
+            k += 1
+        t_sub = (time.perf_counter() - t0) / (k * n_el)
+        adv = O.prepare_advection(nx, ny, 2, u, v)
         t0 = time.perf_counter()
         for f in (H.copy(), A.copy()):
-            O.transport_step(n, n, bt.hx, bt.hy, 2, 120.0, f, adv, omp=omp)
-        t_tr = (time.perf_counter() - t0) / (n * n)
+            O.transport_step(nx, ny, bt.hx, bt.hy, 2, 120.0, f, adv, omp=omp)
+        t_tr = (time.perf_counter() - t0) / n_el
         out[omp] = (1.0 / (nsub_full * t_sub + t_tr), 1.0 / t_sub, k)
-    res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port", "extrapolated": True,
-           "sample": "EXTRAPOLATED, not the 2048x2048 workload itself: oracle/dyn_oracle.c on a 192x192 box test, %d mEVP sub-iterations + "
-                     "1 DG2 RK3 transport step of H and A, per-element costs scaled to %d sub-iterations/step; own CPU restatement -- "
-                     "the reference snapshot has no dynamics code to time" % (out[False][2], nsub_full),
-           "subiters_per_s": out[False][1]}
+    what = "oracle/dyn_oracle.c on the bench's own %dx%d box test: %d of the step's %d mEVP sub-iterations + the DG2 RK3 transport step of H and A, " \
+           "the sub-iteration cost scaled to %d per step (a bounded sample of the same workload, not a smaller grid); own CPU restatement -- the " \
+           "reference snapshot has no dynamics code to time"
+    res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port", "extrapolated": False,
+           "sample": what % (nx, ny, out[False][2], nsub_full, nsub_full), "subiters_per_s": out[False][1]}
     if True in out:
-        res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1], "sample": "OpenMP build, 768x768 box test"}
+        res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1],
+                            "sample": "OpenMP build, the same %dx%d sample, %d sub-iterations + the transport step" % (nx, ny, out[True][2])}
     return res
 
 
@@ -611,7 +601,7 @@ def main():
             line["rehearsal"] = ("NOT A MEASUREMENT OF THE METRIC: one GPU plays the interior block %d of %d, both neighbours are the rank itself (real "
                                  "RCCL send/recv groups, values wrap around); ms_per_step is this block's share of the step" % (eff_rank, eff_world))
         if eff_world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(nsub)
+            line["cpu_baseline"] = cpu_baseline(nsub, nx, ny)
         print(json.dumps(line), flush=True)
     sync()
     core.close()
