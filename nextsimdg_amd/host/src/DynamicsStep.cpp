@@ -380,6 +380,7 @@ void DynamicsStep::stop(const Iterator::TimePoint&)
         return;
     FieldStore& f = pStructure->fields();
     std::vector<double> umax(m_blocks.size(), 0.);
+    bool finite = true;
     std::size_t idx = 0;
     for (auto& bp : m_blocks) { // sequential: the blocks write disjoint row ranges of the host structure
         DynamicsBlock& b = *bp;
@@ -398,8 +399,10 @@ void DynamicsStep::stop(const Iterator::TimePoint&)
         const long rows = 2L * (b.j1 - b.j0) + (b.peerAbove < 0 ? 1 : 0);
         std::vector<double> u(rows * nn);
         checkHip(hipMemcpy(u.data(), b.curU() + 2L * b.j0 * nn, u.size() * sizeof(double), hipMemcpyDeviceToHost), "download u");
-        for (double x : u)
+        for (double x : u) {
             umax[idx] = std::max(umax[idx], std::fabs(x));
+            finite = finite && std::isfinite(x);
+        }
         ++idx;
     }
     m_umax = *std::max_element(umax.begin(), umax.end());
@@ -409,6 +412,12 @@ void DynamicsStep::stop(const Iterator::TimePoint&)
             m_sumH += f.hice[e];
             m_sumA += f.cice[e];
         }
+    // A run that has left the physical range (the sub-cycle going unstable) must fail loudly: the
+    // caller gets an exception (non-zero exit of nextsim_amd) and -- because writeRestartFile() comes through here first -- no
+    // restart file full of NaN is written.  (The reference never checks its fields; it also has no dynamics to go unstable.)
+    if (!finite || !std::isfinite(m_sumH) || !std::isfinite(m_sumA))
+        throw std::runtime_error("DynamicsStep: the run left the physical range (non-finite velocity, thickness or concentration after "
+            + std::to_string(m_steps) + " steps); no restart file is written");
 }
 
 NSDG_REGISTER_MODULE(IModelStep, DynamicsStep, "Nextsim::IModelStep", "Nextsim::DynamicsStep");

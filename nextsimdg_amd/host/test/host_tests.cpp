@@ -590,6 +590,30 @@ static void test_dynamics_step()
     ModuleLoader::getLoader().setAllDefaults();
 }
 
+static void test_dynamics_reports_a_run_that_blows_up()
+{ // a relaxation parameter of 1e-200 makes the stress overflow within two sub-iterations (1 / alpha = 1e200): the fields are
+  // non-finite at the end of the run; the step must say so (exception -> non-zero exit of nextsim_amd) and no restart file may appear
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    std::remove("/tmp/nsdg_dyn_blowup.nsdg");
+    addConfig("[Modules]\nNextsim::IModelStep = Nextsim::DynamicsStep\n[model]\nstructure = rectgrid\nstart = 0\nstop = 1200\ntime_step = 120\n"
+              "final_file = /tmp/nsdg_dyn_blowup.nsdg\n[rectgrid]\nnx = 64\nny = 48\n[init]\nhice = 0.3\ncice = 1.0\n[dynamics]\nnsub = 12\nalpha = 1e-200\nbeta = 1e-200\n");
+    ConfiguredModule::parseConfigurator();
+    bool threw = false;
+    try {
+        Model model;
+        model.configure();
+        model.run();
+    } catch (const std::runtime_error& e) {
+        threw = std::string(e.what()).find("left the physical range") != std::string::npos;
+    }
+    CHECK(threw);
+    std::ifstream probe("/tmp/nsdg_dyn_blowup.nsdg");
+    CHECK(!probe.good()); // ~Model's restart write went through the same check and was abandoned
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+}
+
 static void test_rendezvous()
 { // two "ranks" of a multi-process run agree on 128 bytes over the loopback interface
     int r0, r1, covered = 0;
@@ -771,6 +795,7 @@ int main(int argc, char** argv)
             test_model_dev1();
             test_dynamics_step();
             test_dynamics_row_blocks();
+            test_dynamics_reports_a_run_that_blows_up();
         }
     } catch (const std::exception& e) {
         std::printf("FAIL: unexpected exception: %s\n", e.what());
