@@ -25,7 +25,7 @@ L, dt, nsub = 512e3, 120.0, 120
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
-alpha = bt.stable_alpha(dt)
+alpha = bt.stable_alpha(dt) * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # NSDG_ALPHA_SCALE: a wider stability margin than the default 2.4 x the bound
 ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
 blk = rowblock.RowBlock(nx, ny, 0, 1)
 core = rowblock.CoupledCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, native=True, forcing=None if forcing == "host" else forcing)
