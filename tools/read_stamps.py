@@ -13,7 +13,8 @@ import torch
 
 from nextsimdg_amd import abi, rowblock, synthetic
 
-nx = ny = 2048
+nx = 2048
+ny = int(os.environ.get("NSDG_STAMPS_NY", "2048"))  # 273: the local array of an 8-way row block (strips of 10 rows, 15 march steps per wave)
 L, dt, nsub = 512e3, 120.0, 12
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
