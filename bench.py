@@ -543,7 +543,7 @@ def main():
     full, twos, ones = core.passes_per_step()
     per_launch = core.per_pass if full else (2 if twos else 1)
     launches = full if full else (twos if twos else ones)  # launches of the dominant kernel per sub-cycle
-    fused_kernel = {3: "mevp_fused3_kernel", 2: "mevp_fused2_kernel", 1: "mevp_fused_kernel"}[per_launch]
+    fused_kernel = {4: "mevp_fused4_kernel", 3: "mevp_fused3_kernel", 2: "mevp_fused2_kernel", 1: "mevp_fused_kernel"}[per_launch]
     if rank == 0:
         n_elem = nx * ny
         value = n_elem * args.steps / elapsed
@@ -645,7 +645,7 @@ def plan_blocks(variant, passes_per_exchange, nx, ny, rank, world):
     """row block of `rank`: ghost element rows below / above are (v k, v k - 1) for k passes of v sub-iterations
     between two exchanges"""
     kpass = max(1, min(passes_per_exchange, (ny // world) // 16)) if world > 1 else 1
-    vpass = min(variant, 3)
+    vpass = min(variant, 4)
     depth = (vpass * kpass, vpass * kpass - 1) if vpass >= 2 else (1, 1)
     return rowblock.RowBlock(nx, ny, rank, world, *depth), depth
 

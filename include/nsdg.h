@@ -154,7 +154,9 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
  * kernel that performs two sub-iterations per pass (nsdg_mevp_iterate2 / nsdg_mevp_subcycle on a whole
  * local array; single sub-iterations and row-range calls use the variant-1 kernel), 3 = three
  * sub-iterations per pass (nsdg_mevp_iterate3 / nsdg_mevp_subcycle; remainders of 2 or 1 sub-iterations use
- * the kernels of variants 2 and 1); 3 is the default of a new context.  Variants 1, 2 and 3 agree bit for bit,
+ * the kernels of variants 2 and 1), 4 = four sub-iterations per pass, one pipeline stage per wave of a four-wave
+ * workgroup with the hand-over in LDS (nsdg_mevp_iterate4 / nsdg_mevp_subcycle; remainders of 3, 2 or 1 sub-iterations
+ * use the kernels of variants 3, 2 and 1); 3 is the default of a new context.  Variants 1, 2, 3 and 4 agree bit for bit,
  * variant 0 to fp64 round-off. */
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
 
@@ -270,6 +272,19 @@ int nsdg_mevp_iterate3_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
     const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old, double* u_new,
     double* v_new, const double* packed, const double* pg);
 
+/* FOUR complete sub-iterations in one pass on the owned element rows [j0, j1): reads S_in, u_old on rows
+ * j0-4 .. j1+2 and writes S_out = S^{p+4} on rows [j0, j1) and u_new = u^{p+4} on the nodes they own.  j0 == 0
+ * or j0 >= 4 (four ghost rows below); j1 == ny or j1 + 3 <= ny (three ghost rows above).  Requires variant 4. */
+int nsdg_mevp_iterate4(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
+    const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
+    double* u_new, double* v_new, const double* packed, const double* pg);
+
+/* The same on TWO disjoint row ranges in ONE launch (see nsdg_mevp_iterate3_pair); each range obeys the ghost-row
+ * conditions of nsdg_mevp_iterate4; bit-identical to two calls. */
+int nsdg_mevp_iterate4_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b, int32_t j1b, const double* s11_in, const double* s12_in,
+    const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old, double* u_new,
+    double* v_new, const double* packed, const double* pg);
+
 /* nsub sub-iterations over the whole local array (packs the nodal coefficients, then iterates);
  * result in s11/s12/s22 and u, v (u0/v0 may be the same arrays as u/v).  scratch: 10*(2nx+1)*(2ny+1) + 24*nx*ny doubles, 16-byte aligned
  * (packed coefficients + ping-pong copies of the velocity and the stress). */
@@ -351,7 +366,7 @@ int nsdg_halo_stats_get(nsdg_ctx* ctx, nsdg_halo* plan, nsdg_halo_stats* out, in
  *   local array nx x ny (ghost rows included), owned element rows [j0, j1), nominal ghost depths
  *   (depth_below, depth_above) -- the same on every rank -- and the neighbour ranks (-1 = physical boundary; a
  *   rank keeps ghost rows only towards existing neighbours: j0 = depth_below or 0, j1 = ny - depth_above or ny).
- * Kernels with v = 3 / 2 sub-iterations per pass (nsdg_mevp_variant_set) are used when the depths are (v k, v k - 1)
+ * Kernels with v = 4 / 3 / 2 sub-iterations per pass (nsdg_mevp_variant_set) are used when the depths are (v k, v k - 1)
  * -- k passes run between two exchanges, the ghost rows are advanced redundantly -- or when the block has no
  * neighbours; otherwise one sub-iteration per pass with (1, 1).  Both calls are asynchronous on the context's
  * stream.  Blocks with neighbours need a communicator (nsdg_comm_init*) before the plan is created. */

@@ -21,7 +21,7 @@
 //
 // Row ranges: a launch updates the owned element rows [j0, j1) and reads three rows below and two above
 // them.  Where those rows do not exist the edge of the local array is the physical boundary.
-#include "mevp_common.h"
+#include "mevp_pipeline.h"
 
 #ifdef NSDG_STAMPS
 __device__ unsigned nsdg_stamp_acc3[64 * 16];
@@ -41,61 +41,8 @@ struct RowCarry3 {
     double u[4], v[4]; // u^p, v^p at those nodes
 };
 
-struct MarchConst3 {
-    NodalConsts K;
-    int nx, ny, y0, y1, tbeg, tendA, tendB, ix, ntx, nn, lane;
-    long nplane; // doubles between two pair planes of the packed nodal coefficients
-    bool own, hasL, lastcol;
-    double hx, hy, ihx, ihy, iarea, ialpha, dmin2;
-};
-
-// contributions of a row to its top nodes, carried to the next row of the march
-struct TopCarry3 {
-    double x6 = 0., y6 = 0., x7 = 0., y7 = 0., xl8 = 0., yl8 = 0.; // 6: top-left, 7: top-mid of my column, 8 of the left column
-};
-
 constexpr int PARK_VALUES = 32; // 24 stress coefficients + u, v at the 4 owned nodes
 constexpr int PARK_SLOT = PARK_VALUES * 64; // doubles per slot
-
-// the four owned nodes of one element row from the carried contributions of the row below (`carry`), the
-// contributions of this row (cx, cy) and the left neighbour's right-column contributions
-__device__ __forceinline__ void owned_node_updates(const MarchConst3& M, bool hasB, const double (&c)[4][6], const double (&uu)[4],
-    const double (&vv)[4], const TopCarry3& carry, const double (&cx)[9], const double (&cy)[9], double (&un)[4], double (&vn)[4])
-{
-    const double l2x = lane_from_left(cx[2]), l2y = lane_from_left(cy[2]);
-    const double l5x = lane_from_left(cx[5]), l5y = lane_from_left(cy[5]);
-    if (M.hasL && hasB)
-        node_update_packed(M.K, c[0], uu[0], vv[0], ((carry.xl8 + carry.x6) + l2x) + cx[0], ((carry.yl8 + carry.y6) + l2y) + cy[0], 9. * M.iarea,
-            un[0], vn[0]);
-    else
-        un[0] = vn[0] = 0.;
-    if (hasB)
-        node_update_packed(M.K, c[1], uu[1], vv[1], carry.x7 + cx[1], carry.y7 + cy[1], 4.5 * M.iarea, un[1], vn[1]);
-    else
-        un[1] = vn[1] = 0.;
-    if (M.hasL)
-        node_update_packed(M.K, c[2], uu[2], vv[2], l5x + cx[3], l5y + cy[3], 4.5 * M.iarea, un[2], vn[2]);
-    else
-        un[2] = vn[2] = 0.;
-    node_update_packed(M.K, c[3], uu[3], vv[3], cx[4], cy[4], 2.25 * M.iarea, un[3], vn[3]);
-}
-
-__device__ __forceinline__ void carry_top(TopCarry3& carry, const double (&cx)[9], const double (&cy)[9])
-{
-    carry.x6 = cx[6], carry.y6 = cy[6], carry.x7 = cx[7], carry.y7 = cy[7];
-    carry.xl8 = lane_from_left(cx[8]), carry.yl8 = lane_from_left(cy[8]);
-}
-
-// u at the 9 nodes of an element from the 4 owned nodes of its row (lo), the two bottom nodes of the row
-// above (hi0 = V, hi1 = EX) and the right neighbour lane (node column 2*nx is the right boundary)
-__device__ __forceinline__ void gather_nodes(const MarchConst3& M, const double (&lo)[4], double hi0, double hi1, double (&w)[9])
-{
-    w[0] = lo[0], w[1] = lo[1], w[3] = lo[2], w[4] = lo[3], w[6] = hi0, w[7] = hi1;
-    const double r2 = lane_from_right(lo[0]), r5 = lane_from_right(lo[2]), r8 = lane_from_right(hi0);
-    w[2] = M.lastcol ? 0. : r2;
-    w[5] = M.lastcol ? 0. : r5;
-    w[8] = M.lastcol ? 0. : r8;
-}
 
 // One march step: A(t) into `cur`; B(t) on row t-1 from `prev` (parked in LDS afterwards); C(t) on row t-2 from LDS.
 __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarry3& cur, RowCarry3& prev, TopCarry3& ca, TopCarry3& cb,
@@ -109,26 +56,12 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
         const long ts = tile_off(ix, t, M.ntx, 8), tp = tile_off(ix, t, M.ntx, 9);
         const long nV = (long)(2 * t) * nn + 2 * ix;
         double ul[9], vl[9];
-#ifdef NSDG_EXP_UVPAIR
-        // TIMING-ONLY experiment (wrong values; tools/ab_build.sh uvpair -DNSDG_EXP_UVPAIR, bench.py --no-guard with
-        // NSDG_EXP_UVPAIR=1 so that [u | v] is one allocation): what a (u, v)-interleaved nodal lattice would cost --
-        // the 18 strided 8-byte loads of A become 6 16-byte loads and three DPP columns, the 8 stores of C become 4
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double2 a = *reinterpret_cast<const double2*>(u_old + 2 * (nV + r * nn));
-            const double2 b = *reinterpret_cast<const double2*>(u_old + 2 * (nV + r * nn + 1));
-            ul[3 * r] = a.x, vl[3 * r] = a.y, ul[3 * r + 1] = b.x, vl[3 * r + 1] = b.y;
-            const double cu = lane_from_right(a.x), cv = lane_from_right(a.y);
-            ul[3 * r + 2] = M.lastcol ? 0. : cu, vl[3 * r + 2] = M.lastcol ? 0. : cv;
-        }
-#else
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
             const long n = nV + (a / 3) * nn + a % 3;
             ul[a] = u_old[n];
             vl[a] = v_old[n];
         }
-#endif
         double PA[9];
         tile_load9(pg, tp, ix & 63, PA);
         tile_load8(S.i11, ts, cur.s11);
@@ -232,17 +165,10 @@ __device__ __forceinline__ void march_step3(const MarchConst3& M, int t, RowCarr
             double un[4], vn[4];
             owned_node_updates(M, q > 0, c, qu, qv, cc, cx, cy, un, vn);
             if (store) {
-#ifdef NSDG_EXP_UVPAIR
-                *reinterpret_cast<double2*>(u_new + 2 * nV) = make_double2(un[0], vn[0]);
-                *reinterpret_cast<double2*>(u_new + 2 * (nV + 1)) = make_double2(un[1], vn[1]);
-                *reinterpret_cast<double2*>(u_new + 2 * (nV + nn)) = make_double2(un[2], vn[2]);
-                *reinterpret_cast<double2*>(u_new + 2 * (nV + nn + 1)) = make_double2(un[3], vn[3]);
-#else
                 u_new[nV] = un[0], v_new[nV] = vn[0];
                 u_new[nV + 1] = un[1], v_new[nV + 1] = vn[1];
                 u_new[nV + nn] = un[2], v_new[nV + nn] = vn[2];
                 u_new[nV + nn + 1] = un[3], v_new[nV + nn + 1] = vn[3];
-#endif
                 if (M.lastcol) {
                     u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
                     u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
@@ -281,19 +207,11 @@ __global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, 
     if (M.y0 >= j1)
         return; // wave-uniform
     M.y1 = min(M.y0 + R, j1);
-#ifdef NSDG_EXP_NOHALO
-    const int ixr = cw * 64 + lane; // TIMING-ONLY: no redundant lanes at all (upper bound of what sharing halo columns between waves could gain)
-#else
     const int ixr = cw * 59 - 3 + lane;
-#endif
     const bool valid = ixr >= 0 && ixr < nx;
     M.K = K;
     M.nx = nx, M.ny = ny, M.lane = lane;
-#ifdef NSDG_EXP_NOHALO
-    M.own = valid;
-#else
     M.own = valid && lane >= 3 && lane <= 61;
-#endif
     M.ix = min(max(ixr, 0), nx - 1);
     M.hasL = M.ix > 0, M.lastcol = M.ix == nx - 1;
     M.ntx = tiles_per_row(nx);
@@ -304,18 +222,6 @@ __global__ __launch_bounds__(64) void mevp_fused3_kernel(NodalConsts K, int nx, 
     M.tbeg = max(M.y0 - 3, 0);
     M.tendA = min(M.y1 + 1, ny - 1), M.tendB = min(M.y1, ny - 1); // A runs on rows tbeg .. tendA, B up to tendB
 
-#ifdef NSDG_EXP_STAGGER
-    // EXPERIMENT (tools/ab_build.sh stagger -DNSDG_EXP_STAGGER=cycles): the four waves of a CU start their marches
-    // simd_id x NSDG_EXP_STAGGER shader cycles apart, so that on a SHORT march (a row block of an 8-way decomposition: 15
-    // steps) the load burst that opens a step of one wave falls into the arithmetic of the other three instead of all
-    // waves of the chip loading and computing in lockstep
-    {
-        const unsigned simd = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); // HW_REG_HW_ID bits 5:4
-        const long until = (long)__builtin_amdgcn_s_memtime() + (long)simd * (NSDG_EXP_STAGGER);
-        while ((long)__builtin_amdgcn_s_memtime() < until)
-            __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     RowCarry3 X, Y; // alternate between "written by A" and "read by B": no copies when the march advances
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -360,11 +266,7 @@ int nsdg_launch_mevp_fused3_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg)
 {
-#ifdef NSDG_EXP_NOHALO
-    const int ncw = nsdg_div_up(ctx->nx, 64);
-#else
     const int ncw = nsdg_div_up(ctx->nx, 59); // 59 owned columns per wave
-#endif
     const int rowsB = j0b < j1b ? j1b - j0b : 0;
     int R = ctx->strip_rows;
     if (R <= 0) {

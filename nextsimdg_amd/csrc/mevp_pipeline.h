@@ -1,0 +1,64 @@
+// mevp_pipeline.h -- pieces shared by the pipelined multi-iteration mEVP kernels (mevp_fused3.hip: three stages in one
+// wave; mevp_fused4.hip: four stages on the four waves of a workgroup): the per-lane march constants, the contributions a
+// row carries to the row above it, the update of the four owned nodes of an element row and the gather of an element's
+// nine nodal velocities from the owned nodes of its row, of the row above and of the right neighbour lane.  The same
+// inlined functions in every variant keep their results bit-identical.
+#pragma once
+#include "mevp_common.h"
+
+namespace nsdg_mevp_detail {
+
+struct MarchConst3 {
+    NodalConsts K;
+    int nx, ny, y0, y1, tbeg, tendA, tendB, ix, ntx, nn, lane;
+    long nplane; // doubles between two pair planes of the packed nodal coefficients
+    bool own, hasL, lastcol;
+    double hx, hy, ihx, ihy, iarea, ialpha, dmin2;
+};
+
+// contributions of a row to its top nodes, carried to the next row of the march
+struct TopCarry3 {
+    double x6 = 0., y6 = 0., x7 = 0., y7 = 0., xl8 = 0., yl8 = 0.; // 6: top-left, 7: top-mid of my column, 8 of the left column
+};
+
+// the four owned nodes of one element row from the carried contributions of the row below (`carry`), the
+// contributions of this row (cx, cy) and the left neighbour's right-column contributions
+__device__ __forceinline__ void owned_node_updates(const MarchConst3& M, bool hasB, const double (&c)[4][6], const double (&uu)[4],
+    const double (&vv)[4], const TopCarry3& carry, const double (&cx)[9], const double (&cy)[9], double (&un)[4], double (&vn)[4])
+{
+    const double l2x = lane_from_left(cx[2]), l2y = lane_from_left(cy[2]);
+    const double l5x = lane_from_left(cx[5]), l5y = lane_from_left(cy[5]);
+    if (M.hasL && hasB)
+        node_update_packed(M.K, c[0], uu[0], vv[0], ((carry.xl8 + carry.x6) + l2x) + cx[0], ((carry.yl8 + carry.y6) + l2y) + cy[0], 9. * M.iarea,
+            un[0], vn[0]);
+    else
+        un[0] = vn[0] = 0.;
+    if (hasB)
+        node_update_packed(M.K, c[1], uu[1], vv[1], carry.x7 + cx[1], carry.y7 + cy[1], 4.5 * M.iarea, un[1], vn[1]);
+    else
+        un[1] = vn[1] = 0.;
+    if (M.hasL)
+        node_update_packed(M.K, c[2], uu[2], vv[2], l5x + cx[3], l5y + cy[3], 4.5 * M.iarea, un[2], vn[2]);
+    else
+        un[2] = vn[2] = 0.;
+    node_update_packed(M.K, c[3], uu[3], vv[3], cx[4], cy[4], 2.25 * M.iarea, un[3], vn[3]);
+}
+
+__device__ __forceinline__ void carry_top(TopCarry3& carry, const double (&cx)[9], const double (&cy)[9])
+{
+    carry.x6 = cx[6], carry.y6 = cy[6], carry.x7 = cx[7], carry.y7 = cy[7];
+    carry.xl8 = lane_from_left(cx[8]), carry.yl8 = lane_from_left(cy[8]);
+}
+
+// u at the 9 nodes of an element from the 4 owned nodes of its row (lo), the two bottom nodes of the row
+// above (hi0 = V, hi1 = EX) and the right neighbour lane (node column 2*nx is the right boundary)
+__device__ __forceinline__ void gather_nodes(const MarchConst3& M, const double (&lo)[4], double hi0, double hi1, double (&w)[9])
+{
+    w[0] = lo[0], w[1] = lo[1], w[3] = lo[2], w[4] = lo[3], w[6] = hi0, w[7] = hi1;
+    const double r2 = lane_from_right(lo[0]), r5 = lane_from_right(lo[2]), r8 = lane_from_right(hi0);
+    w[2] = M.lastcol ? 0. : r2;
+    w[5] = M.lastcol ? 0. : r5;
+    w[8] = M.lastcol ? 0. : r8;
+}
+
+} // namespace nsdg_mevp_detail

@@ -10,7 +10,7 @@ send/recv of ghost rows through torch.distributed (backend "nccl" = RCCL over xG
   per mEVP sub-iteration : velocity node rows   up: 2 rows x (u,v) x (2nx+1)     down: 1 row x (u,v)
    (single-iteration       (the stress of the ghost row below is NOT exchanged: it is updated
     kernel)                 redundantly by the rank itself, bit-identically to its owner)
-  per GROUP of k passes  : kernels with v = 2 or 3 sub-iterations per pass and ghost depth (d, d-1), d = v k:
+  per GROUP of k passes  : kernels with v = 2, 3 or 4 sub-iterations per pass and ghost depth (d, d-1), d = v k:
    (v k sub-iterations)    d stress rows + 2d node rows travel up, d-1 stress rows + 2d-1 node rows down.
                            Between two exchanges a rank runs k passes on a row range that shrinks by v rows
                            on each side per pass -- the ghost rows are advanced redundantly, bit-identically
@@ -272,18 +272,17 @@ class DynamicsCore:
         # two exchanges as one hipGraph.
         self.native, self.use_graph = native, use_graph
         self._calls = {}
-        # v sub-iterations per kernel pass (v = 3: variant 3, v = 2: variant 2) need a (v k, v k - 1) ghost depth
+        # v sub-iterations per kernel pass (v = 4: variant 4, v = 3: variant 3, v = 2: variant 2) need a (v k, v k - 1) ghost depth
         # for k passes between two exchanges; a single domain has no ghosts at all.  All variants produce
         # bit-identical results, so a variant-3 context on a (2k, 2k-1) block simply uses the two-iteration kernel.
         variant = getattr(ops, "mevp_variant", None)
         self.per_pass = 1
-        for v in (3, 2):
+        for v in (4, 3, 2):
             deep = blk.depth_below >= v and blk.depth_below % v == 0 and blk.depth_above == blk.depth_below - 1
             if variant is not None and variant >= v and (blk.world == 1 or deep):
                 self.per_pass = v
                 break
         self.two_per_pass = self.per_pass >= 2  # the ghost zones hold stress rows as well as velocity rows
-        self.three_per_pass = self.per_pass == 3
         self.group_passes = blk.depth_below // self.per_pass if (self.per_pass >= 2 and blk.world > 1) else 1  # passes between two exchanges
         self.halo = exchanger if exchanger is not None else HaloExchanger(blk)
         nx, ny = blk.nx, blk.ny
@@ -294,10 +293,7 @@ class DynamicsCore:
         self.s = [ops.private_zeros(8, ny, nx, device) for _ in range(3)]
         self.sb = [ops.private_zeros(8, ny, nx, device) for _ in range(3)]
         self.pg = ops.private_zeros(9, ny, nx, device)
-        if os.environ.get("NSDG_EXP_UVPAIR"):  # timing experiment only (csrc/mevp_fused3.hip): [u | v] of a buffer in ONE allocation
-            (self.u, self.v), (self.ub, self.vb) = z(2, *nodal).unbind(0), z(2, *nodal).unbind(0)
-        else:
-            self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
+        self.u, self.v, self.ub, self.vb = z(*nodal), z(*nodal), z(*nodal), z(*nodal)
         self.ua, self.va = z(*nodal), z(*nodal)
         self.uo, self.vo = z(*nodal), z(*nodal)
         self.packed = z(nodal[0] * nodal[1] * 8)  # per-step momentum coefficients, 8 per node
@@ -371,8 +367,10 @@ class DynamicsCore:
         n, v = self.nsub, self.per_pass
         if v == 1:
             return 0, 0, n
-        full, rest = n // v, n % v
-        return full, (rest // 2 if v == 3 else 0), (rest % 2 if v == 3 else rest)
+        full, rest = n // v, n % v  # the remainder runs through the kernels with fewer sub-iterations per pass: 3 -> one
+        if rest == 3:  # three-iteration pass (counted with the "twos": a minority launch), 2 -> one two-iteration pass, 1 -> a single
+            return full, 1, 0
+        return full, rest // 2, rest % 2
 
     def subcycle(self):
         """the nsub mEVP sub-iterations of one model step (ghost rows exchanged as the ghost depth requires)"""
@@ -391,7 +389,7 @@ class DynamicsCore:
             # of nsub after the v-passes is done by a two-iteration pass and / or single sub-iterations.
             k = self.group_passes
             split_ok = self.overlap and b.world > 1 and (b.j1 - b.j0) >= b.depth_below + b.depth_above + 5
-            for v in ((self.per_pass, 2) if self.per_pass == 3 else (2,)):
+            for v in range(self.per_pass, 1, -1):
                 while self.nsub - it >= v:
                     m = min(k, (self.nsub - it) // v)
                     for i in range(1, m + 1):
@@ -445,7 +443,7 @@ class DynamicsCore:
             self.halo.rows_exchange_finish(*pending)
 
     def _pass_calls(self, v, split, ext=0):
-        """launches of one pass of v (2 or 3) sub-iterations for the current ping-pong parity (bound once, cached).
+        """launches of one pass of v (2, 3 or 4) sub-iterations for the current ping-pong parity (bound once, cached).
         ext > 0: a pass inside a group, one launch over the owned rows extended by v*ext ghost rows on each
         side.  ext == 0 and split: the rows whose results travel to the neighbours first, the interior last"""
         key = (self.u.data_ptr(), self.s[0].data_ptr(), split, v, ext)

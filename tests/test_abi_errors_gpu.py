@@ -33,7 +33,7 @@ def test_bad_grid_and_params(ctx):
     with pytest.raises(abi.NsdgError, match="alpha and beta"):
         ctx.set_mevp_params(ctx.mevp_default_params(alpha=0.0))
     with pytest.raises(abi.NsdgError):
-        ctx.set_mevp_variant(4)
+        ctx.set_mevp_variant(5)
     with pytest.raises(abi.NsdgError):
         ctx.set_mevp_occupancy(4)
 

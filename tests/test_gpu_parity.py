@@ -612,6 +612,86 @@ def test_mevp_three_iterations_per_pass_equals_three_single_passes_bitwise(ctx):
     ctx.set_mevp_params(ctx.mevp_default_params())
 
 
+def test_mevp_four_iterations_per_pass_equals_four_single_passes_bitwise(ctx):
+    """variant 4 runs four sub-iterations per pass, one pipeline stage per wave of a four-wave workgroup (hand-over
+    through LDS, one workgroup barrier per march step); it must reproduce four launches of the single-iteration
+    fused kernel bit for bit, for any strip height, for widths around the 57 owned columns of a workgroup, for
+    sub-ranges of rows, for two ranges in one launch, and inside nsdg_mevp_subcycle (remainders of 3, 2 and 1
+    sub-iterations through the kernels of variants 3, 2 and 1)"""
+    for (nx, ny) in ((130, 45), (57, 9), (58, 13), (200, 3), (56, 1), (7, 5), (115, 22)):
+        b = Box(ctx, nx, ny)
+        rng = np.random.default_rng(59)
+        u, v, s = mevp_state(b, rng)
+        pg_o = O.ice_strength(nx, ny, b.po, b.H, b.A)
+        cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+        tax, tay = O.wind_stress(b.po, b.ua, b.va)
+        packed = pack(ctx, 120.0, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga)
+        pg = tdev(pg_o)
+        s_in = [tdev(x) for x in s]
+        ctx.set_mevp_variant(1)
+        ctx.set_mevp_strip_rows(0)
+        cur = s_in + [dev(u), dev(v)]
+        for _ in range(4):
+            nxt = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+            ctx.mevp_iterate(0, 0, ny, cur[:3], nxt[:3], (cur[3], cur[4]), (nxt[3], nxt[4]), packed, pg)
+            cur = nxt
+        ref = cur
+        ctx.set_mevp_variant(4)
+        for rows in (1, 2, 5, 16, 64, 0):
+            ctx.set_mevp_strip_rows(rows)
+            out = [torch.zeros_like(x) for x in s_in] + [torch.full_like(dev(u), 7.0), torch.full_like(dev(v), 7.0)]
+            ctx.mevp_iterate4(0, ny, s_in, out[:3], (dev(u), dev(v)), (out[3], out[4]), packed, pg)
+            for k, (a, c) in enumerate(zip(ref, out)):
+                assert torch.equal(a, c), (nx, ny, rows, k, float((a - c).abs().max()))
+        if ny >= 13:  # a sub-range with ghost rows on both sides: rows [4, ny - 3)
+            for rows in (0, 3):
+                ctx.set_mevp_strip_rows(rows)
+                out = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+                ctx.mevp_iterate4(4, ny - 3, s_in, out[:3], (dev(u), dev(v)), (out[3], out[4]), packed, pg)
+                assert torch.equal(abi.untile(out[0], nx)[:, 4:ny - 3], abi.untile(ref[0], nx)[:, 4:ny - 3])
+                assert torch.equal(out[3][8:2 * (ny - 3)], ref[3][8:2 * (ny - 3)])
+        if ny >= 22:  # two disjoint ranges in one launch == two launches
+            ctx.set_mevp_strip_rows(0)
+            ra, rb = (ny - 7, ny - 3), (4, 9)
+            one = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+            two = [torch.zeros_like(x) for x in s_in] + [torch.zeros_like(dev(u)), torch.zeros_like(dev(v))]
+            ctx.mevp_iterate4_pair(ra, rb, s_in, one[:3], (dev(u), dev(v)), (one[3], one[4]), packed, pg)
+            for r in (ra, rb):
+                ctx.mevp_iterate4(r[0], r[1], s_in, two[:3], (dev(u), dev(v)), (two[3], two[4]), packed, pg)
+            assert all(torch.equal(a, c) for a, c in zip(one, two))
+            assert torch.equal(abi.untile(one[1], nx)[:, 4:9], abi.untile(ref[1], nx)[:, 4:9])
+            assert torch.equal(one[4][2 * (ny - 7):2 * (ny - 3)], ref[4][2 * (ny - 7):2 * (ny - 3)])
+        # against the oracle
+        so = [x.copy() for x in s]
+        uo_, vo_ = u.copy(), v.copy()
+        O.mevp_subcycle(nx, ny, b.bt.hx, b.bt.hy, 120.0, 4, b.po, so, uo_, vo_, 0.5 * u, 0.5 * v, tax, tay, b.uo, b.vo, cgh, cga, pg_o)
+        assert_close(host(ref[3]), uo_, 1e-10, 1e-12 * np.max(np.abs(uo_)), "u after four sub-iterations")
+        assert_close(thost(ref[0], nx), so[0], 1e-10, 1e-12 * np.max(np.abs(so[0])), "s11 after four sub-iterations")
+    # whole sub-cycle: 4-passes + remainders 3 (nsub = 11), 2 (10), 1 (9), 0 (8) against variant 1
+    b = Box(ctx, 70, 33, alpha=300.0, beta=300.0)
+    nx, ny = b.nx, b.ny
+    pg = O.ice_strength(nx, ny, b.po, b.H, b.A)
+    cgh, cga = O.dg_to_cg(nx, ny, b.H), O.dg_to_cg(nx, ny, b.A)
+    tax, tay = O.wind_stress(b.po, b.ua, b.va)
+    shape = (2 * ny + 1, 2 * nx + 1)
+    for nsub in (11, 10, 9, 8):
+        res = {}
+        for variant in (1, 4):
+            ctx.set_mevp_variant(variant)
+            du, dv = dev(np.zeros(shape)), dev(np.zeros(shape))
+            ds = [tdev(np.zeros((8, ny, nx))) for _ in range(3)]
+            scratch = torch.zeros(10 * du.numel() + 3 * ds[0].numel(), dtype=torch.float64, device="cuda")
+            ctx.mevp_subcycle(120.0, nsub, ds, du, dv, du.clone(), dv.clone(), dev(tax), dev(tay), dev(b.uo), dev(b.vo), dev(cgh), dev(cga),
+                              tdev(pg), scratch)
+            res[variant] = (du, dv, ds)
+        assert torch.equal(res[1][0], res[4][0]) and torch.equal(res[1][1], res[4][1]), nsub
+        assert all(torch.equal(a, c) for a, c in zip(res[1][2], res[4][2])), nsub
+        assert float(res[4][0].abs().max()) > 0
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
+    ctx.set_mevp_strip_rows(0)
+    ctx.set_mevp_params(ctx.mevp_default_params())
+
+
 def test_mevp_subcycle_variant2_matches_oracle(ctx):
     ctx.set_mevp_variant(2)
     b = Box(ctx, 48, 40, alpha=300.0, beta=300.0)

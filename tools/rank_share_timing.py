@@ -54,7 +54,7 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
     alpha = bt.stable_alpha(dt)
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
     rank = world // 2
-    v = min(ctx.mevp_variant, 3)  # sub-iterations per kernel pass
+    v = min(ctx.mevp_variant, 4)  # sub-iterations per kernel pass
     depth = (v * kpass, v * kpass - 1)
     blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
     exchanger = None
