@@ -587,7 +587,7 @@ def main():
                                depth[0], depth[1], core.group_passes,
                                " (chosen in the warm-up: %s)" % ", ".join("%d passes %.3f ms/step" % (k_, t_["ms_per_step"]) for k_, t_ in sorted(tune.items())) if tune else "",
                                args.halo) if eff_world > 1 else ""),
-                       "mevp_passes": "%s sub-iteration%s per kernel pass" % ({3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
+                       "mevp_passes": "%s sub-iteration%s per kernel pass" % ({4: "four", 3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
                        "mevp_variant": args.variant if args.variant is not None else "default",
                        "driver": ("native (nsdg_rb_mevp_run / nsdg_rb_transport_run)" + (" + hipGraph replay" if args.graph else "")) if native else "python sequence",
                        "parity": "dynamics parity unpinned (the reference snapshot has no DG/mEVP code); self-check of this run: "

@@ -321,6 +321,12 @@ int nsdg_comm_rank(nsdg_ctx* ctx, int32_t* rank, int32_t* world);
  * NSDG_COMM_TIMEOUT_S, else 300.  May be called before or after nsdg_comm_init*. */
 int nsdg_comm_deadline_set(nsdg_ctx* ctx, double seconds);
 
+/* Rehearsal aid for a box with ONE GPU (tools/rank_share_timing.py, bench.py's loopback rehearsal): a loopback exchange
+ * has no wire time, so a kernel that spins for delay_us + bytes of the larger direction / gbs (GB/s per direction) is put on
+ * the communication stream between pack and transport of every exchange.  0, 0 = off (the default unless the environment
+ * variables NSDG_HALO_DELAY_US / NSDG_HALO_SIM_GBS are set when the communicator is created: they are read once, there). */
+int nsdg_comm_simulate_wire(nsdg_ctx* ctx, double delay_us, double gbs);
+
 /* A plan fixes what ONE kind of exchange moves: for each of the four directions a list of contiguous blocks of
  * doubles in the caller's arrays (row blocks: ghost rows are contiguous in every layout of this ABI).  up_send
  * travels to rank_above and is received there as from_below, down_send travels to rank_below and arrives as

@@ -115,6 +115,7 @@ SYMBOLS = {
     "nsdg_comm_finalize": (C.c_int, [VP]),
     "nsdg_comm_rank": (C.c_int, [VP, C.POINTER(I32), C.POINTER(I32)]),
     "nsdg_comm_deadline_set": (C.c_int, [VP, D]),
+    "nsdg_comm_simulate_wire": (C.c_int, [VP, D, D]),
     "nsdg_halo_plan_create": (C.c_int, [VP, I32, I32, I32, C.POINTER(HaloSeg), I32, C.POINTER(HaloSeg), I32, C.POINTER(HaloSeg), I32,
                                         C.POINTER(HaloSeg), C.POINTER(VP)]),
     "nsdg_halo_plan_destroy": (C.c_int, [VP]),
@@ -323,6 +324,10 @@ class Context:
     def comm_deadline(self, seconds):
         """upper bound on any wait for a neighbour rank (0 = for ever)"""
         self._call(self.lib.nsdg_comm_deadline_set(self.h, float(seconds)))
+
+    def comm_simulate_wire(self, delay_us=0.0, gbs=0.0):
+        """rehearsal aid: every exchange spins for delay_us + bytes / gbs on the communication stream (0, 0 = off)"""
+        self._call(self.lib.nsdg_comm_simulate_wire(self.h, float(delay_us), float(gbs)))
 
     def num_cus(self):
         import torch

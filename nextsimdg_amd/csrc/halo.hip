@@ -159,6 +159,8 @@ struct nsdg_comm {
     hipStream_t stream = nullptr; // communication stream
     int nplans = 0; // plans created so far (their indices match across the ranks of a group)
     bool broken = false; // a wait ran into the deadline: the streams may never drain, abort instead of draining
+    // rehearsal aid (nsdg_comm_simulate_wire): simulated transfer time per exchange, fixed part and bandwidth per direction
+    double sim_delay_us = 0., sim_gbs = 0.;
 };
 
 // ---------------------------------------------------------------------------------------------- plans
@@ -250,14 +252,21 @@ __global__ void halo_delay_kernel(long ticks)
     while ((long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
     }
 }
-long halo_delay_ticks(long bytes_up, long bytes_down)
+long halo_delay_ticks(const nsdg_comm* c, long bytes_up, long bytes_down)
 {
-    const char* v = std::getenv("NSDG_HALO_DELAY_US"); // read at every exchange: tests switch it on and off
-    const char* b = std::getenv("NSDG_HALO_SIM_GBS");
-    double us = (v && *v) ? std::atof(v) : 0.;
-    if (b && *b && std::atof(b) > 0.)
-        us += 1e-3 * (double)std::max(bytes_up, bytes_down) / std::atof(b); // bytes / (GB/s) = ns
+    double us = c->sim_delay_us;
+    if (c->sim_gbs > 0.)
+        us += 1e-3 * (double)std::max(bytes_up, bytes_down) / c->sim_gbs; // bytes / (GB/s) = ns
     return (long)(100. * us);
+}
+// the environment is read ONCE, when the communicator is created (NSDG_HALO_DELAY_US, NSDG_HALO_SIM_GBS: the rehearsals
+// of tools/rank_share_timing.py and bench.py); a running process changes the values through nsdg_comm_simulate_wire
+void wire_simulation_from_env(nsdg_comm* c)
+{
+    const char* v = std::getenv("NSDG_HALO_DELAY_US");
+    const char* b = std::getenv("NSDG_HALO_SIM_GBS");
+    c->sim_delay_us = (v && *v) ? std::max(std::atof(v), 0.) : 0.;
+    c->sim_gbs = (b && *b) ? std::max(std::atof(b), 0.) : 0.;
 }
 
 // adds the time of the exchange recorded in ring slot k to the plan's totals; wait: block until it has finished
@@ -337,6 +346,7 @@ static int comm_common(nsdg_ctx* ctx, int32_t rank, int32_t world)
     nsdg_comm* c = new nsdg_comm();
     c->rank = rank;
     c->world = world;
+    wire_simulation_from_env(c);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         nsdg_set_error("nsdg_comm_init: hipStreamCreateWithFlags failed");
@@ -532,11 +542,18 @@ int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* p)
         return NSDG_ERR_STATE;
     }
     nsdg_comm* c = ctx->comm;
+    if (c->broken) {
+        nsdg_set_error("nsdg_halo_start: the communicator is broken (an earlier wait ran into the deadline)");
+        return NSDG_ERR_COMM;
+    }
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     // the exchange sees everything the compute stream has been given so far
     NSDG_CHECK_HIP(hipEventRecord(p->ev_ready, ctx->stream));
     NSDG_CHECK_HIP(hipStreamWaitEvent(c->stream, p->ev_ready, 0));
-    harvest_slot(p, p->slot, true); // the ring has come round (32 exchanges ago: long finished)
+    // the ring has come round.  NEVER block here: the host runs many exchanges ahead of the device, and with a dead RCCL
+    // neighbour the event of an exchange 32 starts ago never fires -- an exchange that has not finished gives its slot
+    // up and is counted as untimed
+    harvest_slot(p, p->slot, false);
     NSDG_CHECK_HIP(hipEventRecord(p->t0[p->slot], c->stream)); // "the data to send is ready"
     if (c->local && !p->loopback) {
         // the neighbours must have copied the previous contents of the send buffers out
@@ -556,7 +573,7 @@ int nsdg_halo_start(nsdg_ctx* ctx, nsdg_halo* p)
     if (rc != NSDG_OK)
         return rc;
     if (p->n_up || p->n_down) { // rehearsal only: simulated transfer time
-        const long ticks = halo_delay_ticks(p->n_up * (long)sizeof(double), p->n_down * (long)sizeof(double));
+        const long ticks = halo_delay_ticks(c, p->n_up * (long)sizeof(double), p->n_down * (long)sizeof(double));
         if (ticks > 0)
             hipLaunchKernelGGL(halo_delay_kernel, dim3(1), dim3(1), 0, c->stream, ticks);
     }
@@ -615,6 +632,10 @@ int nsdg_halo_finish(nsdg_ctx* ctx, nsdg_halo* p)
         return NSDG_ERR_STATE;
     }
     nsdg_comm* c = ctx->comm;
+    if (c->broken) {
+        nsdg_set_error("nsdg_halo_finish: the communicator is broken (an earlier wait ran into the deadline)");
+        return NSDG_ERR_COMM;
+    }
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     p->started = false;
     if (c->local && !p->loopback) {
@@ -660,9 +681,14 @@ int nsdg_halo_stats_get(nsdg_ctx* ctx, nsdg_halo* p, nsdg_halo_stats* out, int32
 {
     NSDG_CHECK_ARG(ctx && p && p->ctx == ctx && out, "plan does not belong to this context");
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    if (!(ctx->comm && ctx->comm->broken))
+    if (!(ctx->comm && ctx->comm->broken)) {
+        // the query waits for the last exchanges -- but not beyond the communicator's deadline
+        const int rc = ctx->comm ? nsdg_comm_bounded_drain(ctx) : NSDG_OK;
+        if (rc != NSDG_OK)
+            return rc;
         for (int k = 0; k < nsdg_halo::RING; ++k)
-            harvest_slot(p, k, true);
+            harvest_slot(p, k, false);
+    }
     out->exchanges = p->n_timed + p->n_untimed;
     out->untimed = p->n_untimed;
     out->ms = p->ms_total;
@@ -672,6 +698,19 @@ int nsdg_halo_stats_get(nsdg_ctx* ctx, nsdg_halo* p, nsdg_halo_stats* out, int32
         p->n_timed = p->n_untimed = 0;
         p->ms_total = 0.;
     }
+    return NSDG_OK;
+}
+
+int nsdg_comm_simulate_wire(nsdg_ctx* ctx, double delay_us, double gbs)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(delay_us >= 0. && gbs >= 0., "delay and bandwidth must be >= 0 (0 = off)");
+    if (!ctx->comm) {
+        nsdg_set_error("nsdg_comm_simulate_wire: the context has no communicator");
+        return NSDG_ERR_STATE;
+    }
+    ctx->comm->sim_delay_us = delay_us;
+    ctx->comm->sim_gbs = gbs;
     return NSDG_OK;
 }
 

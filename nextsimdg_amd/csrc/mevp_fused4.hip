@@ -3,16 +3,32 @@
 // Variant 3 runs its three stages one after the other in ONE wave: 486 registers (a sixth of its vector instructions
 // only move values between the two halves of the register file), 1024 waves to fill the chip and therefore short strips
 // that pay the pipeline fill again and again.  Here a workgroup of four waves -- one per SIMD of a CU -- marches through a
-// strip of 57 owned columns x R rows, and wave s performs sub-iteration p+s:
-//     at march step t wave s works on element row  t - 2 s
-// (two rows of skew per stage: wave s needs u^{p+s-1} on the bottom nodes of the row above, which wave s-1 produced one
-// step earlier, and everything of its own row, produced two steps earlier).  The hand-over between two waves -- 24 stress
-// coefficients and u, v at the 4 owned nodes per lane -- goes through LDS: three rotating slots of 16 KB per hand-over
-// (the row being written, the row above and the row being read), 144 KB per workgroup, ONE workgroup barrier per march
-// step.  Wave 0 reads stress and velocity from memory, wave 3 writes them; every wave reads the ice strength and the
-// packed nodal coefficients of its row itself (waves 1-3: L2 / Infinity Cache hits), one march step AHEAD of their use.
-// 256 workgroups fill the chip, so strips are four times taller than variant 3's, and a pass streams the stress once per
-// FOUR sub-iterations (776 B per element and pass = 194 B per element and sub-iteration).
+// strip of 57 owned columns x R rows, and wave s performs sub-iteration p+s on the element row  t - LAG[s]  at march step t,
+// LAG = {0, 2, 5, 8}.  The hand-over between two waves -- 24 stress coefficients and u, v at the 4 owned nodes per lane --
+// goes through LDS: three rotating slots of 16 KB per hand-over, 144 KB per workgroup, 16-byte accesses.  Wave 0 reads
+// stress and velocity from memory, wave 3 writes them; every wave reads the ice strength and the packed nodal
+// coefficients of its row itself (waves 1-3: L2 / Infinity Cache hits).  256 workgroups fill the chip, so strips are four
+// times taller than variant 3's, and a pass streams the stress once per FOUR sub-iterations (776 B per element and pass =
+// 194 B per element and sub-iteration).
+//
+// Synchronisation: ONE workgroup barrier per march step and wave -- but every wave meets it at a DIFFERENT point of its
+// step.  A step is four quarters (Q0 inputs: LDS reads or the values fetched from memory, node gather; Q1 stress update;
+// Q2 nodal contributions and node updates; Q3 outputs: LDS writes or global stores); wave s calls the barrier after
+// quarter BAR[s] = {3, 0, 1, 2}.  The waves therefore run a quarter of a step apart: while one issues its loads the others
+// compute, instead of all four hitting the vector-memory pipeline and the LDS of the CU at the same time (the aligned
+// first version spent half of every step in those collisions: profiles/r04_fused4_development.md).  Why this is race-free
+// with three slots (barrier #i = the barrier call inside step i of each wave; all LDS reads of a step are in Q0, all LDS
+// writes in Q3, and the barrier waits for the wave's own LDS traffic first):
+//   * visibility: stage s reads in Q0 of step i the rows  rho = i - LAG[s]  and  rho + 1  of stage s-1.  Row rho + 1 was
+//     written in Q3 of step i - LAG[s] + LAG[s-1] + 1 of that wave: for s = 1 that is step i - 1 and Q3 comes before the
+//     producer's barrier #(i-1); for s = 2, 3 it is step i - 2 and Q3 comes after its barrier #(i-2) but before #(i-1).
+//     The consumer's Q0 of step i comes after its barrier #(i-1).
+//   * slot reuse: the producer overwrites the slot of row rho with row rho + 3.  For s = 1 that happens in step i + 1 of
+//     wave 0, after its barrier #i; for s = 2, 3 in step i of waves 1, 2, after their barrier #i (their barrier comes before
+//     Q3).  The consumer's reads of row rho are complete before its barrier #i.
+// Inputs from memory are requested one row ahead, each group right after the values of the current row have been
+// consumed (the stress after the relaxation, the nodal coefficients after the node updates, ...): ONE register set is
+// always either waiting to be used or in flight, instead of two alternating sets.
 //
 // Redundancy instead of synchronisation between workgroups, one more level than variant 3: a workgroup owns 57 of its 64
 // columns (lanes 0-3 recompute the four columns to its left, lanes 61-63 the three to its right), and a strip of R rows
@@ -22,6 +38,10 @@
 // Row ranges: a launch updates the owned element rows [j0, j1) and reads four rows below and three above them.  Where
 // those rows do not exist the edge of the local array is the physical boundary.
 #include "mevp_pipeline.h"
+
+#ifdef NSDG_STAMPS
+__device__ unsigned nsdg_stamp_acc4[64 * 16]; // 16 sampled workgroups x 4 stages x 16 values
+#endif
 
 namespace nsdg_mevp_detail {
 
@@ -33,122 +53,174 @@ struct StressPtrs4 {
 constexpr int F4_OWNED = 57, F4_LEFT = 4; // lanes 4 .. 60 own a column
 constexpr int F4_SLOTS = 3; // rotating slots per hand-over
 constexpr int F4_HAND = 32; // doubles per lane and slot: 24 stress coefficients + u, v at the 4 owned nodes
-constexpr int F4_SLOT = F4_HAND * 64; // doubles per slot
+constexpr int F4_SLOT = F4_HAND * 64; // doubles per slot; value k of lane l at (k / 2) * 128 + 2 l + k % 2 (16-byte pairs)
 constexpr int F4_LDS = 3 * F4_SLOTS * F4_SLOT; // three hand-overs
+constexpr int F4_LAG_TOTAL = 8; // stage 3 works on row t - 8
+constexpr int F4_STEPS_EXTRA = 7 + F4_LAG_TOTAL; // a strip of R rows takes R + 15 march steps
 
-// what a wave fetches from memory for one element row, one march step before it is used
+// what a wave holds from memory for the row it works on next (requested right after the current row's values were used)
 struct Fetch4 {
     double P[9]; // ice strength at the Gauss points
     double c[4][6]; // packed momentum coefficients of the 4 owned nodes (V, EX, EY, C)
     double s11[8], s12[8], s22[8]; // stage 0 only: the stress the pass starts from
-    double ul[9], vl[9]; // stage 0 only: the velocity the pass starts from at the 9 nodes of the element
+    double ub[3], vb[3], um[3], vm[3], ut[3], vt[3]; // stage 0 only: u, v of the pass's start on the three node rows of the element row
 };
 
 struct Stage4 {
     int s; // pipeline stage of this wave = sub-iteration p + s
+    int lag; // this stage works on row t - lag at march step t
+    int bar; // the quarter after which this wave meets the workgroup barrier
     int first, last; // element rows this stage works on
     int last_prev; // last row of the previous stage (the row above `last` exists unless the strip ends at the physical top)
     int upd0; // node updates from this row on (the first row of a stage only feeds the carried contributions)
 };
 
-__device__ __forceinline__ void fetch_row4(const MarchConst3& M, const Stage4& G, int row, Fetch4& f, const StressPtrs4& S,
-    const double* __restrict__ u_old, const double* __restrict__ v_old, const double* __restrict__ packed, const double* __restrict__ pg)
-{
-    const int ix = M.ix, nn = M.nn;
-    const long nV = (long)(2 * row) * nn + 2 * ix;
-    if (G.s == 0) { // wave-uniform
-#pragma unroll
-        for (int a = 0; a < 9; ++a) {
-            const long n = nV + (a / 3) * nn + a % 3;
-            f.ul[a] = u_old[n];
-            f.vl[a] = v_old[n];
-        }
-    }
-    tile_load9(pg, tile_off(ix, row, M.ntx, 9), ix & 63, f.P);
-    if (G.s == 0) {
-        const long ts = tile_off(ix, row, M.ntx, 8);
-        tile_load8(S.i11, ts, f.s11);
-        tile_load8(S.i12, ts, f.s12);
-        tile_load8(S.i22, ts, f.s22);
-    }
-    load_nodal(packed, M.nplane, nV, f.c[0]);
-    load_nodal(packed, M.nplane, nV + 1, f.c[1]);
-    load_nodal(packed, M.nplane, nV + nn, f.c[2]);
-    load_nodal(packed, M.nplane, nV + nn + 1, f.c[3]);
-}
-
-// all LDS traffic of the step has landed and every wave of the workgroup has arrived; global loads and stores stay in flight
+// all LDS traffic of this wave has landed and every wave of the workgroup has arrived; global loads and stores stay in flight
 __device__ __forceinline__ void handover_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// One march step of one wave: fetch the inputs of the NEXT row of this stage into `nxt`, work on the current row with the
-// inputs `cur` fetched one step ago, meet the other three waves.
-__device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& G, int t, Fetch4& cur, Fetch4& nxt, TopCarry3& carry,
-    double* __restrict__ lds, const StressPtrs4& S, const double* __restrict__ u_old, const double* __restrict__ v_old,
-    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+__device__ __forceinline__ double2 lds_pair(const double* slot, int k) { return *reinterpret_cast<const double2*>(slot + k * 128); }
+__device__ __forceinline__ void lds_pair(double* slot, int k, double a, double b) { *reinterpret_cast<double2*>(slot + k * 128) = make_double2(a, b); }
+
+// the three nodes n, n+1, n+2 of one node row: the first two as ONE 16-byte access (node rows start at odd multiples of
+// 8 bytes on odd rows: global memory instructions only need 4-byte alignment), the third as an 8-byte access -- 8
+// instead of 12 vector-memory instructions per element row, and they are what bounds the loader wave
+typedef double nsdg_pair8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void fetch_nodes4(const double* __restrict__ w, long n, double (&o)[3])
 {
-    const int row = t - 2 * G.s;
-    if (row + 1 >= G.first && row + 1 <= G.last) // wave-uniform
-        fetch_row4(M, G, row + 1, nxt, S, u_old, v_old, packed, pg);
-    if (row >= G.first && row <= G.last) { // wave-uniform
-        double s11[8], s12[8], s22[8], uu[4], vv[4], ul[9], vl[9];
-        if (G.s == 0) {
+    const nsdg_pair8 a = *reinterpret_cast<const nsdg_pair8*>(w + n);
+    o[0] = a.x, o[1] = a.y, o[2] = w[n + 2];
+}
+
+// One march step of one wave.  FIRST: the loader wave (stage 0, inputs from memory; a code path of its own so that its
+// register allocation and the compiler's bookkeeping of outstanding loads are not entangled with the other stages').
+// The step is straight-line code: a wave whose stage has not reached its first row yet, or is past its last, works on
+// that row again and again with whatever the hand-over slots hold and only SUPPRESSES ITS OUTPUTS -- branches around
+// the loads made the compiler wait for loads it had just issued (profiles/r04_fused4_development.md).
+template <bool FIRST>
+__device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& G, int t, Fetch4& f, TopCarry3& carry, double* __restrict__ lds,
+    const StressPtrs4& S, const double* __restrict__ u_old, const double* __restrict__ v_old, const double* __restrict__ packed,
+    const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new NSDG_STAMP_ARGS)
+{
+    const int stage = FIRST ? 0 : G.s, bar = FIRST ? 3 : G.bar;
+    const int rowraw = t - (FIRST ? 0 : G.lag);
+    const bool active = rowraw >= G.first && rowraw <= G.last; // wave-uniform
+    const int row = min(max(rowraw, G.first), G.last);
+    const int nrow = min(max(rowraw + 1, G.first), G.last); // the row this stage works on in the NEXT step: its inputs are requested during this one
+    const int ix = M.ix, nn = M.nn;
+    const long nVn = (long)(2 * nrow) * nn + 2 * ix; // vertex node of the next row
+    double s11[8], s12[8], s22[8], uu[4], vv[4], ul[9], vl[9], un[4], vn[4];
+    NSDG_STAMP(0);
+    // ------------------------------------------------------------------------------------------ Q0: inputs of the row
+    if (FIRST) {
 #pragma unroll
-            for (int a = 0; a < 9; ++a)
-                ul[a] = cur.ul[a], vl[a] = cur.vl[a];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                s11[i] = cur.s11[i], s12[i] = cur.s12[i], s22[i] = cur.s22[i];
-            uu[0] = ul[0], uu[1] = ul[1], uu[2] = ul[3], uu[3] = ul[4];
-            vv[0] = vl[0], vv[1] = vl[1], vv[2] = vl[3], vv[3] = vl[4];
-        } else {
-            // hand-over of the previous stage: its row `row` (two steps old) and the bottom nodes of its row `row + 1` (one step old)
-            const double* in = lds + ((G.s - 1) * F4_SLOTS + row % F4_SLOTS) * F4_SLOT + M.lane;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uu[k] = in[(24 + k) * 64];
-                vv[k] = in[(28 + k) * 64];
-            }
-            double tu0 = 0., tu1 = 0., tv0 = 0., tv1 = 0.; // node row 2*ny is the top boundary
-            if (row + 1 <= G.last_prev) {
-                const double* top = lds + ((G.s - 1) * F4_SLOTS + (row + 1) % F4_SLOTS) * F4_SLOT + M.lane;
-                tu0 = top[24 * 64], tu1 = top[25 * 64], tv0 = top[28 * 64], tv1 = top[29 * 64];
-            }
-            gather_nodes(M, uu, tu0, tu1, ul);
-            gather_nodes(M, vv, tv0, tv1, vl);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s11[i] = in[i * 64];
-                s12[i] = in[(8 + i) * 64];
-                s22[i] = in[(16 + i) * 64];
-            }
+        for (int a = 0; a < 3; ++a) {
+            ul[a] = f.ub[a], ul[3 + a] = f.um[a], ul[6 + a] = f.ut[a];
+            vl[a] = f.vb[a], vl[3 + a] = f.vm[a], vl[6 + a] = f.vt[a];
         }
-        stress_update(ul, vl, cur.P, M.ihx, M.ihy, M.ialpha, M.dmin2, s11, s12, s22);
+        uu[0] = ul[0], uu[1] = ul[1], uu[2] = ul[3], uu[3] = ul[4];
+        vv[0] = vl[0], vv[1] = vl[1], vv[2] = vl[3], vv[3] = vl[4];
+    } else {
+        // hand-over of the previous stage: its row `row` and the bottom nodes of its row `row + 1`
+        const double* in = lds + ((stage - 1) * F4_SLOTS + row % F4_SLOTS) * F4_SLOT + 2 * M.lane;
+        const double* top = lds + ((stage - 1) * F4_SLOTS + (row + 1) % F4_SLOTS) * F4_SLOT + 2 * M.lane;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double2 a = lds_pair(in, 12 + k), b = lds_pair(in, 14 + k);
+            uu[2 * k] = a.x, uu[2 * k + 1] = a.y, vv[2 * k] = b.x, vv[2 * k + 1] = b.y;
+        }
+        double2 tu = lds_pair(top, 12), tv = lds_pair(top, 14);
+        if (row + 1 > G.last_prev) // wave-uniform: node row 2*ny is the top boundary
+            tu = tv = make_double2(0., 0.);
+        gather_nodes(M, uu, tu.x, tu.y, ul);
+        gather_nodes(M, vv, tv.x, tv.y, vl);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double2 a = lds_pair(in, k), b = lds_pair(in, 4 + k), c = lds_pair(in, 8 + k);
+            s11[2 * k] = a.x, s11[2 * k + 1] = a.y, s12[2 * k] = b.x, s12[2 * k + 1] = b.y, s22[2 * k] = c.x, s22[2 * k + 1] = c.y;
+        }
+    }
+    NSDG_STAMP(1);
+    if (!FIRST && bar == 0)
+        handover_barrier();
+    NSDG_STAMP(2);
+    // ------------------------------------------------------------------------------------------ Q1: stress update
+    double r11[8], r12[8], r22[8];
+    stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.dmin2, r11, r12, r22);
+    __builtin_amdgcn_sched_barrier(0);
+    NSDG_STAMP(3);
+    tile_load9(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P); // P, and in stage 0 u, v, of the next row
+    if (FIRST) {
+        if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                f.ub[a] = f.ut[a], f.vb[a] = f.vt[a];
+        }
+        fetch_nodes4(u_old, nVn + nn, f.um);
+        fetch_nodes4(v_old, nVn + nn, f.vm);
+        fetch_nodes4(u_old, nVn + 2 * nn, f.ut);
+        fetch_nodes4(v_old, nVn + 2 * nn, f.vt);
+    }
+    NSDG_STAMP(9);
+    if (FIRST) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            s11[i] = f.s11[i], s12[i] = f.s12[i], s22[i] = f.s22[i];
+    }
+    stress_relax(M.ialpha, r11, r12, r22, s11, s12, s22);
+    __builtin_amdgcn_sched_barrier(0);
+    if (FIRST) { // stress of the next row
+        const long ts = tile_off(ix, nrow, M.ntx, 8);
+        tile_load8(S.i11, ts, f.s11);
+        tile_load8(S.i12, ts, f.s12);
+        tile_load8(S.i22, ts, f.s22);
+    }
+    NSDG_STAMP(10);
+    if (!FIRST && bar == 1)
+        handover_barrier();
+    NSDG_STAMP(4);
+    // ------------------------------------------------------------------------------------------ Q2: contributions, node updates
+    {
         double cx[9], cy[9];
         node_contrib_all(s11, s12, s22, M.hx, M.hy, cx, cy);
-        double un[4] = { 0., 0., 0., 0. }, vn[4] = { 0., 0., 0., 0. };
-        if (row >= G.upd0) // wave-uniform
-            owned_node_updates(M, row > 0, cur.c, uu, vv, carry, cx, cy, un, vn);
-        carry_top(carry, cx, cy);
-        if (G.s < 3) {
-            double* out = lds + (G.s * F4_SLOTS + row % F4_SLOTS) * F4_SLOT + M.lane;
+        owned_node_updates(M, row > 0, f.c, uu, vv, carry, cx, cy, un, vn);
+        if (row < G.upd0) { // wave-uniform: the first row of a stage only feeds the carried contributions
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                out[i * 64] = s11[i];
-                out[(8 + i) * 64] = s12[i];
-                out[(16 + i) * 64] = s22[i];
-            }
+            for (int k = 0; k < 4; ++k)
+                un[k] = vn[k] = 0.;
+        }
+        carry_top(carry, cx, cy);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    NSDG_STAMP(5);
+    load_nodal(packed, M.nplane, nVn, f.c[0]); // nodal coefficients of the next row
+    load_nodal(packed, M.nplane, nVn + 1, f.c[1]);
+    load_nodal(packed, M.nplane, nVn + nn, f.c[2]);
+    load_nodal(packed, M.nplane, nVn + nn + 1, f.c[3]);
+    NSDG_STAMP(11);
+    if (!FIRST && bar == 2)
+        handover_barrier();
+    NSDG_STAMP(6);
+    // ------------------------------------------------------------------------------------------ Q3: outputs
+    if (active) {
+        if (FIRST || stage < 3) {
+            double* out = lds + (stage * F4_SLOTS + row % F4_SLOTS) * F4_SLOT + 2 * M.lane;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                out[(24 + k) * 64] = un[k];
-                out[(28 + k) * 64] = vn[k];
+                lds_pair(out, k, s11[2 * k], s11[2 * k + 1]);
+                lds_pair(out, 4 + k, s12[2 * k], s12[2 * k + 1]);
+                lds_pair(out, 8 + k, s22[2 * k], s22[2 * k + 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                lds_pair(out, 12 + k, un[2 * k], un[2 * k + 1]);
+                lds_pair(out, 14 + k, vn[2 * k], vn[2 * k + 1]);
             }
         } else if (M.own && row >= M.y0) { // the last stage runs on rows y0-1 .. y1-1
-            const int nn = M.nn;
-            const long ts = tile_off(M.ix, row, M.ntx, 8);
-            const long nV = (long)(2 * row) * nn + 2 * M.ix;
+            const long ts = tile_off(ix, row, M.ntx, 8);
+            const long nV = (long)(2 * row) * nn + 2 * ix;
             tile_store8(S.o11, ts, s11);
             tile_store8(S.o12, ts, s12);
             tile_store8(S.o22, ts, s22);
@@ -168,7 +240,10 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
             }
         }
     }
-    handover_barrier();
+    NSDG_STAMP(7);
+    if (FIRST || bar == 3)
+        handover_barrier();
+    NSDG_STAMP(8);
 }
 
 // Row ranges as in variant 3: [j0, j1) in strips of R rows and, when nsA > 0 strips are given for it, a SECOND disjoint
@@ -177,7 +252,7 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nx,
     double hx, double hy, double ialpha, double dmin2, StressPtrs4 S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
 {
-    __shared__ double lds[F4_LDS]; // 144 KB: the three hand-overs of this workgroup
+    __shared__ __attribute__((aligned(16))) double lds[F4_LDS]; // 144 KB: the three hand-overs of this workgroup
     const int lane = threadIdx.x & 63;
     const int group = xcd_contiguous_block(blockIdx.x, gridDim.x);
     int strip = group / ncw;
@@ -208,26 +283,70 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nx,
 
     Stage4 G;
     G.s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    G.lag = G.s == 0 ? 0 : 3 * G.s - 1; // 0, 2, 5, 8
+    G.bar = (G.s + 3) & 3; // 3, 0, 1, 2
     G.first = max(M.y0 - 4 + G.s, 0);
     G.last = min(M.y1 + 2 - G.s, ny - 1);
     G.last_prev = min(M.y1 + 3 - G.s, ny - 1);
     G.upd0 = G.s == 0 ? 0 : M.y0 - 3 + G.s;
 
-    Fetch4 X, Y; // alternate between "being fetched" and "being used": no copies when the march advances
+    Fetch4 f;
     TopCarry3 carry;
-    const int tlast = M.y1 + 5; // stage 3 finishes row y1 - 1 at step y1 - 1 + 6
-    if (G.s == 0)
-        fetch_row4(M, G, G.first, X, S, u_old, v_old, packed, pg); // G.first == M.tbeg for stage 0
-    for (int t = M.tbeg; t <= tlast; t += 2) {
-        march_step4(M, G, t, X, Y, carry, lds, S, u_old, v_old, packed, pg, u_new, v_new);
-        if (t + 1 <= tlast)
-            march_step4(M, G, t + 1, Y, X, carry, lds, S, u_old, v_old, packed, pg, u_new, v_new);
+    const int tlast = M.y1 - 1 + F4_LAG_TOTAL; // stage 3 finishes row y1 - 1
+    { // the inputs of the first row of the stage; every other row is requested by the row before it
+        const int row = G.first;
+        const long nV = (long)(2 * row) * M.nn + 2 * M.ix, ts = tile_off(M.ix, row, M.ntx, 8);
+        if (G.s == 0) {
+            fetch_nodes4(u_old, nV, f.ub);
+            fetch_nodes4(v_old, nV, f.vb);
+            fetch_nodes4(u_old, nV + M.nn, f.um);
+            fetch_nodes4(v_old, nV + M.nn, f.vm);
+            fetch_nodes4(u_old, nV + 2 * M.nn, f.ut);
+            fetch_nodes4(v_old, nV + 2 * M.nn, f.vt);
+            tile_load8(S.i11, ts, f.s11);
+            tile_load8(S.i12, ts, f.s12);
+            tile_load8(S.i22, ts, f.s22);
+        }
+        tile_load9(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
+        load_nodal(packed, M.nplane, nV, f.c[0]);
+        load_nodal(packed, M.nplane, nV + 1, f.c[1]);
+        load_nodal(packed, M.nplane, nV + M.nn, f.c[2]);
+        load_nodal(packed, M.nplane, nV + M.nn + 1, f.c[3]);
     }
+#ifdef NSDG_STAMPS
+    unsigned stamp_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned stamp_last = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned stamp_t0 = stamp_last, stamp_rt0 = (unsigned)__builtin_amdgcn_s_memrealtime(); // 100 MHz reference
+#endif
+    if (G.s == 0) {
+        for (int t = M.tbeg; t <= tlast; ++t)
+            march_step4<true>(M, G, t, f, carry, lds, S, u_old, v_old, packed, pg, u_new, v_new NSDG_STAMP_PASS);
+    } else {
+        for (int t = M.tbeg; t <= tlast; ++t)
+            march_step4<false>(M, G, t, f, carry, lds, S, u_old, v_old, packed, pg, u_new, v_new NSDG_STAMP_PASS);
+    }
+#ifdef NSDG_STAMPS
+    if (lane == 0 && (group & 15) == 0 && group / 16 < 16) {
+        unsigned* o = nsdg_stamp_acc4 + ((group / 16) * 4 + G.s) * 16;
+        for (int k = 0; k < 12; ++k)
+            o[k] = stamp_acc[k];
+        o[12] = tlast + 1 - M.tbeg; // march steps
+        o[13] = (unsigned)__builtin_amdgcn_s_memtime() - stamp_t0;
+        o[14] = (unsigned)__builtin_amdgcn_s_memrealtime() - stamp_rt0;
+    }
+#endif
 }
 
 } // namespace nsdg_mevp_detail
 
 using namespace nsdg_mevp_detail;
+
+#ifdef NSDG_STAMPS
+extern "C" int nsdg_debug_read_stamps4(unsigned* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(nsdg_stamp_acc4), sizeof(unsigned) * 64 * 16);
+}
+#endif
 
 // four sub-iterations on the rows [j0, j1) of the local array and, if j0b < j1b, on a second disjoint range [j0b, j1b)
 // in the same launch
@@ -239,7 +358,7 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j
     const int rowsB = j0b < j1b ? j1b - j0b : 0;
     int R = ctx->strip_rows;
     if (R <= 0) {
-        // a strip of R rows takes R + 10 march steps (stage 0 runs on R + 7 rows, stage 3 ends six steps after it);
+        // a strip of R rows takes R + 15 march steps (stage 0 runs on R + 7 rows, stage 3 ends eight steps after it);
         // one resident workgroup per CU (LDS)
         const long slots = ctx->num_cus;
         double best = 1e30;
@@ -247,7 +366,7 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j
         for (int r = 1; r <= 4096; ++r) {
             const long groups = ((long)nsdg_div_up(j1 - j0, r) + nsdg_div_up(rowsB, r)) * ncw;
             const long rounds = (groups + slots - 1) / slots;
-            const double cost = rounds * (r + 10.0);
+            const double cost = rounds * (r + (double)F4_STEPS_EXTRA);
             if (cost < best) {
                 best = cost;
                 R = r;

@@ -393,9 +393,9 @@ def test_a_rank_that_exits_early_does_not_block_its_neighbours(gpu):
         assert t_fail[r] < 30.0, t_fail
 
 
-def test_bounded_drain_reports_a_stalled_communication_stream(ctx, monkeypatch):
+def test_bounded_drain_reports_a_stalled_communication_stream(ctx):
     """nsdg_ctx_synchronize on a context with a communicator polls the streams against the deadline instead of blocking:
-    with the communication stream held up (the rehearsal aid NSDG_HALO_DELAY_US spins for 3 s where a transfer would be --
+    with the communication stream held up (the rehearsal aid nsdg_comm_simulate_wire spins for 3 s where a transfer would be --
     the stand-in for an ncclRecv whose sender has died; it ends by itself, nothing is left hanging) and a 0.5 s deadline the
     call returns NSDG_ERR_COMM in time, the communicator is marked broken, and finalising it does not wait either"""
     import time
@@ -409,10 +409,18 @@ def test_bounded_drain_reports_a_stalled_communication_stream(ctx, monkeypatch):
     assert torch.equal(x[2048:3072], x[0:1024])
     assert plan.stats()["exchanges"] == 1 and plan.stats()["ms"] > 0
     ctx.comm_deadline(0.5)
-    monkeypatch.setenv("NSDG_HALO_DELAY_US", "3000000")
+    ctx.comm_simulate_wire(delay_us=3e6)
     plan.start()
     plan.finish()
-    monkeypatch.delenv("NSDG_HALO_DELAY_US")
+    ctx.comm_simulate_wire(0.0, 0.0)
+    # the host runs ahead of the stalled stream: MORE exchanges than the statistics ring has slots (32) are posted behind
+    # the stalled one -- nsdg_halo_start must not wait for the exchange whose ring slot comes round (it never finishes with
+    # a dead neighbour), it gives the slot up as untimed
+    t0 = time.perf_counter()
+    for _ in range(40):
+        plan.start()
+        plan.finish()
+    assert time.perf_counter() - t0 < 0.4, "posting exchanges behind a stalled one blocked the host"
     t0 = time.perf_counter()
     with pytest.raises(abi.NsdgError, match="did not drain within 0.5 s"):
         ctx.synchronize()
@@ -420,6 +428,8 @@ def test_bounded_drain_reports_a_stalled_communication_stream(ctx, monkeypatch):
     assert 0.4 < waited < 2.0, waited
     with pytest.raises(abi.NsdgError, match="broken"):
         ctx.synchronize()
+    with pytest.raises(abi.NsdgError, match="broken"):  # and no further exchange is posted on a broken communicator
+        plan.start()
     t0 = time.perf_counter()
     plan.close()
     ctx.comm_finalize()  # does not drain a broken communicator

@@ -53,6 +53,8 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
     bt = synthetic.BoxTest(nx, ny, L)
     alpha = bt.stable_alpha(dt)
     ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+    if os.environ.get("NSDG_SHARE_VARIANT"):  # A/B of the mEVP kernel variants
+        ctx.set_mevp_variant(int(os.environ["NSDG_SHARE_VARIANT"]))
     rank = world // 2
     v = min(ctx.mevp_variant, 4)  # sub-iterations per kernel pass
     depth = (v * kpass, v * kpass - 1)

@@ -34,6 +34,24 @@ for _ in range(2):
 torch.cuda.synchronize()
 lib = abi.load_library()
 out = (ctypes.c_uint * (64 * 16))()
+if ctx.mevp_variant == 4:
+    # one record per (sampled workgroup, pipeline stage): the four waves of a workgroup printed side by side
+    rc = lib.nsdg_debug_read_stamps4(out)
+    a = np.array(out[:], dtype=np.float64).reshape(16, 4, 16)
+    a = a[a[:, 0, 12] > 0]
+    order = [(0, "loop overhead"), (1, "Q0 inputs: LDS reads / fetched values, node gather"), (2, "  barrier (wave 1)"), (3, "Q1 projected stress"),
+             (9, "   requests: P (+ u, v in stage 0) of the next row"), (10, "   relaxation (+ request: stress of the next row in stage 0)"), (4, "  barrier (wave 2)"),
+             (5, "Q2 contributions, node updates, carries"), (11, "   request: nodal coefficients of the next row"), (6, "  barrier (wave 3)"),
+             (7, "Q3 outputs: LDS writes / global stores"), (8, "  barrier (wave 0)")]
+    per = a[:, :, :12] / a[:, :, 12:13]
+    med = np.median(per, axis=0)  # [stage, phase]
+    print("variant 4: workgroups sampled %d, march steps %s; cycles per march step, stages 0..3" % (len(a), sorted(set(a[:, 0, 12].astype(int)))))
+    for k, name in order:
+        print("%-62s %s" % (name, "  ".join("%7.0f" % med[s, k] for s in range(4))))
+    print("%-62s %s" % ("sum", "  ".join("%7.0f" % med[s].sum() for s in range(4))))
+    clk = a[:, :, 13] / (a[:, :, 14] * 10e-9) / 1e9
+    print("in-kernel shader clock: median %.2f GHz (min %.2f, max %.2f); march of one workgroup %.3f ms" % (np.median(clk), clk.min(), clk.max(), np.median(a[:, :, 14]) * 10e-6))
+    sys.exit(0)
 if ctx.mevp_variant == 3:
     rc = lib.nsdg_debug_read_stamps3(out)
     nph, isteps, icyc, irt = 11, 11, 12, 13
