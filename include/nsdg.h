@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define NSDG_ABI_VERSION 3
+#define NSDG_ABI_VERSION 4
 
 typedef enum {
     NSDG_OK = 0,
@@ -156,8 +156,9 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
  * sub-iterations per pass (nsdg_mevp_iterate3 / nsdg_mevp_subcycle; remainders of 2 or 1 sub-iterations use
  * the kernels of variants 2 and 1), 4 = four sub-iterations per pass, one pipeline stage per wave of a four-wave
  * workgroup with the hand-over in LDS (nsdg_mevp_iterate4 / nsdg_mevp_subcycle; remainders of 3, 2 or 1 sub-iterations
- * use the kernels of variants 3, 2 and 1); 3 is the default of a new context.  Variants 1, 2, 3 and 4 agree bit for bit,
- * variant 0 to fp64 round-off. */
+ * use the kernels of variants 3, 2 and 1); NSDG_MEVP_DEFAULT_VARIANT (4) is the default of a new context.  Variants 1, 2,
+ * 3 and 4 agree bit for bit, variant 0 to fp64 round-off. */
+#define NSDG_MEVP_DEFAULT_VARIANT 4
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
 
 /* CG2 velocity -> DG(order) velocity and edge-normal velocities used by the transport */

@@ -68,7 +68,7 @@ class NsdgError(RuntimeError):
 VP = C.c_void_p
 I32, I64, D = C.c_int32, C.c_int64, C.c_double
 DEFAULT_TRANSPORT_VARIANT = 2  # nsdg_ctx_create's default transport stage kernel (csrc/nsdg_ctx.hip)
-DEFAULT_MEVP_VARIANT = 3  # nsdg_ctx_create's default: three sub-iterations per kernel pass (csrc/mevp_fused3.hip)
+DEFAULT_MEVP_VARIANT = 4  # nsdg_ctx_create's default (NSDG_MEVP_DEFAULT_VARIANT): four sub-iterations per kernel pass (csrc/mevp_fused4.hip)
 
 SYMBOLS = {
     "nsdg_abi_version": (C.c_int, []),
@@ -293,7 +293,7 @@ class Context:
         self._call(self.lib.nsdg_ctx_create(self.device.index or 0, VP(self.stream.cuda_stream), C.byref(h)))
         self.h = h
         self.nx = self.ny = 0
-        self.mevp_variant = DEFAULT_MEVP_VARIANT  # the library default (three sub-iterations per pass)
+        self.mevp_variant = DEFAULT_MEVP_VARIANT  # the library default (four sub-iterations per pass)
 
     def _call(self, rc):
         if rc != 0:

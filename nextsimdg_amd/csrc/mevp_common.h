@@ -224,26 +224,42 @@ __device__ __forceinline__ void sf_grad(const double (&U)[9], double (&dxi)[8], 
     deta[7] = 0.;
 }
 
-// values of a DG8 function at the 3x3 Gauss points, V[3*qy + qx]
+// values of a DG8 function at the 3x3 Gauss points, V[3*qy + qx].  ZERO names coefficients known to vanish (the compiler
+// may not drop 0 * x): 1 = c[3], c[6] (a d/dxi of a biquadratic has no xi^2 part), 2 = c[4], c[7] (a d/deta has no eta^2 part)
+template <int ZERO = 0>
 __device__ __forceinline__ void sf_eval(const double (&c)[8], double (&V)[9])
 {
     double T0[3], T1[3], T2[3]; // T_b[qx] = sum_a C[a][b] p_a(xi_qx)
     // every output is one fused expression: S -+ g*c = fma(-+g, c, S)
-    {
-        const double S = c[0] + SF_P2E * c[3];
-        T0[0] = S - SF_G * c[1], T0[2] = S + SF_G * c[1], T0[1] = c[0] + SF_P2M * c[3];
+    if constexpr (ZERO == 1) {
+        T0[0] = c[0] - SF_G * c[1], T0[2] = c[0] + SF_G * c[1], T0[1] = c[0];
+        T1[0] = c[2] - SF_G * c[5], T1[2] = c[2] + SF_G * c[5], T1[1] = c[2];
+    } else {
+        {
+            const double S = c[0] + SF_P2E * c[3];
+            T0[0] = S - SF_G * c[1], T0[2] = S + SF_G * c[1], T0[1] = c[0] + SF_P2M * c[3];
+        }
+        {
+            const double S = c[2] + SF_P2E * c[6];
+            T1[0] = S - SF_G * c[5], T1[2] = S + SF_G * c[5], T1[1] = c[2] + SF_P2M * c[6];
+        }
     }
-    {
-        const double S = c[2] + SF_P2E * c[6];
-        T1[0] = S - SF_G * c[5], T1[2] = S + SF_G * c[5], T1[1] = c[2] + SF_P2M * c[6];
-    }
-    T2[0] = c[4] - SF_G * c[7], T2[2] = c[4] + SF_G * c[7], T2[1] = c[4];
+    if constexpr (ZERO == 2) {
 #pragma unroll
-    for (int qx = 0; qx < 3; ++qx) {
-        const double S = T0[qx] + SF_P2E * T2[qx];
-        V[qx] = S - SF_G * T1[qx];
-        V[6 + qx] = S + SF_G * T1[qx];
-        V[3 + qx] = T0[qx] + SF_P2M * T2[qx];
+        for (int qx = 0; qx < 3; ++qx) {
+            V[qx] = T0[qx] - SF_G * T1[qx];
+            V[6 + qx] = T0[qx] + SF_G * T1[qx];
+            V[3 + qx] = T0[qx];
+        }
+    } else {
+        T2[0] = c[4] - SF_G * c[7], T2[2] = c[4] + SF_G * c[7], T2[1] = c[4];
+#pragma unroll
+        for (int qx = 0; qx < 3; ++qx) {
+            const double S = T0[qx] + SF_P2E * T2[qx];
+            V[qx] = S - SF_G * T1[qx];
+            V[6 + qx] = S + SF_G * T1[qx];
+            V[3 + qx] = T0[qx] + SF_P2M * T2[qx];
+        }
     }
 }
 
@@ -317,40 +333,54 @@ __device__ __forceinline__ void sf_geta(const double (&c)[8], double (&G)[9])
     }
 }
 
-// (1/alpha) Proj sigma(v): the projected viscous-plastic stress of one element from its 9 nodal velocities
+// (1/alpha) Proj sigma(v): the projected viscous-plastic stress of one element from its 9 nodal velocities, ALREADY SCALED
+// by 1/alpha.  Round 4 (the four-wave pipeline is bound by vector-instruction issue, so instructions are time): sigma is
+// linear in the ice strength, so 1/alpha and the 1/2 of "- P/2" are folded into it once (hp = P/(2 alpha): 9 multiplies
+// that replace the 9 of P/2 and the 24 of the relaxation); the strain-rate coefficients that vanish identically -- a
+// d/dxi of a biquadratic has no xi^2 part, a d/deta no eta^2 part -- are neither formed nor evaluated (28 operations).
 __device__ __forceinline__ void stress_projected(const double (&ul)[9], const double (&vl)[9], const double (&P)[9], double ihx,
-    double ihy, double dmin2, double (&r11)[8], double (&r12)[8], double (&r22)[8])
+    double ihy, double ialpha, double dmin2, double (&r11)[8], double (&r12)[8], double (&r22)[8])
 {
     double E11[8], E12[8], E22[8];
     {
         double uxi[8], ueta[8], vxi[8], veta[8];
         sf_grad(ul, uxi, ueta);
         sf_grad(vl, vxi, veta);
+        const double hihx = 0.5 * ihx, hihy = 0.5 * ihy;
+        // d/dxi: entries 3, 6 vanish; d/deta: entries 4, 7 vanish
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            E11[i] = uxi[i] * ihx;
-            E22[i] = veta[i] * ihy;
-            E12[i] = 0.5 * (ueta[i] * ihy + vxi[i] * ihx);
+            const bool zx = i == 3 || i == 6, zy = i == 4 || i == 7;
+            E11[i] = zx ? 0. : uxi[i] * ihx;
+            E22[i] = zy ? 0. : veta[i] * ihy;
+            E12[i] = zx ? ueta[i] * hihy : (zy ? vxi[i] * hihx : ueta[i] * hihy + vxi[i] * hihx);
         }
     }
     double e11[9], e12[9], e22[9];
-    sf_eval(E11, e11);
-    sf_eval(E12, e12);
-    sf_eval(E22, e22);
+    sf_eval<1>(E11, e11);
+    sf_eval<0>(E12, e12);
+    sf_eval<2>(E22, e22);
     double t11[9], t12[9], t22[9];
+    const double hps = 0.5 * ialpha;
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-        const double d2 = dmin2 + 1.25 * (e11[q] * e11[q] + e22[q] * e22[q]) + 1.5 * e11[q] * e22[q] + e12[q] * e12[q];
-        const double pd = P[q] * fast_rsqrt(d2);
-        t11[q] = pd * (0.625 * e11[q] + 0.375 * e22[q]) - 0.5 * P[q];
-        t22[q] = pd * (0.625 * e22[q] + 0.375 * e11[q]) - 0.5 * P[q];
-        t12[q] = pd * 0.25 * e12[q];
+        // with a = e11 + e22, hb = (e11 - e22) / 2:  Delta^2 = Dmin^2 + a^2 + hb^2 + e12^2 (= Dmin^2 + 1.25 (e11^2 + e22^2) + 1.5 e11 e22
+        // + e12^2 for the ellipse ratio 2) and 5/8 e11 + 3/8 e22 = (a + hb / 2) / 2: every factor is an inline constant of the
+        // instruction set, so no literal has to be held in (or moved out of) scalar registers
+        const double hp = P[q] * hps; // P / (2 alpha)
+        const double a = e11[q] + e22[q], hb = 0.5 * (e11[q] - e22[q]);
+        const double d2 = __builtin_fma(hb, hb, __builtin_fma(a, a, __builtin_fma(e12[q], e12[q], dmin2)));
+        const double pd = hp * fast_rsqrt(d2); // P / (2 alpha Delta)
+        t11[q] = __builtin_fma(pd, __builtin_fma(0.5, hb, a), -hp);
+        t22[q] = __builtin_fma(pd, __builtin_fma(-0.5, hb, a), -hp);
+        t12[q] = (0.5 * pd) * e12[q];
     }
     sf_project(t11, r11);
     sf_project(t12, r12);
     sf_project(t22, r22);
 }
 
+// S <- (1 - 1/alpha) S + r, r = (1/alpha) Proj sigma(v) from stress_projected
 __device__ __forceinline__ void stress_relax(double ialpha, const double (&r11)[8], const double (&r12)[8], const double (&r22)[8],
     double (&s11)[8], double (&s12)[8], double (&s22)[8])
 {
@@ -359,9 +389,9 @@ __device__ __forceinline__ void stress_relax(double ialpha, const double (&r11)[
     const double keep = 1. - ialpha;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s11[i] = __builtin_fma(ialpha, r11[i], keep * s11[i]);
-        s12[i] = __builtin_fma(ialpha, r12[i], keep * s12[i]);
-        s22[i] = __builtin_fma(ialpha, r22[i], keep * s22[i]);
+        s11[i] = __builtin_fma(keep, s11[i], r11[i]);
+        s12[i] = __builtin_fma(keep, s12[i], r12[i]);
+        s22[i] = __builtin_fma(keep, s22[i], r22[i]);
     }
 }
 
@@ -370,7 +400,7 @@ __device__ __forceinline__ void stress_update(const double (&ul)[9], const doubl
     double ihx, double ihy, double ialpha, double dmin2, double (&s11)[8], double (&s12)[8], double (&s22)[8])
 {
     double r11[8], r12[8], r22[8];
-    stress_projected(ul, vl, P, ihx, ihy, dmin2, r11, r12, r22);
+    stress_projected(ul, vl, P, ihx, ihy, ialpha, dmin2, r11, r12, r22);
     stress_relax(ialpha, r11, r12, r22, s11, s12, s22);
 }
 

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
             // 2 waves/SIMD build: stage the loads so that the live set stays under 256 registers -- the old
             // stress is fetched only after the projected stress is formed, the partner wave covers the latency
             double r11[8], r12[8], r22[8];
-            stress_projected(ul, vl, Pq, ihx, ihy, dmin2, r11, r12, r22);
+            stress_projected(ul, vl, Pq, ihx, ihy, ialpha, dmin2, r11, r12, r22);
             asm volatile("" ::: "memory");
             tile_load8(S.i11, ts, s11);
             tile_load8(S.i12, ts, s12);

@@ -99,6 +99,27 @@ __device__ __forceinline__ void fetch_nodes4(const double* __restrict__ w, long 
 // The step is straight-line code: a wave whose stage has not reached its first row yet, or is past its last, works on
 // that row again and again with whatever the hand-over slots hold and only SUPPRESSES ITS OUTPUTS -- branches around
 // the loads made the compiler wait for loads it had just issued (profiles/r04_fused4_development.md).
+// the inputs of element row `nrow` that every stage reads from memory itself: ice strength and nodal coefficients
+__device__ __forceinline__ void request_P4(const MarchConst3& M, int nrow, Fetch4& f, const double* __restrict__ pg)
+{
+    tile_load9(pg, tile_off(M.ix, nrow, M.ntx, 9), M.ix & 63, f.P);
+}
+__device__ __forceinline__ void request_c4(const MarchConst3& M, int nrow, double (&c)[4][6], const double* __restrict__ packed)
+{
+    const long nVn = (long)(2 * nrow) * M.nn + 2 * M.ix;
+    load_nodal(packed, M.nplane, nVn, c[0]);
+    load_nodal(packed, M.nplane, nVn + 1, c[1]);
+    load_nodal(packed, M.nplane, nVn + M.nn, c[2]);
+    load_nodal(packed, M.nplane, nVn + M.nn + 1, c[3]);
+}
+
+// One march step of one wave.  FIRST: the loader wave (stage 0, inputs from memory; a code path of its own so that its
+// register allocation and the compiler's bookkeeping of outstanding loads are not entangled with the other stages').
+// A busy step is straight-line code.  A stage that has not reached its first row yet, or is past its last, takes the IDLE
+// step: it requests the inputs of its next row and meets the barrier, nothing else (at the power cap idle arithmetic costs
+// the busy waves their clock).  The loader has no idle step: it works on its first / last row again and only suppresses
+// the outputs -- with its arithmetic behind a branch the compiler copied freshly loaded values between registers at the join
+// and waited for them, a full HBM round trip (profiles/r04_fused4_development.md).
 template <bool FIRST>
 __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& G, int t, Fetch4& f, TopCarry3& carry, double* __restrict__ lds,
     const StressPtrs4& S, const double* __restrict__ u_old, const double* __restrict__ v_old, const double* __restrict__ packed,
@@ -110,9 +131,16 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     const int row = min(max(rowraw, G.first), G.last);
     const int nrow = min(max(rowraw + 1, G.first), G.last); // the row this stage works on in the NEXT step: its inputs are requested during this one
     const int ix = M.ix, nn = M.nn;
+    NSDG_STAMP(0);
+    if (!FIRST && !active) { // ------------------------------------------------------------------- idle step
+        request_P4(M, nrow, f, pg);
+        request_c4(M, nrow, f.c, packed);
+        handover_barrier();
+        NSDG_STAMP(8);
+        return;
+    }
     const long nVn = (long)(2 * nrow) * nn + 2 * ix; // vertex node of the next row
     double s11[8], s12[8], s22[8], uu[4], vv[4], ul[9], vl[9], un[4], vn[4];
-    NSDG_STAMP(0);
     // ------------------------------------------------------------------------------------------ Q0: inputs of the row
     if (FIRST) {
 #pragma unroll
@@ -148,10 +176,10 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     NSDG_STAMP(2);
     // ------------------------------------------------------------------------------------------ Q1: stress update
     double r11[8], r12[8], r22[8];
-    stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.dmin2, r11, r12, r22);
+    stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
     __builtin_amdgcn_sched_barrier(0);
     NSDG_STAMP(3);
-    tile_load9(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P); // P, and in stage 0 u, v, of the next row
+    request_P4(M, nrow, f, pg); // P, and in stage 0 u, v, of the next row
     if (FIRST) {
         if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
 #pragma unroll
@@ -195,49 +223,49 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     }
     __builtin_amdgcn_sched_barrier(0);
     NSDG_STAMP(5);
-    load_nodal(packed, M.nplane, nVn, f.c[0]); // nodal coefficients of the next row
-    load_nodal(packed, M.nplane, nVn + 1, f.c[1]);
-    load_nodal(packed, M.nplane, nVn + nn, f.c[2]);
-    load_nodal(packed, M.nplane, nVn + nn + 1, f.c[3]);
+    // nodal coefficients of the next row.  (Requested for the CURRENT row after the register peak of the projected stress
+    // instead -- 48 registers fewer across the step in the stages 1-3, whose coefficients come from L2 / the Infinity Cache --
+    // measured 0.5 % slower: 1.000-1.002 against 0.994-0.998 ms per pass, alternating runs on one box.)
+    request_c4(M, nrow, f.c, packed);
     NSDG_STAMP(11);
     if (!FIRST && bar == 2)
         handover_barrier();
     NSDG_STAMP(6);
     // ------------------------------------------------------------------------------------------ Q3: outputs
-    if (active) {
-        if (FIRST || stage < 3) {
-            double* out = lds + (stage * F4_SLOTS + row % F4_SLOTS) * F4_SLOT + 2 * M.lane;
+    if (FIRST && !active) {
+        // the loader wave past its last row: nothing to hand over
+    } else if (FIRST || stage < 3) {
+        double* out = lds + (stage * F4_SLOTS + row % F4_SLOTS) * F4_SLOT + 2 * M.lane;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                lds_pair(out, k, s11[2 * k], s11[2 * k + 1]);
-                lds_pair(out, 4 + k, s12[2 * k], s12[2 * k + 1]);
-                lds_pair(out, 8 + k, s22[2 * k], s22[2 * k + 1]);
-            }
+        for (int k = 0; k < 4; ++k) {
+            lds_pair(out, k, s11[2 * k], s11[2 * k + 1]);
+            lds_pair(out, 4 + k, s12[2 * k], s12[2 * k + 1]);
+            lds_pair(out, 8 + k, s22[2 * k], s22[2 * k + 1]);
+        }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                lds_pair(out, 12 + k, un[2 * k], un[2 * k + 1]);
-                lds_pair(out, 14 + k, vn[2 * k], vn[2 * k + 1]);
-            }
-        } else if (M.own && row >= M.y0) { // the last stage runs on rows y0-1 .. y1-1
-            const long ts = tile_off(ix, row, M.ntx, 8);
-            const long nV = (long)(2 * row) * nn + 2 * ix;
-            tile_store8(S.o11, ts, s11);
-            tile_store8(S.o12, ts, s12);
-            tile_store8(S.o22, ts, s22);
-            u_new[nV] = un[0], v_new[nV] = vn[0];
-            u_new[nV + 1] = un[1], v_new[nV + 1] = vn[1];
-            u_new[nV + nn] = un[2], v_new[nV + nn] = vn[2];
-            u_new[nV + nn + 1] = un[3], v_new[nV + nn + 1] = vn[3];
-            if (M.lastcol) {
-                u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
-                u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
-            }
-            if (row == M.ny - 1) {
-                u_new[nV + 2 * nn] = 0., v_new[nV + 2 * nn] = 0.;
-                u_new[nV + 2 * nn + 1] = 0., v_new[nV + 2 * nn + 1] = 0.;
-                if (M.lastcol)
-                    u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
-            }
+        for (int k = 0; k < 2; ++k) {
+            lds_pair(out, 12 + k, un[2 * k], un[2 * k + 1]);
+            lds_pair(out, 14 + k, vn[2 * k], vn[2 * k + 1]);
+        }
+    } else if (M.own && row >= M.y0) { // the last stage runs on rows y0-1 .. y1-1
+        const long ts = tile_off(ix, row, M.ntx, 8);
+        const long nV = (long)(2 * row) * nn + 2 * ix;
+        tile_store8(S.o11, ts, s11);
+        tile_store8(S.o12, ts, s12);
+        tile_store8(S.o22, ts, s22);
+        u_new[nV] = un[0], v_new[nV] = vn[0];
+        u_new[nV + 1] = un[1], v_new[nV + 1] = vn[1];
+        u_new[nV + nn] = un[2], v_new[nV + nn] = vn[2];
+        u_new[nV + nn + 1] = un[3], v_new[nV + nn + 1] = vn[3];
+        if (M.lastcol) {
+            u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
+            u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
+        }
+        if (row == M.ny - 1) {
+            u_new[nV + 2 * nn] = 0., v_new[nV + 2 * nn] = 0.;
+            u_new[nV + 2 * nn + 1] = 0., v_new[nV + 2 * nn + 1] = 0.;
+            if (M.lastcol)
+                u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
         }
     }
     NSDG_STAMP(7);
@@ -308,10 +336,7 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nx,
             tile_load8(S.i22, ts, f.s22);
         }
         tile_load9(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
-        load_nodal(packed, M.nplane, nV, f.c[0]);
-        load_nodal(packed, M.nplane, nV + 1, f.c[1]);
-        load_nodal(packed, M.nplane, nV + M.nn, f.c[2]);
-        load_nodal(packed, M.nplane, nV + M.nn + 1, f.c[3]);
+        request_c4(M, row, f.c, packed);
     }
 #ifdef NSDG_STAMPS
     unsigned stamp_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };

@@ -80,7 +80,7 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     c->nx = c->ny = 0;
     c->row0 = c->ny_global = 0;
     c->hx = c->hy = 0.;
-    c->mevp_variant = 3;
+    c->mevp_variant = NSDG_MEVP_DEFAULT_VARIANT;
     c->strip_rows = 0;
     {
         hipDeviceProp_t prop;

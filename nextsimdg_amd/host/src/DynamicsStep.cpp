@@ -208,7 +208,7 @@ void DynamicsStep::start(const Iterator::TimePoint& startTime)
                 throw std::invalid_argument("dynamics.devices names a device that does not exist");
     }
     // ghost depth: (v k, v k - 1) for k passes of the v-iterations-per-pass kernel between two exchanges
-    const int v = 3; // the library's default kernel
+    const int v = NSDG_MEVP_DEFAULT_VARIANT; // the library's default kernel: sub-iterations per pass
     int k = world > 1 ? std::max(1, std::min(passesPerExchange, (nyf / world) / 16)) : 1;
     const int depthBelow = world > 1 ? v * k : 0, depthAbove = world > 1 ? v * k - 1 : 0;
     if (world > 1 && nyf < world * 2 * std::max(depthBelow, 1))

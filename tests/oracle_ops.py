@@ -103,6 +103,28 @@ class OracleOps:
             _np(b)[:, j0:j1] = a[:, j0:j1]
         O.mevp_velocity(*args, j0, j1, self.hx, self.hy, dt, self.p, sp, up2, [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga)
 
+    def mevp_iterate4(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
+        """four sub-iterations on the owned rows [j0, j1), reading four rows below / three above, exactly the
+        dependency region of the four-iterations-per-pass kernel (csrc/mevp_fused4.hip): sub-iteration k of v = 4 updates
+        the stress on rows j0-(v-k) .. j1+(v-2-k) and the velocity of the nodes owned by rows j0-(v-1-k) .. j1+(v-2-k)"""
+        v = 4
+        dt, u0v0, tau, ocean, cgh, cga = self.nodal
+        ny = self.ny
+        top = lambda r: min(r, ny - 1) + 1  # exclusive end of a row range clipped to the array
+        sp = [_np(x).copy() for x in s_in]
+        u = [_np(x) for x in uv_old]
+        args = (self.nx, ny)
+        for k in range(v):
+            last = k == v - 1
+            end = j1 if last else top(j1 + (v - 2 - k))
+            O.mevp_stress(*args, max(j0 - (v - k), 0), end, self.hx, self.hy, self.p, u[0], u[1], _np(pg), *sp)
+            if last:
+                for a, b in zip(sp, s_out):
+                    _np(b)[:, j0:j1] = a[:, j0:j1]
+            un = [_np(x) for x in uv_new] if last else [x.copy() for x in u]
+            O.mevp_velocity(*args, max(j0 - (v - 1 - k), 0), end, self.hx, self.hy, dt, self.p, sp, u, un, u0v0, tau, ocean, cgh, cga)
+            u = un
+
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):
         res = O.prepare_advection(self.nx, self.ny, order, _np(u), _np(v))
         for dst, src in zip((vx, vy, unx, uny), res):

@@ -28,7 +28,7 @@ def test_plain_command_with_two_ranks_self_launches():
     assert len(lines) == 1, p.stdout.decode()
     assert lines[0]["dry_run"] is True and lines[0]["value"] is None  # a dry run reports no metric
     assert lines[0]["n_gpus"] == 2 and lines[0]["rows_total"] == 2048 and lines[0]["max_rank_seen"] == 1
-    assert lines[0]["ghost_depth"] == [9, 8]  # 3 passes of the three-iteration kernel between two exchanges (profiles/r03_rank_share_bandwidth.txt)
+    assert lines[0]["ghost_depth"] == [12, 11]  # 3 passes of the four-iteration kernel between two exchanges
 
 
 def test_worker_failure_is_reported_by_the_exit_status():

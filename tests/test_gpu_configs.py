@@ -13,6 +13,8 @@ import pytest
 import torch
 
 from nextsimdg_amd import abi, rowblock, synthetic
+
+V = abi.DEFAULT_MEVP_VARIANT  # the library default: four sub-iterations per kernel pass
 from thread_ranks import fields, gather, run_world
 
 pytestmark = pytest.mark.gpu
@@ -38,36 +40,36 @@ def check_physical(res, mass0, nx, ny):
 
 def test_config3_1024_transport_and_mevp_120_subiterations(gpu):
     """config 3: 1024x1024 DG2 transport (H, A; SSP-RK3) + mEVP with 120 sub-iterations, 3 model steps, default
-    kernel (three sub-iterations per pass) against one sub-iteration per pass: bit-identical; mass, walls"""
+    kernel (four sub-iterations per pass, one pipeline stage per wave) against one sub-iteration per pass: bit-identical; mass, walls"""
     n, nsub, nsteps = 1024, 120, 3
     data = fields(n, n, wind_scale=1.0)
     alpha = data[0].stable_alpha(120.0)
     mass0 = (float(np.sum(data[1][0])), float(np.sum(data[2][0])))
     res = {}
-    for variant in (3, 1):
+    for variant in (V, 1):
         res[variant] = run_world(1, variant, False, n, n, nsub, nsteps, data=data, alpha=alpha)[0]
         check_physical(res[variant], mass0, n, n)
     for k in ("u", "v", "H", "A", "s11"):
-        assert torch.equal(res[3][k], res[1][k]), k
-    assert float((res[3]["H"][0] - torch.from_numpy(data[1][0]).cuda()).abs().max()) > 1e-9  # the ice did move
+        assert torch.equal(res[V][k], res[1][k]), k
+    assert float((res[V]["H"][0] - torch.from_numpy(data[1][0]).cuda()).abs().max()) > 1e-9  # the ice did move
     del res
     free()
 
 
 def test_config4_2048_four_row_blocks_equal_single_domain_bitwise(gpu):
-    """config 4: 2048x2048 DG2 full dynamics, 4 row blocks of 512 rows, 120 sub-iterations, 3 passes of the
-    three-iteration kernel between two ghost-row exchanges (ghost depth 9 / 8: the default of bench.py and of the C++ host
-    since round 3; config 5 below runs 6 passes per exchange), overlap split on, 2 model steps:
+    """config 4: 2048x2048 DG2 full dynamics, 4 row blocks of 512 rows, 120 sub-iterations, 3 passes of the default
+    (four-iteration) kernel between two ghost-row exchanges (ghost depth 12 / 11: the default of bench.py and of the C++
+    host; config 5 below runs 6 passes per exchange), overlap split on, 2 model steps:
     every owned row of every block equals the single-domain run (Python sequence of launches) bit for bit"""
     n, nsub, nsteps, world, group = 2048, 120, 2, 4, 3
     data = fields(n, n, wind_scale=1.0)
     alpha = data[0].stable_alpha(120.0)
     mass0 = (float(np.sum(data[1][0])), float(np.sum(data[2][0])))
-    ref = run_world(1, 3, False, n, n, nsub, nsteps, data=data, alpha=alpha)[0]
+    ref = run_world(1, V, False, n, n, nsub, nsteps, data=data, alpha=alpha)[0]
     check_physical(ref, mass0, n, n)
     # the product path: native row-block drivers (nsdg_rb_*_run) and the exchange behind the C ABI (nsdg_halo_*) on its
     # in-process transport -- everything of the 4-GPU run except RCCL itself
-    parts = run_world(world, 3, False, n, n, nsub, nsteps, group=group, data=data, alpha=alpha, transport="native", native=True)
+    parts = run_world(world, V, False, n, n, nsub, nsteps, group=group, data=data, alpha=alpha, transport="native", native=True)
     for k in ("H", "A", "u", "v", "s11"):
         got = gather(parts, world, k)
         assert got.shape == ref[k].shape, k
@@ -91,13 +93,13 @@ def test_config5_4096_coupled_eight_row_blocks_equal_single_domain_bitwise(gpu):
     column = {**cs, **cf}
     alpha = bt.stable_alpha(120.0)
     keep = ("H", "A", "u", "v")
-    ref = run_world(1, 3, True, n, n, nsub, nsteps, data=data, column=column, alpha=alpha, keep=keep)[0]
+    ref = run_world(1, V, True, n, n, nsub, nsteps, data=data, column=column, alpha=alpha, keep=keep)[0]
     check_physical(ref, None, n, n)
     assert 0.25 < float(ref["H"][0].min()) and float(ref["H"][0].max()) < 0.45
     assert 0.9 < float(ref["A"][0].min()) and float(ref["A"][0].max()) < 1.01
     assert -40.0 < float(ref["tice0"].min()) and float(ref["tice0"].max()) <= 0.0
     assert float((ref["tice0"] - torch.from_numpy(column["tice0"]).cuda()).abs().max()) > 1e-3  # the column step ran
-    parts = run_world(world, 3, True, n, n, nsub, nsteps, group=group, data=data, column=column, alpha=alpha, keep=keep,
+    parts = run_world(world, V, True, n, n, nsub, nsteps, group=group, data=data, column=column, alpha=alpha, keep=keep,
                       transport="native", native=True)
     for k in keep + ("hsnow", "tice0"):
         got = gather(parts, world, k)
