@@ -16,9 +16,11 @@ step, fp64, synthetic 512 km box test.  One "step" = one model time step of the 
 is split into N row blocks (strong scaling) with ghost-row send/recv over RCCL.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel: one pass
-of the fused mEVP kernel, HIP-event timed in this run; `frac` is bounded by 1: the kernel's own compulsory
-bytes per pass against 8 TB/s -- the unfused accounting of SURVEY.md section 8(d), 896 B per element and
-sub-iteration, is reported beside it as `survey_8d` and is NOT a roofline fraction) and `cpu_baseline` (the CPU
+of the fused mEVP kernel, HIP-event timed in this run; `algorithmic_bytes_per_launch` is the figure of SURVEY.md
+section 8(d), 896 B per element and sub-iteration x the sub-iterations of a launch, and `survey_8d_ratio` its rate
+against 8 TB/s -- NOT a fraction of anything physical for a kernel that keeps intermediate iterates on chip, it exceeds
+1; `frac` = `frac_compulsory` is bounded by 1: the bytes a pass MUST move, 776 B per element, against 8 TB/s) and
+`cpu_baseline` (the CPU
 oracle = this repo's own restatement, "port", timed on a bounded sample of the same 2048 x 2048 workload: a few of the
 step's 120 sub-iterations and its transport step).
 """
@@ -42,7 +44,9 @@ BYTES_PER_ELEM_SUBITER = 896  # byte model of ONE mEVP s
 BYTES_COMPULSORY_PER_PASS = 776  # what a pass of a fused kernel must move per element whatever it computes on chip
 SHADER_CLOCK_PEAK_HZ = 2.4e9  # MI355X_MICROARCH.md: peak engine clock
 BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
-COMM_DEADLINE_S = float(os.environ.get("NSDG_COMM_TIMEOUT_S", "300"))  # a rank that has died must not block the others for ever
+COMM_DEADLINE_S = float(os.environ.get("NSDG_COMM_TIMEOUT_S", "300"))  # a rank that has died must not block the others for ever; 0 = wait for ever
+# the same number for torch's process group, where 0 would mean "fail at once": the library's "for ever" becomes a day
+TORCH_TIMEOUT_S = COMM_DEADLINE_S if COMM_DEADLINE_S > 0 else 86400.0
 
 
 class stdout_to_stderr:
@@ -59,6 +63,31 @@ class stdout_to_stderr:
         sys.stdout.flush()
         os.dup2(self.saved, 1)
         os.close(self.saved)
+
+
+DIAGNOSTICS_FAILED = []
+
+
+def optional(name, fn, *a, **kw):
+    """an optional diagnostic of the line (exchange statistics, copy ceiling, offline counters, CPU baseline): a failure
+    degrades its field to null and is named in `diagnostics_failed` -- it never costs the run its JSON line"""
+    try:
+        return fn(*a, **kw)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 -- anything: the measurement itself is already complete
+        DIAGNOSTICS_FAILED.append("%s: %s: %s" % (name, type(e).__name__, str(e)[:300]))
+        sys.stderr.write("bench.py: optional diagnostic %s failed: %r\n" % (name, e))
+        return None
+
+
+def failure_line(args, world, where, err):
+    """the line of a run that failed in its measured part: the contract's keys with value null and the error text, so
+    that a BENCH / SCALE record says what happened instead of being empty"""
+    return {"metric": "element-steps/sec (dynamics+transport)", "value": None, "unit": "element-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "%dx%d DG2 transport + mEVP (%d sub-iterations)" % (args.nx, args.ny, args.nsub)},
+            "error": "%s: %s" % (type(err).__name__, str(err)[:1000]), "failed_in": where}
 
 
 def host_cores():
@@ -334,9 +363,13 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
     ap.add_argument("--transport-variant", type=int, default=None, help="transport stage kernel: 0 one element per lane, 2 two elements per lane (default: library default = 2)")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
-    ap.add_argument("--passes-per-exchange", type=int, default=0,
-                    help="N > 1: mEVP kernel passes (v = 3 or 2 sub-iterations each) between two ghost-row exchanges (ghost depth v k / v k - 1 rows); "
-                         "0 (default) = try 3 and 8 during the warm-up and keep the faster")
+    ap.add_argument("--passes-per-exchange", type=int, default=3,
+                    help="N > 1: mEVP kernel passes (v = 4 sub-iterations each with the default kernel) between two ghost-row exchanges "
+                         "(ghost depth v k / v k - 1 rows); default 3")
+    ap.add_argument("--tune-passes", type=str, default="",
+                    help="N > 1, explicit opt-in: comma-separated candidates for --passes-per-exchange, e.g. 2,3,6: each is run for two un-timed "
+                         "steps in the warm-up (a context and a communicator of its own) and the fastest is kept.  Off by default: a plain "
+                         "N-rank run creates exactly ONE library communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["native", "torch"], default="native",
                     help="N > 1: ghost-row exchange through the C ABI (nsdg_halo_*, RCCL calls and pack kernels in libnsdg.so) or through torch.distributed P2P ops")
@@ -372,7 +405,7 @@ def main():
         with stdout_to_stderr():
             import datetime
 
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=COMM_DEADLINE_S))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=TORCH_TIMEOUT_S))
             dist.barrier()  # the first collective creates torch's communicator (and waits for rank 0's build)
             torch.cuda.synchronize()
 
@@ -450,16 +483,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Passes per exchange.  How many kernel passes should run between two ghost exchanges depends on what a transfer costs
-    # on the machine the job runs on -- mostly latency (few, large exchanges win: 8 passes) or mostly bandwidth (small, hidden
-    # exchanges and fewer redundant ghost rows win: 3 passes) -- and that is only known on the real
-    # links.  With --passes-per-exchange 0 (the default) an N-rank run therefore TRIES both during the warm-up, two
-    # un-timed steps each, and keeps the faster one (max over ranks); the timed region then runs K steps of that choice.
+    # Passes per exchange: a fixed 3 by default (with a transfer time proportional to the bytes few passes
+    # per exchange win, and the first runs on real links should be boring: ONE context, ONE library communicator).  What a
+    # transfer costs on the machine -- mostly latency or mostly bandwidth -- is only known there, so --tune-passes K1,K2,...
+    # tries the candidates during the warm-up, two un-timed steps each, and keeps the fastest (max over ranks).
     tune = None
-    kpass = args.passes_per_exchange
-    if eff_world > 1 and kpass == 0:
+    kpass = max(args.passes_per_exchange, 1)
+    cands = [int(x) for x in args.tune_passes.split(",") if x.strip()] if eff_world > 1 else []
+    if cands:
         tune = {}
-        for cand in (3, 8):
+        for cand in cands:
             c_, b_, d_, ex_, nat_, co_ = build_core(cand)
             if d_ in [t["ghost_depth"] for t in tune.values()]:  # short blocks cap the depth: both candidates are the same plan
                 co_.close()
@@ -480,34 +513,43 @@ def main():
             co_ = ex_ = None
             c_.close()
         kpass = min(tune, key=lambda k_: tune[k_]["ms_per_step"])
-    elif kpass == 0:
-        kpass = 3
     ctx, blk, depth, exchanger, native, core = build_core(kpass)
     del H, A, uo, vo, ua, va, column
 
     def sync():
         drain(ctx, exchanger)
 
-    for _ in range(args.warmup):
-        core.step()
-    sync()
-    exchange_stats(core, reset=True)  # count the exchanges of the timed region only
-    # Timed region: EXACTLY what core.step() does (column thermodynamics when coupled, per-step preparation, the
-    # sub-cycle, transport), with HIP events on the context's stream around the sub-cycle for the dominant kernel
-    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record(ctx.stream)
-        core._set_grid()
-        if coupled:
-            core.thermodynamics()
-        core.prepare()
-        ev[k][1].record(ctx.stream)
-        core.subcycle()
-        ev[k][2].record(ctx.stream)
-        core.transport()
-        ev[k][3].record(ctx.stream)
-    sync()
+    where = "warm-up"
+    try:
+        for _ in range(args.warmup):
+            core.step()
+        sync()
+        optional("exchange_stats(reset)", exchange_stats, core, reset=True)  # count the exchanges of the timed region only
+        # Timed region: EXACTLY what core.step() does (column thermodynamics when coupled, per-step preparation, the
+        # sub-cycle, transport), with HIP events on the context's stream around the sub-cycle for the dominant kernel
+        where = "timed region"
+        ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            ev[k][0].record(ctx.stream)
+            core._set_grid()
+            if coupled:
+                core.thermodynamics()
+            core.prepare()
+            ev[k][1].record(ctx.stream)
+            core.subcycle()
+            ev[k][2].record(ctx.stream)
+            core.transport()
+            ev[k][3].record(ctx.stream)
+        sync()
+    except (abi.NsdgError, RuntimeError) as e:
+        # a failed launch, a broken communicator, a device error: rank 0 still prints a line (value null + the error), every
+        # rank leaves with a non-zero status WITHOUT destructors (they would synchronise a device that may never drain)
+        sys.stderr.write("bench.py rank %d failed in the %s: %r\n" % (rank, where, e))
+        if rank == 0:
+            print(json.dumps(failure_line(args, world, where, e)), flush=True)
+        sys.stderr.flush()
+        os._exit(3)
     elapsed = time.perf_counter() - t0
     own_elapsed = elapsed
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -519,7 +561,7 @@ def main():
                    "cycle_ms": cycle_ms, "prepare_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
                    "transport_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev])),
                    "step_gpu_ms": float(np.mean([e[0].elapsed_time(e[3]) for e in ev])), "step_wall_ms": 1e3 * own_elapsed / args.steps}
-    rank_report.update(exchange_stats(core, steps=args.steps))
+    rank_report.update(optional("exchange_stats", exchange_stats, core, steps=args.steps) or {})
     reports = [rank_report]
     if use_dist:
         reports = [None] * world
@@ -552,28 +594,37 @@ def main():
         # time is its share of the sub-iterations (remainder launches of 2 / 1 sub-iterations are the minority)
         launch_ms = cycle_ms * per_launch / nsub
         compulsory = own_elems * BYTES_COMPULSORY_PER_PASS
+        algorithmic = own_elems * BYTES_PER_ELEM_SUBITER * per_launch  # SURVEY.md section 8(d) x the sub-iterations of a launch
         achieved = compulsory / (launch_ms * 1e-3) / 1e9
-        off = offline_counters(nx, ny, fused_kernel) if eff_world == 1 else None
-        copy_peak = copy_peak_gbs(ctx, device)
+        survey_gbs = algorithmic / (launch_ms * 1e-3) / 1e9
+        off = optional("offline_counters", offline_counters, nx, ny, fused_kernel) if eff_world == 1 else None
+        copy_peak = optional("copy_peak_gbs", copy_peak_gbs, ctx, device)
         roof = {"bound": "hbm", "kernel": fused_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "copy_peak_GBs": copy_peak, "frac_of_copy_peak": achieved / copy_peak,
+                "frac_definition": "frac = frac_compulsory = compulsory_bytes_per_launch / avg_launch_ms / 8 TB/s: the bytes one pass must move whatever it "
+                                   "keeps on chip; a pass performs subiterations_per_launch sub-iterations on them, so fractions of kernels with "
+                                   "different numbers of sub-iterations per pass do not compare -- ms_per_subiteration does",
+                "frac_compulsory": achieved / HBM_PEAK_GBS,
+                "survey_8d_ratio": survey_gbs / HBM_PEAK_GBS,
+                "survey_8d_note": "algorithmic_bytes_per_launch / avg_launch_ms / 8 TB/s with the one-HBM-round-trip-per-sub-iteration byte model of "
+                                  "SURVEY.md 8(d); the fused kernel keeps the intermediate stress and velocity of %d sub-iterations on chip, so "
+                                  "this ratio is NOT a roofline fraction (it exceeds 1)" % per_launch,
+                "copy_peak_GBs": copy_peak, "frac_of_copy_peak": (achieved / copy_peak) if copy_peak else None,
                 "copy_peak_note": "measured in this run on this box: nsdg_copy_f64, 16 bytes per lane, 1 GiB read + 1 GiB written per launch "
                                   "(SURVEY.md 8(d): 'additionally against a measured device-copy peak on the box')",
                 "traffic": off["traffic"] if off else None,
                 "traffic_source": (off["source"] + (" -- STALE: kernel sources changed since" if off["stale"] else "")) if off else None,
-                "algorithmic_bytes_per_launch": compulsory,
+                "wasted_traffic_ratio": (off["traffic"] / compulsory) if off else None,
+                "algorithmic_bytes_per_launch": algorithmic,
+                "algorithmic_bytes_model": "SURVEY.md 8(d): %d B per element and sub-iteration x %d sub-iterations per launch x owned elements" % (
+                    BYTES_PER_ELEM_SUBITER, per_launch),
                 "compulsory_bytes_per_launch": compulsory,
-                "bytes_model": "%d B per element and launch: u,v of the 4 owned nodes 64 + ice strength 72 + stress in 192 + nodal coefficients 192 "
-                               "+ stress out 192 + u,v out 64; a launch performs %d sub-iterations on them" % (BYTES_COMPULSORY_PER_PASS, per_launch),
+                "compulsory_bytes_model": "%d B per element and launch: u,v of the 4 owned nodes 64 + ice strength 72 + stress in 192 + nodal coefficients 192 "
+                                          "+ stress out 192 + u,v out 64" % BYTES_COMPULSORY_PER_PASS,
                 "avg_launch_ms": launch_ms, "launches_per_step": launches, "subiterations_per_launch": per_launch,
+                "ms_per_subiteration": launch_ms / per_launch,
                 "hbm_physical_frac": (off["traffic"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if off else None,
-                "valu_issue_frac": valu_issue_frac(off["valu_insts"], launch_ms, ctx) if off and off.get("valu_insts") else None,
-                "survey_8d": {"bytes_per_element_subiteration": BYTES_PER_ELEM_SUBITER,
-                              "equivalent_GBs": own_elems * BYTES_PER_ELEM_SUBITER * per_launch / (launch_ms * 1e-3) / 1e9,
-                              "ratio_to_hbm_peak": own_elems * BYTES_PER_ELEM_SUBITER * per_launch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "note": "one-pass-per-sub-iteration byte model of SURVEY.md 8(d); the fused kernel keeps the intermediate stress and "
-                                      "velocity of %d sub-iterations on chip, so this ratio is NOT a roofline fraction (it may exceed 1)" % per_launch}}
+                "valu_issue_frac": valu_issue_frac(off["valu_insts"], launch_ms, ctx) if off and off.get("valu_insts") else None}
         line = {
             "metric": "element-steps/sec (dynamics+transport)", "value": None if loop_world else value, "unit": "element-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -585,7 +636,7 @@ def main():
                        "decomposition": "%d row block(s), ghost-row send/recv" % eff_world + (
                            ", ghost depth %d/%d rows, one exchange per %d mEVP passes%s, halo=%s" % (
                                depth[0], depth[1], core.group_passes,
-                               " (chosen in the warm-up: %s)" % ", ".join("%d passes %.3f ms/step" % (k_, t_["ms_per_step"]) for k_, t_ in sorted(tune.items())) if tune else "",
+                               " (--tune-passes, chosen in the warm-up: %s)" % ", ".join("%d passes %.3f ms/step" % (k_, t_["ms_per_step"]) for k_, t_ in sorted(tune.items())) if tune else "",
                                args.halo) if eff_world > 1 else ""),
                        "mevp_passes": "%s sub-iteration%s per kernel pass" % ({4: "four", 3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
                        "mevp_variant": args.variant if args.variant is not None else "default",
@@ -601,7 +652,9 @@ def main():
             line["rehearsal"] = ("NOT A MEASUREMENT OF THE METRIC: one GPU plays the interior block %d of %d, both neighbours are the rank itself (real "
                                  "RCCL send/recv groups, values wrap around); ms_per_step is this block's share of the step" % (eff_rank, eff_world))
         if eff_world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(nsub, nx, ny)
+            line["cpu_baseline"] = optional("cpu_baseline", cpu_baseline, nsub, nx, ny)
+        if DIAGNOSTICS_FAILED:
+            line["diagnostics_failed"] = DIAGNOSTICS_FAILED
         print(json.dumps(line), flush=True)
     sync()
     core.close()
@@ -704,21 +757,49 @@ def self_launch(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def exchange_plan(blk, nx, nsub, per_pass):
+    """what one rank's ghost exchanges of a model step move (pure arithmetic from the block geometry; the native plans report
+    the same sizes through nsdg_halo_counts): bytes per mEVP ghost-zone exchange and direction -- tiled stress rows of the
+    three components + node rows of u and v -- the number of such exchanges per step, and the bytes of the one exchange of
+    the advected fields"""
+    tiled_row = ((nx + 63) // 64) * 8 * 64 * 8  # bytes of one element row of one stress component (tiles of 64 elements x 8 coefficients)
+    node_row = (2 * nx + 1) * 8
+    up = (blk.depth_below * 3 * tiled_row + 2 * blk.depth_below * 2 * node_row) if blk.above is not None else 0
+    down = (blk.depth_above * 3 * tiled_row + (2 * blk.depth_above + 1) * 2 * node_row) if blk.below is not None else 0
+    k = max(blk.depth_below // per_pass, 1)
+    groups = -(-(nsub // per_pass) // k) + (1 if nsub % per_pass else 0)
+    field_row = nx * 6 * 8 * 2  # H and A, 6 DG2 coefficients
+    return {"mevp_exchange_bytes_up": up, "mevp_exchange_bytes_down": down, "mevp_exchanges_per_step": groups if blk.world > 1 else 0,
+            "transport_exchange_bytes_up": blk.depth_below * field_row if blk.above is not None else 0,
+            "transport_exchange_bytes_down": blk.depth_above * field_row if blk.below is not None else 0}
+
+
 def dry_run(args, rank, world):
     """Plumbing check without a GPU (tests/test_bench_launch.py, gloo): the launch, the rendezvous, the row-block
-    planning and the max-over-ranks reduction of the real run -- no kernel runs, NO metric is reported."""
+    planning of the REAL run (ghost depths, rows, bytes per exchange: every rank's entry reaches rank 0 as in the `ranks`
+    object of a real line) and the max-over-ranks reduction -- no kernel runs, NO metric is reported."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29512")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    blk, depth = plan_blocks(abi.DEFAULT_MEVP_VARIANT, args.passes_per_exchange or 3, args.nx, args.ny, rank, world)  # 0 = chosen in the warm-up of a real run
+    import datetime
+
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=TORCH_TIMEOUT_S))
+    v = abi.DEFAULT_MEVP_VARIANT
+    blk, depth = plan_blocks(v, max(args.passes_per_exchange, 1), args.nx, args.ny, rank, world)
     rows = torch.tensor([float(blk.r1 - blk.r0)], dtype=torch.float64)
     dist.all_reduce(rows, op=dist.ReduceOp.SUM)
     dist.barrier()
     t = torch.tensor([float(rank)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    entry = {"rank": rank, "rows_owned": blk.r1 - blk.r0, "rows_local": blk.ny, "row_first": blk.r0, "ghost_rows_below": blk.gb, "ghost_rows_above": blk.gt,
+             "neighbour_below": blk.below, "neighbour_above": blk.above}
+    entry.update(exchange_plan(blk, args.nx, args.nsub, min(v, 4)))
+    entries = [None] * world
+    dist.all_gather_object(entries, entry)
     if rank == 0:
         print(json.dumps({"dry_run": True, "metric": None, "value": None, "n_gpus": world, "rows_total": int(rows[0]),
-                          "ghost_depth": list(depth), "max_rank_seen": int(t[0])}), flush=True)
+                          "ghost_depth": list(depth), "passes_per_exchange": depth[0] // min(v, 4) if world > 1 else None,
+                          "subiterations_per_pass": min(v, 4), "max_rank_seen": int(t[0]),
+                          "ranks": sorted(entries, key=lambda e: e["rank"])}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -24,10 +24,20 @@ void broadcastFromRankZero(const RankEnvironment& env, void* buffer, std::size_t
 
 //! The opposite direction, used once per run for the restart file: every rank r > 0 sends `bytes` bytes of `buffer`
 //! to rank 0, which calls sink(r, data, count) for each of them (in the order they arrive; counts may differ between
-//! ranks).  Rank 0's own buffer is not passed to the sink.  The server listens on port + 18.  A rank that has died
-//! never connects: rank 0 then throws std::runtime_error after `timeoutSeconds` (no partial file is written by the
-//! caller), and a sender whose rank 0 has gone throws in the same way.
+//! ranks).  Rank 0's own buffer is not passed to the sink.  The server listens on port + 18.
+//! ACKNOWLEDGED: once every rank has delivered, rank 0 runs `commit` (the write of the restart file) while the
+//! connections are still open and then answers every sender with one status byte.  A sender returns only after that
+//! byte: if rank 0 failed -- the sink or `commit` threw, a rank reported a failure, a rank never connected -- every
+//! sender throws std::runtime_error too, so that no rank of a run without a restart file exits with status 0.
+//! A rank that has died never connects: rank 0 then throws after `timeoutSeconds` (and writes nothing), and a sender
+//! whose rank 0 has gone throws in the same way.  `deadlineSeconds` <= 0 means the communicator's "wait for ever"
+//! (NSDG_COMM_TIMEOUT_S = 0): a day.
 void gatherToRankZero(const RankEnvironment& env, const void* buffer, std::size_t bytes,
-    const std::function<void(int rank, const char* data, std::size_t count)>& sink, int timeoutSeconds = 120);
+    const std::function<void(int rank, const char* data, std::size_t count)>& sink, int timeoutSeconds = 120,
+    const std::function<void()>& commit = nullptr);
+
+//! What a rank r > 0 calls INSTEAD of gatherToRankZero when it cannot deliver (its own run failed): rank 0 learns of it at
+//! once -- its gatherToRankZero throws without waiting for the timeout -- and tells the other ranks.  Never throws.
+void reportFailureToRankZero(const RankEnvironment& env, int timeoutSeconds = 10) noexcept;
 
 } // namespace Nextsim

@@ -426,24 +426,48 @@ void DynamicsStep::writeRestartFile(const std::string& filePath)
 {
     if (!pStructure)
         throw std::logic_error("DynamicsStep::writeRestartFile: setInitialData() was not called");
-    stop(0);
-    if (m_world > 1) {
-        // a rank holds only its own rows up to date: they travel to rank 0, which writes the ONE restart file (every row
-        // of it current).  A rank that has died never delivers: rank 0 throws after the timeout and writes nothing.
-        FieldStore& f = pStructure->fields();
-        const RankEnvironment env = RankEnvironment::fromEnv();
-        int r0, r1;
-        splitRows(nyf, m_world, m_rank, r0, r1);
-        const std::vector<double> mine = m_rank == 0 ? std::vector<double>() : packRows(f, thermo, nxf, r0, r1);
-        gatherToRankZero(env, mine.data(), mine.size() * sizeof(double), [&](int rank, const char* data, std::size_t bytes) {
+    if (m_world <= 1) {
+        stop(0);
+        pStructure->dump(filePath);
+        return;
+    }
+    // A rank holds only its own rows up to date: they travel to rank 0, which writes the ONE restart file (every row of it
+    // current) and ACKNOWLEDGES it: no rank returns before rank 0 has written the file, and if anything fails -- a rank's
+    // fields are non-finite (stop() throws), a rank has died, the write fails -- EVERY rank throws, so that a run without a
+    // restart file never exits with status 0 on some of its ranks.  The waits are bounded by the communicator's deadline
+    // (NSDG_COMM_TIMEOUT_S, the same variable the library and bench.py read; 0 = for ever; default 120 s here).
+    const char* tv = std::getenv("NSDG_COMM_TIMEOUT_S");
+    const int timeout = (tv && *tv) ? std::atoi(tv) : 120;
+    const RankEnvironment env = RankEnvironment::fromEnv();
+    std::exception_ptr own;
+    try {
+        stop(0);
+    } catch (...) {
+        own = std::current_exception();
+    }
+    if (own && m_rank != 0) {
+        reportFailureToRankZero(env, std::min(timeout > 0 ? timeout : 86400, 30));
+        std::rethrow_exception(own);
+    }
+    FieldStore& f = pStructure->fields();
+    int r0, r1;
+    splitRows(nyf, m_world, m_rank, r0, r1);
+    const std::vector<double> mine = (m_rank == 0 || own) ? std::vector<double>() : packRows(f, thermo, nxf, r0, r1);
+    gatherToRankZero(
+        env, mine.data(), mine.size() * sizeof(double),
+        [&](int rank, const char* data, std::size_t bytes) {
+            if (own)
+                return; // rank 0 itself failed: the rows are received and dropped, the senders are told below
             int a, b;
             splitRows(nyf, m_world, rank, a, b);
             placeRows(f, thermo, nxf, a, b, reinterpret_cast<const double*>(data), bytes / sizeof(double));
+        },
+        timeout,
+        [&]() {
+            if (own)
+                std::rethrow_exception(own);
+            pStructure->dump(filePath);
         });
-        if (m_rank != 0)
-            return;
-    }
-    pStructure->dump(filePath);
 }
 
 std::vector<std::vector<double>*> DynamicsStep::restartPlanes(FieldStore& f, bool thermodynamics)

@@ -23,6 +23,7 @@
 #include "ModuleLoader.hpp"
 #include "PhysicsModules.hpp"
 #include "Rendezvous.hpp"
+#include <atomic>
 #include "Timer.hpp"
 
 using namespace Nextsim;
@@ -711,6 +712,60 @@ static void test_restart_gather()
         CHECK(ok);
         const std::vector<double> few(5, 0.);
         CHECK_THROWS_AS(DynamicsStep::placeRows(root, thermo, nx, 0, 3, few.data(), few.size()), std::runtime_error);
+    }
+    // EIGHT ranks (the node the scaling runs use), acknowledged: no sender returns before rank 0's commit (the write of the
+    // restart file) has run; if the commit fails, or a rank reports a failure instead of delivering, EVERY rank throws
+    for (int scenario = 0; scenario < 3; ++scenario) { // 0: all well, 1: the commit throws, 2: rank 5 reports a failure
+        const int W = 8;
+        RankEnvironment env[W];
+        const int port = 20000 + (int)(std::hash<std::thread::id>()(std::this_thread::get_id()) % 20000) + 70 + 3 * scenario;
+        for (int r = 0; r < W; ++r)
+            env[r].world = W, env[r].rank = r, env[r].masterPort = port;
+        std::atomic<bool> committed(false);
+        std::atomic<int> returnedBeforeCommit(0), threw(0);
+        std::vector<std::thread> senders;
+        for (int r = 1; r < W; ++r)
+            senders.emplace_back([&, r] {
+                try {
+                    if (scenario == 2 && r == 5) {
+                        reportFailureToRankZero(env[r], 20);
+                        ++threw; // such a rank rethrows its own error
+                        return;
+                    }
+                    const std::vector<double> rows(1000 + r, (double)r);
+                    gatherToRankZero(env[r], rows.data(), rows.size() * sizeof(double), nullptr, 20);
+                    if (!committed)
+                        ++returnedBeforeCommit;
+                } catch (const std::runtime_error&) {
+                    ++threw;
+                }
+            });
+        int delivered = 0;
+        bool rootThrew = false;
+        try {
+            gatherToRankZero(
+                env[0], nullptr, 0,
+                [&](int rank, const char* data, std::size_t bytes) {
+                    const double* d = reinterpret_cast<const double*>(data);
+                    if (bytes == (1000u + (unsigned)rank) * sizeof(double) && d[0] == (double)rank && d[999 + rank] == (double)rank)
+                        ++delivered;
+                },
+                20,
+                [&]() {
+                    std::this_thread::sleep_for(std::chrono::milliseconds(200)); // a sender that does not wait would be caught
+                    if (scenario == 1)
+                        throw std::runtime_error("disk full");
+                    committed = true;
+                });
+        } catch (const std::runtime_error&) {
+            rootThrew = true;
+        }
+        for (auto& t : senders)
+            t.join();
+        if (scenario == 0)
+            CHECK(delivered == W - 1 && committed && !rootThrew && threw == 0 && returnedBeforeCommit == 0);
+        else
+            CHECK(rootThrew && !committed && threw == W - 1); // every rank of a run without a restart file fails
     }
     // a rank that died before the end never delivers: rank 0 gives up after the timeout instead of hanging
     RankEnvironment alone;

@@ -31,6 +31,36 @@ def test_plain_command_with_two_ranks_self_launches():
     assert lines[0]["ghost_depth"] == [12, 11]  # 3 passes of the four-iteration kernel between two exchanges
 
 
+def test_eight_ranks_plan_the_real_2048_blocks():
+    """the N = 8 run of the scaling record, as far as it goes without GPUs: eight processes through the launcher path, the real
+    2048 x 2048 row blocks with the default passes per exchange (a FIXED 3: ghost depth 12 / 11 with the four-iteration
+    kernel), every rank's entry in the line, the rows tile the grid, and the bytes of an exchange are what the geometry says"""
+    p = run_bench("--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "0")
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout.decode()
+    L = lines[0]
+    assert L["n_gpus"] == 8 and L["rows_total"] == 2048 and L["max_rank_seen"] == 7 and L["value"] is None
+    assert L["ghost_depth"] == [12, 11] and L["passes_per_exchange"] == 3 and L["subiterations_per_pass"] == 4
+    ranks = L["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8))
+    first = 0
+    for r in ranks:
+        assert r["row_first"] == first and r["rows_owned"] == 256
+        first += r["rows_owned"]
+        inner_below, inner_above = r["rank"] > 0, r["rank"] < 7
+        assert r["ghost_rows_below"] == (12 if inner_below else 0) and r["ghost_rows_above"] == (11 if inner_above else 0)
+        assert r["rows_local"] == 256 + r["ghost_rows_below"] + r["ghost_rows_above"]
+        assert r["neighbour_below"] == (r["rank"] - 1 if inner_below else None) and r["neighbour_above"] == (r["rank"] + 1 if inner_above else None)
+        # 12 stress rows of 3 components (32 tiles x 8 coefficients x 64 elements x 8 B) + 24 node rows of u and v (4097 nodes) upwards,
+        # 11 stress rows + 23 node rows downwards; 120 sub-iterations = 30 passes of 4 = 10 groups of 3
+        assert r["mevp_exchange_bytes_up"] == (12 * 3 * 131072 + 24 * 2 * 4097 * 8 if inner_above else 0)
+        assert r["mevp_exchange_bytes_down"] == (11 * 3 * 131072 + 23 * 2 * 4097 * 8 if inner_below else 0)
+        assert r["mevp_exchanges_per_step"] == 10
+        assert r["transport_exchange_bytes_up"] == (12 * 2048 * 96 if inner_above else 0)
+    assert first == 2048
+
+
 def test_worker_failure_is_reported_by_the_exit_status():
     # the workers refuse a world size that does not match --gpus; the parent must pass the failure on
     p = run_bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "3", "RANK": "0"})
@@ -60,3 +90,23 @@ def test_ranks_summary_of_an_n_gpu_line():
     assert s["step_gpu_ms_max"] == 6.5 and s["step_gpu_ms_min"] == 6.0 and abs(s["exchange_ms_per_step_max"] - 1.65) < 1e-12
     # a rank without native-driver statistics (python driver / torch halo) still summarises
     assert bench.ranks_summary([{"rank": 0, "cycle_ms": 1.0, "step_gpu_ms": 2.0}])["exchange_ms_per_step_max"] == 0.0
+
+
+def test_failure_line_and_optional_diagnostics():
+    """a run that fails in its measured part still has a line (value null + the error); an optional diagnostic that fails
+    costs a field, not the line"""
+    import argparse
+
+    import bench
+
+    a = argparse.Namespace(steps=5, warmup=2, nx=2048, ny=2048, nsub=120)
+    L = bench.failure_line(a, 8, "timed region", RuntimeError("ncclRecv: peer gone"))
+    assert L["value"] is None and L["n_gpus"] == 8 and L["failed_in"] == "timed region" and "peer gone" in L["error"]
+    for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in L
+    json.dumps(L)
+    del bench.DIAGNOSTICS_FAILED[:]
+    assert bench.optional("works", lambda x: x + 1, 1) == 2 and not bench.DIAGNOSTICS_FAILED
+    assert bench.optional("copy_peak_gbs", lambda: 1 / 0) is None
+    assert len(bench.DIAGNOSTICS_FAILED) == 1 and "copy_peak_gbs" in bench.DIAGNOSTICS_FAILED[0] and "ZeroDivisionError" in bench.DIAGNOSTICS_FAILED[0]
+    del bench.DIAGNOSTICS_FAILED[:]

@@ -132,6 +132,16 @@ def test_native_driver_equals_python_driver_in_rccl_loopback(gpu, overlap):
             core.step()
         torch.cuda.synchronize()
         res.append([x.clone() for x in (core.u, core.v, core.H, core.A, core.s[0], core.s[2])])
+        if native:
+            # the sizes bench.py's dry run plans from the geometry alone are the sizes the native plans really move
+            import bench
+
+            plan = bench.exchange_plan(blk, nx, nsub, core.per_pass)
+            st = core._run_mevp.stats(False)
+            assert st["bytes_sent"] == plan["mevp_exchange_bytes_up"] + plan["mevp_exchange_bytes_down"], (st, plan)
+            assert st["exchanges"] == 2 * plan["mevp_exchanges_per_step"], (st, plan)
+            tr = core._run_transport.stats(False)
+            assert tr["bytes_sent"] == plan["transport_exchange_bytes_up"] + plan["transport_exchange_bytes_down"], (tr, plan)
         del core, ex
         c.close()
     assert float(res[0][0].abs().max()) > 1e-6
