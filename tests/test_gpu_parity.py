@@ -897,3 +897,51 @@ def test_hip_path_matches_the_frozen_oracle_outputs(ctx, variant):
         assert_close(host(core.col[k]), want[k], 1e-10, 1e-12, "frozen coupled " + k)
     ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     ctx.set_mevp_params(ctx.mevp_default_params())
+
+
+@pytest.mark.parametrize("variant", [1, abi.DEFAULT_MEVP_VARIANT])
+def test_hip_path_matches_the_independent_restatement(ctx, variant):
+    """the HIP path against tests/golden/dyn_independent_v1.npz -- the outputs of the independent dense numpy restatement of
+    DESIGN.md section 3 (tests/dyn_independent.py), which the oracle is held to on the CPU: ice strength, nodal means, wind
+    stress, ONE mEVP sub-iteration and ONE DG2 transport stage on the 6 x 5 case, through the C ABI.  Not reference parity
+    (the snapshot has no dynamics code, /root/reference/CMakeLists.txt:43-46): it removes the common mode of oracle and kernels."""
+    import dyn_independent as D
+
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v1.npz"))
+    c, nx, ny = D.CASE, D.CASE["nx"], D.CASE["ny"]
+    I = lambda k: np.ascontiguousarray(fix["in_" + k])
+    W = lambda k: fix["out_" + k]
+    ctx.set_grid(nx, ny, c["hx"], c["hy"])
+    ctx.set_mevp_params(ctx.mevp_default_params(**{k: D.PARAMS[k] for k in D.PARAMS}))
+    ctx.set_mevp_variant(variant)
+    ctx.set_mevp_strip_rows(0)
+    H, A = dev(I("H")), dev(I("A"))
+    pg = ctx.private_zeros(9, ny, nx, "cuda")
+    ctx.ice_strength(H, A, pg)
+    assert_close(thost(pg, nx), W("pg"), 1e-12, 1e-13 * np.max(W("pg")), "ice strength")
+    cgh, cga = torch.zeros(2 * ny + 1, 2 * nx + 1, dtype=torch.float64, device="cuda"), torch.zeros(2 * ny + 1, 2 * nx + 1, dtype=torch.float64, device="cuda")
+    ctx.dg_to_cg(H, cgh)
+    ctx.dg_to_cg(A, cga)
+    assert_close(host(cgh), W("cgh"), 1e-12, 1e-14, "nodal mean of H")
+    assert_close(host(cga), W("cga"), 1e-12, 1e-14, "nodal mean of A")
+    tax, tay = torch.zeros_like(cgh), torch.zeros_like(cgh)
+    ctx.wind_stress(dev(I("ua")), dev(I("va")), tax, tay)
+    assert_close(host(tax), W("tax"), 1e-12, 1e-14, "wind stress")
+    # one sub-iteration through nsdg_mevp_subcycle (the variant's kernel for a single sub-iteration and the packing)
+    u, v = dev(I("u")), dev(I("v"))
+    S = [tdev(np.ascontiguousarray(x)) for x in I("S")]
+    scratch = torch.zeros(10 * u.numel() + 3 * S[0].numel(), dtype=torch.float64, device="cuda")
+    ctx.mevp_subcycle(c["dt"], 1, S, u, v, dev(I("u0")), dev(I("v0")), tax, tay, dev(I("uo")), dev(I("vo")), cgh, cga, pg, scratch)
+    for k, name in enumerate(("s11", "s12", "s22")):
+        assert_close(thost(S[k], nx), W(name), 1e-11, 1e-12 * np.max(np.abs(W(name))), name)
+    assert_close(host(u), W("u_new"), 1e-11, 1e-12 * np.max(np.abs(W("u_new"))), "u after one sub-iteration")
+    assert_close(host(v), W("v_new"), 1e-11, 1e-12 * np.max(np.abs(W("v_new"))), "v after one sub-iteration")
+    # advection velocity and one RK stage of the DG2 transport
+    adv = adv_on_device(ctx, nx, ny, 2, I("u"), I("v"))
+    for a, name in zip(adv, ("vx_dg", "vy_dg", "un_x", "un_y")):
+        assert_close(host(a), W(name), 1e-12, 1e-13 * np.max(np.abs(W(name))), name)
+    out = torch.zeros(6, ny, nx, dtype=torch.float64, device="cuda")
+    ctx.transport_stage(2, 0, ny, c["dt"], c["rk_a"], c["rk_b"], [dev(I("phi0"))], [dev(I("phi"))], [out], adv)
+    assert_close(host(out), W("phi_stage"), 1e-12, 1e-13 * np.max(np.abs(W("phi_stage"))), "DG2 transport stage")
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
+    ctx.set_mevp_params(ctx.mevp_default_params())

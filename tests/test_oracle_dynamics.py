@@ -331,3 +331,46 @@ def test_nodal_divergence_is_the_weak_divergence_of_the_dg_stress():
     np.testing.assert_allclose(vn[inner] * scale * lump[inner], divy[inner], rtol=1e-12, atol=1e-12)
     for a in (un, vn):  # Dirichlet walls
         assert np.all(a[0] == 0) and np.all(a[-1] == 0) and np.all(a[:, 0] == 0) and np.all(a[:, -1] == 0)
+
+
+def test_oracle_agrees_with_the_independent_restatement():
+    """tests/dyn_independent.py restates DESIGN.md section 3 a second time, in dense numpy, from the formulas only and by
+    different routes (zeta / eta form of the VP law, strain from the derivative of the biquadratic instead of the projected
+    coefficients, full-mass-matrix projections, weak divergence by quadrature).  Its outputs on a 6 x 5 case are committed
+    (tests/golden/dyn_independent_v1.npz, tools/gen_dyn_independent.py); the oracle must reproduce every one of them --
+    ice strength, nodal means, wind stress, ONE mEVP sub-iteration (stress and velocity), advection velocity, ONE DG2
+    transport stage -- to 1e-12.  NOT reference parity: the snapshot has no dynamics code (/root/reference/CMakeLists.txt:43-46).
+    A fresh evaluation of the restatement must equal the committed file (the file is not an opaque blob)."""
+    import dyn_independent as D
+
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v1.npz"))
+    inp = D.case_inputs()
+    for k, v in inp.items():
+        v = np.stack(v) if isinstance(v, list) else v
+        assert np.array_equal(fix["in_" + k], v), k
+    fresh = D.case_outputs(inp)
+    rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    for k, v in fresh.items():
+        assert rel(v, fix["out_" + k]) < 1e-13, ("fresh evaluation", k)
+    c, nx, ny = D.CASE, D.CASE["nx"], D.CASE["ny"]
+    po = O.mevp_params(**D.PARAMS)
+    got = {"pg": O.ice_strength(nx, ny, po, inp["H"], inp["A"]), "cgh": O.dg_to_cg(nx, ny, inp["H"]), "cga": O.dg_to_cg(nx, ny, inp["A"])}
+    got["tax"], got["tay"] = O.wind_stress(po, inp["ua"], inp["va"])
+    s = [x.copy() for x in inp["S"]]
+    O.mevp_stress(nx, ny, 0, ny, c["hx"], c["hy"], po, inp["u"], inp["v"], got["pg"], *s)
+    got["s11"], got["s12"], got["s22"] = s
+    un, vn = np.zeros_like(inp["u"]), np.zeros_like(inp["u"])
+    O.mevp_velocity(nx, ny, 0, ny, c["hx"], c["hy"], c["dt"], po, s, (inp["u"], inp["v"]), (un, vn), (inp["u0"], inp["v0"]),
+                    (got["tax"], got["tay"]), (inp["uo"], inp["vo"]), got["cgh"], got["cga"])
+    got["u_new"], got["v_new"] = un, vn
+    adv = O.prepare_advection(nx, ny, 2, inp["u"], inp["v"])
+    got["vx_dg"], got["vy_dg"], got["un_x"], got["un_y"] = adv
+    out = np.zeros_like(inp["phi"])
+    O.transport_stage(nx, ny, 0, ny, c["hx"], c["hy"], 2, c["dt"], c["rk_a"], c["rk_b"], inp["phi0"], inp["phi"], out, adv)
+    got["phi_stage"] = out
+    assert sorted(got) == sorted(fresh)
+    for k, v in got.items():
+        assert rel(v, fix["out_" + k]) < 1e-12, (k, rel(v, fix["out_" + k]))
+    # the case exercises the clamps and the floor: concentration above 1 and thickness below 0 at Gauss points, a node thinner than h_min
+    assert float(fix["out_cga"].max()) > 1.0 and float(fix["out_cgh"].min()) < D.PARAMS["h_min"] and float(np.abs(fix["out_u_new"]).max()) > 0.05
+    assert float((fix["out_pg"] == 0.0).sum()) > 0  # max(h, 0) was active
