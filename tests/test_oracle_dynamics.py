@@ -3,6 +3,8 @@
 PARITY UNPINNED: the reference snapshot contains no DG transport or mEVP implementation, test or
 fixture, so these tests pin the oracle to the mathematics it restates rather than
 to reference outputs."""
+import os
+
 import numpy as np
 import pytest
 
