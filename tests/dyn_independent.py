@@ -293,7 +293,7 @@ def case_inputs():
     H[1:] = 0.02 * rng.standard_normal((5, ny, nx))
     H[:, 2, 3] = 0.0
     H[0, 2, 3] = 5e-5  # thinner than h_min at the centre node of this element
-    H[0, 1, 1] = 0.01  # ... and negative at some Gauss points of this one (max(h, 0) in the ice strength)
+    H[0, 1, 1], H[1, 1, 1] = 0.002, 0.05  # ... and negative at the left Gauss points of this one (max(h, 0) in the ice strength)
     A[0] = 0.9 + 0.08 * rng.standard_normal((ny, nx))
     A[1:] = 0.05 * rng.standard_normal((5, ny, nx))
     inp["H"], inp["A"] = H, A
