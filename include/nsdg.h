@@ -129,7 +129,15 @@ int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hice, double* 
     const double* wind, double* newice, double* diag);
 
 /* ---- dynamics: DG transport + mEVP (no counterpart in the reference snapshot: CMakeLists.txt:43-46
- *      comments the dynamics component out; built from the published formulation) */
+ *      comments the dynamics component out; built from the published formulation)
+ * VALID INPUT DOMAIN (round 4, profiles/r04_soak_divergence_cause.md).  The scheme has no redistribution closure (nothing caps
+ * the concentration at 1: the reference has none either, physics/src/modules/HiblerConcentration.cpp:32-38), no limiter in the
+ * DG2 transport and no treatment of nodes without ice.  It is valid for a compact cover that starts at A = 1 (the box test: the
+ * clamp of A in the ice strength makes dP/dA = 0) and for any run that ends before a row of elements at a closed boundary has
+ * converged to A = 1.  Beyond that a one-element-wide band piles up at the wall, breaks into converging and diverging cells,
+ * the transport undershoots beside it, the nodal mass reaches h_min and the velocity of such a node runs away -- after 22
+ * model hours from a uniform A = 0.9 at 4096 x 4096, after 34-43 hours at 1024 x 1024.  A larger alpha = beta only delays the
+ * sequence.  The calls do not check this; both hosts stop loudly on non-finite fields. */
 typedef struct {
     double rho_ice, rho_atm, rho_ocean;
     double c_atm, c_ocean;

@@ -8,7 +8,12 @@ freeze (HiblerConcentration.cpp:32-38: del_c = newice / h0, no limit at 1) and t
 piles concentration up; no limiter exists in the scheme).  The run therefore books, per step and on the device, the
 EXCESS E = sum over elements of max(A - 1, 0) (cell means) before the column step, after it and after the transport, and
 reports which of the two produced it (cumulative, and over the last reporting interval), with the maxima of A after each.
-usage: python tools/soak_coupled.py [steps=720] [n=512] [forcing=winter|dummy|host]"""
+usage: python tools/soak_coupled.py [steps=720] [n=512] [forcing=winter|dummy|host]
+
+NSDG_SOAK_DIAG=first,last[,every]: per-step device-side dump for the steps first..last (round 4: where and why a run leaves the
+physical range): the node of the largest speed, and around it the cell means and Gauss-point extrema of H and A, the ice
+strength, the nodal thickness that enters the mass, the strain rate; plus domain-wide extrema and the change of the velocity
+over the last kernel pass of the sub-cycle (how far from converged it is)."""
 import os
 import sys
 import time
@@ -21,7 +26,7 @@ from nextsimdg_amd import abi, rowblock, synthetic
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 720
 nx = ny = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 forcing = sys.argv[3] if len(sys.argv) > 3 else "winter"
-L, dt, nsub = 512e3, 120.0, 120
+L, dt, nsub = 512e3, float(os.environ.get("NSDG_SOAK_DT", "120")), 120  # NSDG_SOAK_DT: model time step (experiments on the strength / concentration coupling)
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
@@ -43,6 +48,73 @@ uo, vo = bt.ocean()
 ua, va = bt.wind(0.0)
 core.load_global(H, A, uo, vo, ua, va)
 del H, A, uo, vo, ua, va, cs, cf
+diag = [int(x) for x in os.environ.get("NSDG_SOAK_DIAG", "").split(",") if x]
+if diag:
+    import numpy as np
+
+    g = 0.5 * np.sqrt(0.6)
+    gp = [(x, y) for y in (-g, 0.0, g) for x in (-g, 0.0, g)]
+    psi = lambda x, y: (1.0, x, y, x * x - 1.0 / 12.0, y * y - 1.0 / 12.0, x * y)
+    GP = torch.tensor([psi(x, y) for (x, y) in gp], dtype=torch.float64, device=dev)  # [9, 6]: DG2 basis at the 3 x 3 Gauss points
+
+
+def dump(step):
+    """where the speed is largest, and what the scheme sees there"""
+    hx, hy = L / nx, L / ny
+    sp = core.u * core.u + core.v * core.v
+    k = int(torch.argmax(sp))
+    gy, gx = divmod(k, 2 * nx + 1)
+    iy, ix = min(gy // 2, ny - 1), min(gx // 2, nx - 1)
+    y0, y1, x0, x1 = max(iy - 2, 0), min(iy + 3, ny), max(ix - 2, 0), min(ix + 3, nx)
+    Hw, Aw = core.H[:, y0:y1, x0:x1], core.A[:, y0:y1, x0:x1]
+    Hg, Ag = torch.einsum("qc,cyx->qyx", GP, Hw), torch.einsum("qc,cyx->qyx", GP, Aw)
+    hnode = core.packed[:6 * (2 * ny + 1) * (2 * nx + 1)].view(2 * ny + 1, 2 * nx + 1, 6)[:, :, 0]  # h' = max(cgH, h_min) of the last packing
+    pgw = abi.untile(core.pg, nx)[:, y0:y1, x0:x1]
+    # strain rate at the element centres of the window from the nodal velocities (central differences over the element)
+    U, V = core.u[2 * y0:2 * y1 + 1, 2 * x0:2 * x1 + 1], core.v[2 * y0:2 * y1 + 1, 2 * x0:2 * x1 + 1]
+    e11 = (U[1::2, 2::2] - U[1::2, :-2:2]) / hx
+    e22 = (V[2::2, 1::2] - V[:-2:2, 1::2]) / hy
+    e12 = 0.5 * ((U[2::2, 1::2] - U[:-2:2, 1::2]) / hy + (V[1::2, 2::2] - V[1::2, :-2:2]) / hx)
+    delta = torch.sqrt(4e-18 + 1.25 * (e11 * e11 + e22 * e22) + 1.5 * e11 * e22 + e12 * e12)
+    allH, allA = torch.einsum("qc,cyx->qyx", GP, core.H), torch.einsum("qc,cyx->qyx", GP, core.A)
+    print("DIAG step %4d  umax %.4g at node (%d, %d) = element (%d, %d);  |u - u four sub-iterations earlier| max %.3g;  domain: H at Gauss points [%.4g, %.4g], "
+          "A at Gauss points [%.4g, %.4g], nodal thickness h' min %.4g, ice strength max %.4g"
+          % (step, float(sp.flatten()[k].sqrt()), gy, gx, iy, ix, float(torch.maximum((core.u - core.ub).abs().max(), (core.v - core.vb).abs().max())),
+             float(allH.min()), float(allH.max()), float(allA.min()), float(allA.max()), float(hnode.min()), float(core.pg.max())), flush=True)
+    f = lambda t: np.array2string(t.cpu().numpy(), precision=4, max_line_width=200, suppress_small=False)
+    print("  window rows %d..%d, columns %d..%d (top row = highest y)" % (y0, y1 - 1, x0, x1 - 1))
+    for name, t in (("H mean", Hw[0]), ("H min over Gauss points", Hg.min(0).values), ("A mean", Aw[0]), ("A min over Gauss points", Ag.min(0).values),
+                    ("A max over Gauss points", Ag.max(0).values), ("ice strength max over Gauss points", pgw.max(0).values),
+                    ("ice strength min over Gauss points", pgw.min(0).values), ("Delta at the element centre", delta),
+                    ("divergence e11 + e22", e11 + e22), ("nodal thickness h' at the centre nodes", hnode[2 * y0 + 1:2 * y1:2, 2 * x0 + 1:2 * x1:2]),
+                    ("speed at the centre nodes", sp[2 * y0 + 1:2 * y1:2, 2 * x0 + 1:2 * x1:2].sqrt())):
+        print("  %s\n%s" % (name, f(t.flip(0))), flush=True)
+    del allH, allA
+
+
+def limit(F, lo, hi):
+    """EXPERIMENT (NSDG_SOAK_LIMITER=1; torch, outside the product path): Zhang-Shu scaling limiter after the transport -- the
+    higher coefficients of a DG2 field are scaled towards the cell mean until its values at the 3 x 3 Gauss points lie in [lo, hi]
+    (hi = None: no upper bound); the cell mean -- the conserved quantity -- is untouched"""
+    g = torch.einsum("qc,cyx->qyx", GP, F)
+    mean = F[0]
+    gmin, gmax = g.min(0).values, g.max(0).values
+    theta = torch.ones_like(mean)
+    theta = torch.minimum(theta, ((mean - lo).clamp_min(0.0) / (mean - gmin).clamp_min(1e-300)))
+    if hi is not None:
+        theta = torch.minimum(theta, ((hi - mean).clamp_min(0.0) / (gmax - mean).clamp_min(1e-300)))
+    F[1:] *= theta.clamp(0.0, 1.0)
+    return float((theta < 1.0).sum())
+
+
+limiter = os.environ.get("NSDG_SOAK_LIMITER") == "1"
+if limiter and not diag:
+    import numpy as np
+
+    g = 0.5 * np.sqrt(0.6)
+    psi = lambda x, y: (1.0, x, y, x * x - 1.0 / 12.0, y * y - 1.0 / 12.0, x * y)
+    GP = torch.tensor([psi(x, y) for y in (-g, 0.0, g) for x in (-g, 0.0, g)], dtype=torch.float64, device=dev)
+limited = 0.0
 m0 = float(core.H[0].sum())
 every = int(os.environ.get("NSDG_SOAK_EVERY", max(1, steps // 12)))
 torch.cuda.synchronize()
@@ -63,11 +135,15 @@ for step in range(steps):
     amax["column"] = torch.maximum(amax["column"], core.A[0].max())
     core.momentum()
     core.transport()
+    if limiter:
+        limited = limit(core.H, 0.0, None) + limit(core.A, 0.0, 1.0)
     core.time += core.dt
     e2 = excess()
     amax["transport"] = torch.maximum(amax["transport"], core.A[0].max())
     made["column"] += e1 - e0
     made["transport"] += e2 - e1
+    if diag and diag[0] <= step <= diag[1] and (step - diag[0]) % (diag[2] if len(diag) > 2 else 1) == 0:
+        dump(step)
     if step % every == 0 or step == steps - 1:
         fin = all(bool(torch.isfinite(f).all()) for f in (core.u, core.v, core.H, core.A, core.col["hsnow"], core.col["tice0"]))
         if not fin:
@@ -87,6 +163,8 @@ for step in range(steps):
               % (float(excess()), tot["column"], tot["transport"], tot["column"] - last["column"], tot["transport"] - last["transport"],
                  float(amax["column"]), float(amax["transport"])), flush=True)
         last = tot
+        if limiter:
+            print("           limiter (experiment): %d elements scaled in this step" % limited, flush=True)
         if not fin or float(core.u.abs().max()) > 5.0:
             raise SystemExit("the coupled run left the physical range")
 torch.cuda.synchronize()
