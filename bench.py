@@ -306,20 +306,43 @@ def transport_bench(args, device):
     scratch = z(2 * phi.size)
     dt = 0.1 / (2 * order + 1) * (1.0 / n) / np.pi
     m0 = float(d[0].sum())
-    for _ in range(max(args.warmup, 1)):
-        ctx.transport_step(order, dt, [d], adv, scratch)
+    # --transport-fused (default for this workload): all stages of a step in ONE launch (nsdg_transport_step_oop), the field
+    # ping-pongs between two buffers; --no-transport-fused: one launch per stage (nsdg_transport_step, in place)
+    fused = not args.no_transport_fused
+    d2 = torch.empty_like(d)
+    if fused:
+        # the two paths are bit-identical: checked here on the live field before anything is timed
+        chk = d.clone()
+        ctx.transport_step(order, dt, [chk], adv, scratch)
+        ctx.transport_step_oop(order, dt, [d], [d2], adv)
+        if not torch.equal(chk, d2):
+            raise SystemExit("transport bench: the fused-stages step differs from the staged step: invalid run")
+        del chk
+
+    def step(k):
+        if fused:
+            a, b = (d, d2) if k % 2 == 0 else (d2, d)
+            ctx.transport_step_oop(order, dt, [a], [b], adv)
+        else:
+            ctx.transport_step(order, dt, [d], adv, scratch)
+
+    nwarm = max(args.warmup, 1) + (max(args.warmup, 1) % 2)  # an even number of steps: the field is back in d
+    nsteps = args.steps + (args.steps % 2 if fused else 0)
+    for k in range(nwarm):
+        step(k)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(ctx.stream)
-    for _ in range(args.steps):
-        ctx.transport_step(order, dt, [d], adv, scratch)
+    for k in range(nsteps):
+        step(k)
     e1.record(ctx.stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ms = e0.elapsed_time(e1) / args.steps
+    ms = e0.elapsed_time(e1) / nsteps
     if abs(float(d[0].sum()) - m0) > 1e-11 * abs(m0):
         raise SystemExit("transport bench lost mass: invalid run")
+    args.steps = nsteps
     stages = order + 1
     per_stage = 8 * nc * 2 + 2 * 8 * nc + 2 * ng * 8
     alg = n * n * stages * per_stage
@@ -341,9 +364,11 @@ def transport_bench(args, device):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%dx%d DG%d advection-only rotating patch, SSP-RK%d, 1 field" % (n, n, order, stages)},
-        "roofline": {"bound": "hbm", "kernel": "transport_stage_kernel<%d> x %d" % (order, stages), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg / stages,
-                     "avg_launch_ms": ms / stages},
+        "roofline": {"bound": "hbm", "kernel": ("transport_fused_kernel<%d> (all %d stages in one launch)" if fused else "transport_stage_kernel<%d> x %d") % (order, stages),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg if fused else alg / stages,
+                     "avg_launch_ms": ms if fused else ms / stages, "launches_per_step": 1 if fused else stages,
+                     "self_check": "fused-stages step == staged step bitwise on the live field" if fused else None},
         "cpu_baseline": {"value": cpu, "unit": "element-steps/s", "cores": 1, "kind": "port",
                          "sample": "oracle/dyn_oracle.c, %d RK steps of a 256x256 grid, single thread" % reps}}), flush=True)
 
@@ -370,6 +395,7 @@ def main():
                     help="N > 1, explicit opt-in: comma-separated candidates for --passes-per-exchange, e.g. 2,3,6: each is run for two un-timed "
                          "steps in the warm-up (a context and a communicator of its own) and the fastest is kept.  Off by default: a plain "
                          "N-rank run creates exactly ONE library communicator")
+    ap.add_argument("--no-transport-fused", action="store_true", help="transport workload: one launch per Runge-Kutta stage instead of all stages in one launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["native", "torch"], default="native",
                     help="N > 1: ghost-row exchange through the C ABI (nsdg_halo_*, RCCL calls and pack kernels in libnsdg.so) or through torch.distributed P2P ops")

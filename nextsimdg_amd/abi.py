@@ -89,6 +89,7 @@ SYMBOLS = {
     "nsdg_transport_variant_set": (C.c_int, [VP, I32, I32]),
     "nsdg_transport_stage": (C.c_int, [VP, I32, I32, I32, D, D, D, I32, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
     "nsdg_transport_step": (C.c_int, [VP, I32, D, I32, C.POINTER(VP)] + [VP] * 5),
+    "nsdg_transport_step_oop": (C.c_int, [VP, I32, D, I32, C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
     "nsdg_dg_to_cg": (C.c_int, [VP, I32, VP, VP]),
     "nsdg_ice_strength": (C.c_int, [VP, I32, I32, VP, VP, VP]),
     "nsdg_boxtest_forcing": (C.c_int, [VP, D, D, VP, VP, VP, VP]),
@@ -524,6 +525,12 @@ class Context:
             raise NsdgError("transport scratch too small: need %d doubles" % need)
         self._call(self.lib.nsdg_transport_step(self.h, order, float(dt), len(fields), _ptr_array(fields),
                                                 *[_ptr(t) for t in adv], _ptr(scratch)))
+
+    def transport_step_oop(self, order, dt, fields_in, fields_out, adv):
+        """one SSP-RK step of every field, out of place, all stages in ONE launch (fields_out must not alias fields_in)"""
+        _check_f64(*fields_in, *fields_out, *adv)
+        self._call(self.lib.nsdg_transport_step_oop(self.h, order, float(dt), len(fields_in), _ptr_array(fields_in), _ptr_array(fields_out),
+                                                    *[_ptr(t) for t in adv]))
 
     def dg_to_cg(self, f_dg, f_cg):
         _check_f64(f_dg, f_cg)

@@ -945,3 +945,30 @@ def test_hip_path_matches_the_independent_restatement(ctx, variant):
     assert_close(host(out), W("phi_stage"), 1e-12, 1e-13 * np.max(np.abs(W("phi_stage"))), "DG2 transport stage")
     ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     ctx.set_mevp_params(ctx.mevp_default_params())
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_fused_stages_transport_step_equals_staged_step_bitwise(ctx, order):
+    """nsdg_transport_step_oop performs all Runge-Kutta stages of a step in ONE launch (tiles of 32 x 16 elements, the
+    intermediate stages on a halo in LDS); it must reproduce nsdg_transport_step -- one launch per stage -- bit for bit, for
+    grids that are not multiples of the tile, smaller than a tile, for several fields, over several steps"""
+    for (nx, ny, nf) in ((70, 37, 1), (33, 17, 2), (5, 3, 1), (128, 64, 3), (31, 50, 4)):
+        rng = np.random.default_rng(77 + order)
+        nc = basis.NCOEF[order]
+        ctx.set_grid(nx, ny, 1.0 / nx, 1.3 / ny)
+        u, v = 0.3 * rng.standard_normal((2 * ny + 1, 2 * nx + 1)), 0.3 * rng.standard_normal((2 * ny + 1, 2 * nx + 1))
+        adv = adv_on_device(ctx, nx, ny, order, u, v)
+        fields = [dev(np.concatenate([1.0 + 0.2 * rng.standard_normal((1, ny, nx)), 0.1 * rng.standard_normal((nc - 1, ny, nx))])) for _ in range(nf)]
+        staged = [f.clone() for f in fields]
+        a, b = [f.clone() for f in fields], [torch.full_like(f, 7.0) for f in fields]
+        scratch = torch.zeros(2 * sum(f.numel() for f in fields), dtype=torch.float64, device="cuda")
+        dt = 0.02 / max(nx, ny)
+        for step in range(3):
+            ctx.transport_step(order, dt, staged, adv, scratch)
+            ctx.transport_step_oop(order, dt, a, b, adv)
+            a, b = b, a
+            for k in range(nf):
+                assert torch.equal(a[k], staged[k]), (order, nx, ny, nf, step, k, float((a[k] - staged[k]).abs().max()))
+        assert float((staged[0] - fields[0]).abs().max()) > 0
+    with pytest.raises(abi.NsdgError, match="alias"):
+        ctx.transport_step_oop(order, 1e-3, [a[0]], [a[0]], adv)

@@ -24,7 +24,7 @@ def load(d):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         key = None
-        for k in ("mevp_fused_kernel", "mevp_fused2_kernel", "mevp_fused3_kernel", "transport_stage_kernel<2>", "transport_pair_kernel<2>", "wind_stress_kernel", "ice_strength_kernel",
+        for k in ("mevp_fused_kernel", "mevp_fused2_kernel", "mevp_fused3_kernel", "mevp_fused4_kernel", "transport_stage_kernel<2>", "transport_pair_kernel<2>", "wind_stress_kernel", "ice_strength_kernel",
                   "mevp_pack_nodal_kernel", "mevp_stress_kernel", "mevp_velocity_kernel", "column_step_kernel"):
             if k in name:
                 key = k
@@ -61,7 +61,7 @@ def main():
     L.append("\n=> read bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction), write bytes = WRITE_SIZE x 1024.\n\n"
              "| kernel | launches | read GB | write GB | total GB / launch | algorithmic GB / launch |\n|---|---|---|---|---|---|\n")
     out = {}
-    for k, alg in (("mevp_fused_kernel", 896 * N), ("mevp_fused2_kernel", 2 * 896 * N), ("mevp_fused3_kernel", 3 * 896 * N), ("mevp_stress_kernel", None), ("mevp_velocity_kernel", None),
+    for k, alg in (("mevp_fused_kernel", 896 * N), ("mevp_fused2_kernel", 2 * 896 * N), ("mevp_fused3_kernel", 3 * 896 * N), ("mevp_fused4_kernel", 4 * 896 * N), ("mevp_stress_kernel", None), ("mevp_velocity_kernel", None),
                    ("transport_stage_kernel<2>", 1008 * N / 3), ("transport_pair_kernel<2>", 1008 * N / 3), ("column_step_kernel", 160 * N)):
         if k in fe and k in wr:
             rd, w = 2 * mean(fe[k]["FETCH_SIZE"]) * 1024, mean(wr[k]["WRITE_SIZE"]) * 1024
