@@ -412,7 +412,7 @@ void DynamicsStep::stop(const Iterator::TimePoint&)
             m_sumH += f.hice[e];
             m_sumA += f.cice[e];
         }
-    // A run that has left the physical range (the sub-cycle going unstable) must fail loudly: the
+    // A run that has left the physical range (profiles/r04_soak_divergence_cause.md) must fail loudly: the
     // caller gets an exception (non-zero exit of nextsim_amd) and -- because writeRestartFile() comes through here first -- no
     // restart file full of NaN is written.  (The reference never checks its fields; it also has no dynamics to go unstable.)
     if (!finite || !std::isfinite(m_sumH) || !std::isfinite(m_sumA))
