@@ -166,21 +166,23 @@ __device__ __forceinline__ double fast_sqrt(double x)
 }
 
 // Neighbour-lane exchange of the marching kernels as DPP moves (GFX9 wave_shr:1 / wave_shl:1 shift the
-// whole 64-lane wavefront by one lane): two VALU moves per double instead of two ds_bpermute round
-// trips through the LDS crossbar with their s_waitcnt.  The lane without a neighbour keeps its own
-// value (it is a redundant column whose result is discarded) -- same semantics as __shfl_up/down(x, 1).
+// whole 64-lane wavefront by one lane): one VALU move per dword instead of two ds_bpermute round
+// trips through the LDS crossbar with their s_waitcnt.  The lane without a neighbour reads ZERO (bound_ctrl): it is a
+// redundant column whose result is discarded.  (Rounds 1-3 let that lane keep its own value, `old` = the source: the
+// compiler then needs a copy before every DPP move because the instruction overwrites its destination in place -- 24
+// extra moves per element row of a pipeline stage.)
 __device__ __forceinline__ double lane_from_left(double x)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false); // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true); // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_from_right(double x)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false); // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true); // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

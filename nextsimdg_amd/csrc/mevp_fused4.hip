@@ -116,8 +116,9 @@ __device__ __forceinline__ void request_c4(const MarchConst3& M, int nrow, doubl
 // One march step of one wave.  FIRST: the loader wave (stage 0, inputs from memory; a code path of its own so that its
 // register allocation and the compiler's bookkeeping of outstanding loads are not entangled with the other stages').
 // A busy step is straight-line code.  A stage that has not reached its first row yet, or is past its last, takes the IDLE
-// step: it requests the inputs of its next row and meets the barrier, nothing else (at the power cap idle arithmetic costs
-// the busy waves their clock).  The loader has no idle step: it works on its first / last row again and only suppresses
+// step: it meets the barrier and touches nothing -- in particular not the prefetch set, so that no value of it is merged
+// between the two paths (at the power cap idle arithmetic costs the busy waves their clock; with loads in the idle path the
+// register allocator moved ~100 values per step between the two halves of the register file at the joins).  The loader has no idle step: it works on its first / last row again and only suppresses
 // the outputs -- with its arithmetic behind a branch the compiler copied freshly loaded values between registers at the join
 // and waited for them, a full HBM round trip (profiles/r04_fused4_development.md).
 template <bool FIRST>
@@ -132,12 +133,14 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     const int nrow = min(max(rowraw + 1, G.first), G.last); // the row this stage works on in the NEXT step: its inputs are requested during this one
     const int ix = M.ix, nn = M.nn;
     NSDG_STAMP(0);
-    if (!FIRST && !active) { // ------------------------------------------------------------------- idle step
-        request_P4(M, nrow, f, pg);
-        request_c4(M, nrow, f.c, packed);
+    if (!FIRST && !active) { // ------------------------------------------------------------------- idle step: meet the barrier, touch nothing
         handover_barrier();
         NSDG_STAMP(8);
         return;
+    }
+    if (!FIRST && row == G.first) { // wave-uniform: the first row of the stage has no predecessor that requested its inputs
+        request_P4(M, row, f, pg);
+        request_c4(M, row, f.c, packed);
     }
     const long nVn = (long)(2 * nrow) * nn + 2 * ix; // vertex node of the next row
     double s11[8], s12[8], s22[8], uu[4], vv[4], ul[9], vl[9], un[4], vn[4];
@@ -334,9 +337,9 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nx,
             tile_load8(S.i11, ts, f.s11);
             tile_load8(S.i12, ts, f.s12);
             tile_load8(S.i22, ts, f.s22);
+            tile_load9(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
+            request_c4(M, row, f.c, packed);
         }
-        tile_load9(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
-        request_c4(M, row, f.c, packed);
     }
 #ifdef NSDG_STAMPS
     unsigned stamp_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
