@@ -3,29 +3,29 @@
 // Variant 3 runs its three stages one after the other in ONE wave: 486 registers (a sixth of its vector instructions
 // only move values between the two halves of the register file), 1024 waves to fill the chip and therefore short strips
 // that pay the pipeline fill again and again.  Here a workgroup of four waves -- one per SIMD of a CU -- marches through a
-// strip of 57 owned columns x R rows, and wave s performs sub-iteration p+s on the element row  t - LAG[s]  at march step t,
-// LAG = {0, 2, 5, 8}.  The hand-over between two waves -- 24 stress coefficients and u, v at the 4 owned nodes per lane --
-// goes through LDS: three rotating slots of 16 KB per hand-over, 144 KB per workgroup, 16-byte accesses.  Wave 0 reads
-// stress and velocity from memory, wave 3 writes them; every wave reads the ice strength and the packed nodal
-// coefficients of its row itself (waves 1-3: L2 / Infinity Cache hits).  256 workgroups fill the chip, so strips are four
-// times taller than variant 3's, and a pass streams the stress once per FOUR sub-iterations (776 B per element and pass =
-// 194 B per element and sub-iteration).
+// strip of 57 owned columns x R rows, and wave s performs sub-iteration p+s on the element row  t - 3 s  at march step t.
+// The hand-over between two waves -- 24 stress coefficients and u, v at the 4 owned nodes per lane -- goes through LDS:
+// three rotating slots of 16 KB per hand-over, 144 KB per workgroup, 16-byte accesses.  Wave 0 reads stress and velocity
+// from memory, wave 3 writes them; every wave reads the ice strength and the packed nodal coefficients of its row itself
+// (waves 1-3: L2 / Infinity Cache hits).  256 workgroups fill the chip, so strips are four times taller than variant 3's,
+// and a pass streams the stress once per FOUR sub-iterations (776 B per element and pass = 194 B per element and
+// sub-iteration).
 //
 // Synchronisation: ONE workgroup barrier per march step and wave -- but every wave meets it at a DIFFERENT point of its
-// step.  A step is four quarters (Q0 inputs: LDS reads or the values fetched from memory, node gather; Q1 stress update;
-// Q2 nodal contributions and node updates; Q3 outputs: LDS writes or global stores); wave s calls the barrier after
-// quarter BAR[s] = {3, 0, 1, 2}.  The waves therefore run a quarter of a step apart: while one issues its loads the others
-// compute, instead of all four hitting the vector-memory pipeline and the LDS of the CU at the same time (the aligned
-// first version spent half of every step in those collisions: profiles/r04_fused4_development.md).  Why this is race-free
-// with three slots (barrier #i = the barrier call inside step i of each wave; all LDS reads of a step are in Q0, all LDS
-// writes in Q3, and the barrier waits for the wave's own LDS traffic first):
-//   * visibility: stage s reads in Q0 of step i the rows  rho = i - LAG[s]  and  rho + 1  of stage s-1.  Row rho + 1 was
-//     written in Q3 of step i - LAG[s] + LAG[s-1] + 1 of that wave: for s = 1 that is step i - 1 and Q3 comes before the
-//     producer's barrier #(i-1); for s = 2, 3 it is step i - 2 and Q3 comes after its barrier #(i-2) but before #(i-1).
-//     The consumer's Q0 of step i comes after its barrier #(i-1).
-//   * slot reuse: the producer overwrites the slot of row rho with row rho + 3.  For s = 1 that happens in step i + 1 of
-//     wave 0, after its barrier #i; for s = 2, 3 in step i of waves 1, 2, after their barrier #i (their barrier comes before
-//     Q3).  The consumer's reads of row rho are complete before its barrier #i.
+// step.  A step is four quarters (Q0 velocity inputs: LDS reads or the values fetched from memory, node gather; Q1 projected
+// stress, then the stress of the row -- read from LDS only here, after the register peak -- and its relaxation; Q2 nodal
+// contributions and node updates; Q3 outputs: LDS writes or global stores); wave s calls the barrier after quarter s.  The
+// waves therefore run a quarter of a step apart: while one issues its loads the others compute, instead of all four hitting
+// the vector-memory pipeline and the LDS of the CU at the same time (the aligned first version spent half of every step in
+// those collisions: profiles/r04_fused4_development.md).  Why this is race-free with three slots (barrier #i = the barrier
+// call inside step i of each wave; the LDS reads of a step are in Q0 and Q1, never after the wave's own barrier call --
+// wave s >= 1 reads, its barrier comes after quarter s >= 1 -- all LDS writes are in Q3, and the barrier waits for the wave's
+// own LDS traffic first):
+//   * visibility: stage s reads in step i the rows  rho = i - 3 s  and  rho + 1  of stage s-1.  Row rho + 1 was written in Q3
+//     of step i - 2 of that wave, i.e. after its barrier #(i-2) and before its barrier #(i-1) (its barrier comes before Q3:
+//     s-1 <= 2); the consumer's reads of step i come after its barrier #(i-1).
+//   * slot reuse: the producer overwrites the slot of row rho with row rho + 3 in Q3 of ITS step i, after its barrier #i; the
+//     consumer's reads of row rho (Q0 / Q1 of step i, and as the row above in step i - 1) are complete before its barrier #i.
 // Inputs from memory are requested one row ahead, each group right after the values of the current row have been
 // consumed (the stress after the relaxation, the nodal coefficients after the node updates, ...): ONE register set is
 // always either waiting to be used or in flight, instead of two alternating sets.
@@ -55,8 +55,8 @@ constexpr int F4_SLOTS = 3; // rotating slots per hand-over
 constexpr int F4_HAND = 32; // doubles per lane and slot: 24 stress coefficients + u, v at the 4 owned nodes
 constexpr int F4_SLOT = F4_HAND * 64; // doubles per slot; value k of lane l at (k / 2) * 128 + 2 l + k % 2 (16-byte pairs)
 constexpr int F4_LDS = 3 * F4_SLOTS * F4_SLOT; // three hand-overs
-constexpr int F4_LAG_TOTAL = 8; // stage 3 works on row t - 8
-constexpr int F4_STEPS_EXTRA = 7 + F4_LAG_TOTAL; // a strip of R rows takes R + 15 march steps
+constexpr int F4_LAG_TOTAL = 9; // stage 3 works on row t - 9: every link is three steps deep
+constexpr int F4_STEPS_EXTRA = 7 + F4_LAG_TOTAL; // a strip of R rows takes R + 16 march steps
 
 // what a wave holds from memory for the row it works on next (requested right after the current row's values were used)
 struct Fetch4 {
@@ -68,8 +68,8 @@ struct Fetch4 {
 
 struct Stage4 {
     int s; // pipeline stage of this wave = sub-iteration p + s
-    int lag; // this stage works on row t - lag at march step t
-    int bar; // the quarter after which this wave meets the workgroup barrier
+    int lag; // this stage works on row t - lag at march step t (3 s)
+    int bar; // the quarter after which this wave meets the workgroup barrier (s)
     int first, last; // element rows this stage works on
     int last_prev; // last row of the previous stage (the row above `last` exists unless the strip ends at the physical top)
     int upd0; // node updates from this row on (the first row of a stage only feeds the carried contributions)
@@ -126,7 +126,7 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     const StressPtrs4& S, const double* __restrict__ u_old, const double* __restrict__ v_old, const double* __restrict__ packed,
     const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new NSDG_STAMP_ARGS)
 {
-    const int stage = FIRST ? 0 : G.s, bar = FIRST ? 3 : G.bar;
+    const int stage = FIRST ? 0 : G.s, bar = FIRST ? 0 : G.bar;
     const int rowraw = t - (FIRST ? 0 : G.lag);
     const bool active = rowraw >= G.first && rowraw <= G.last; // wave-uniform
     const int row = min(max(rowraw, G.first), G.last);
@@ -167,14 +167,9 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
             tu = tv = make_double2(0., 0.);
         gather_nodes(M, uu, tu.x, tu.y, ul);
         gather_nodes(M, vv, tv.x, tv.y, vl);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double2 a = lds_pair(in, k), b = lds_pair(in, 4 + k), c = lds_pair(in, 8 + k);
-            s11[2 * k] = a.x, s11[2 * k + 1] = a.y, s12[2 * k] = b.x, s12[2 * k + 1] = b.y, s22[2 * k] = c.x, s22[2 * k + 1] = c.y;
-        }
     }
     NSDG_STAMP(1);
-    if (!FIRST && bar == 0)
+    if (bar == 0)
         handover_barrier();
     NSDG_STAMP(2);
     // ------------------------------------------------------------------------------------------ Q1: stress update
@@ -199,6 +194,14 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             s11[i] = f.s11[i], s12[i] = f.s12[i], s22[i] = f.s22[i];
+    }
+    else {
+        const double* in = lds + ((stage - 1) * F4_SLOTS + row % F4_SLOTS) * F4_SLOT + 2 * M.lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double2 a = lds_pair(in, k), b = lds_pair(in, 4 + k), c = lds_pair(in, 8 + k);
+            s11[2 * k] = a.x, s11[2 * k + 1] = a.y, s12[2 * k] = b.x, s12[2 * k + 1] = b.y, s22[2 * k] = c.x, s22[2 * k + 1] = c.y;
+        }
     }
     stress_relax(M.ialpha, r11, r12, r22, s11, s12, s22);
     __builtin_amdgcn_sched_barrier(0);
@@ -228,7 +231,8 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     NSDG_STAMP(5);
     // nodal coefficients of the next row.  (Requested for the CURRENT row after the register peak of the projected stress
     // instead -- 48 registers fewer across the step in the stages 1-3, whose coefficients come from L2 / the Infinity Cache --
-    // measured 0.5 % slower: 1.000-1.002 against 0.994-0.998 ms per pass, alternating runs on one box.)
+    // measured slower twice, alternating runs on one box: 1.000-1.002 against 0.994-0.998 ms per pass in the first structure,
+    // 1.005-1.008 against 0.962-0.964 in the final one: the L2 / Infinity-Cache latency is then exposed.)
     request_c4(M, nrow, f.c, packed);
     NSDG_STAMP(11);
     if (!FIRST && bar == 2)
@@ -272,7 +276,7 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
         }
     }
     NSDG_STAMP(7);
-    if (FIRST || bar == 3)
+    if (bar == 3)
         handover_barrier();
     NSDG_STAMP(8);
 }
@@ -314,8 +318,8 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nx,
 
     Stage4 G;
     G.s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    G.lag = G.s == 0 ? 0 : 3 * G.s - 1; // 0, 2, 5, 8
-    G.bar = (G.s + 3) & 3; // 3, 0, 1, 2
+    G.lag = 3 * G.s;
+    G.bar = G.s;
     G.first = max(M.y0 - 4 + G.s, 0);
     G.last = min(M.y1 + 2 - G.s, ny - 1);
     G.last_prev = min(M.y1 + 3 - G.s, ny - 1);
@@ -386,7 +390,7 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j
     const int rowsB = j0b < j1b ? j1b - j0b : 0;
     int R = ctx->strip_rows;
     if (R <= 0) {
-        // a strip of R rows takes R + 15 march steps (stage 0 runs on R + 7 rows, stage 3 ends eight steps after it);
+        // a strip of R rows takes R + 16 march steps (stage 0 runs on R + 7 rows, stage 3 ends eight steps after it);
         // one resident workgroup per CU (LDS)
         const long slots = ctx->num_cus;
         double best = 1e30;
