@@ -449,22 +449,39 @@ __device__ __forceinline__ void node_contrib(const double (&s11)[8], const doubl
 // the update of DESIGN.md section 3.2 reads
 //   drag = cd*|v_o - v|;  u' = (K1 h' u + c2 + drag*u_o + K3 h' v + div_x/M) / (K2 h' + drag)
 //                         v' = (K1 h' v + c3 + drag*v_o - K3 h' u + div_y/M) / (K2 h' + drag)
-// Layout: six consecutive doubles per node (node-major), read with three 16-byte loads at a lane stride of 96 bytes.
-// Round 3 measured the alternative the round-2 review asked for -- three PAIR PLANES, pair k = (c[2k], c[2k+1]) of node n
-// at packed[k * 2 NN + 2 n], lane stride 32 bytes, every touched line completely used by the two instructions of a
-// node row (86 against 74 cycles per instruction in profiles/r01_vmem_issue_microbench.txt) -- and found it 0.4 % SLOWER
-// in the three-iteration kernel (0.7716 against 0.7682 ms per pass, three alternating runs on one box,
-// profiles/r03_fused3_levers.md): the node-major form keeps the 48 bytes of a node in ONE 128-byte line (one line per
-// lane and node, three loads that hit it), the planes spread them over three lines in three distant streams.  The plane
-// layout stays available as -DNSDG_NODAL_PLANES (A/B builds); both are bit-identical in their results.
-#ifndef NSDG_NODAL_PLANES
-constexpr int NODAL_STRIDE = 6;
-__host__ __device__ __forceinline__ long nodal_plane(long nnodes) { return 2; } // pair k at + 2 k
-__host__ __device__ __forceinline__ long nodal_node(long n) { return n * NODAL_STRIDE; }
-#else
-__host__ __device__ __forceinline__ long nodal_plane(long nnodes) { return 2 * nnodes; } // doubles between two pair planes
-__host__ __device__ __forceinline__ long nodal_node(long n) { return 2 * n; }
+// Layout (NSDG_NODAL_LAYOUT).  Rounds 1-3: node-major, six consecutive doubles per node, three 16-byte loads at a lane stride of
+// 96 bytes; the pair-plane form -- pair k = (c[2k], c[2k+1]) of node n at packed[k * 2 NN + 2 n], lane stride 32 bytes -- was
+// 0.4 % slower in the single-wave three-iteration kernel (profiles/r03_fused3_levers.md).  Round 4: in the four-wave
+// pipeline all four waves of a CU read these coefficients, 36 instructions per march step that each touch 48 cache lines in the
+// node-major form against 16; pair planes measured 0.9349-0.9385 ms per pass against 0.9450-0.9491 node-major and 0.9393-0.9394 for
+// planes split by node parity (one contiguous kilobyte per access), alternating runs on one box -> pair planes are the default.
+// All three are bit-identical in their results.
+#ifndef NSDG_NODAL_LAYOUT
+#define NSDG_NODAL_LAYOUT 1
 #endif
+// NSDG_NODAL_LAYOUT: 0 node-major; 1 three pair planes (lane stride 32 bytes); 2 three pair planes, each split by the parity of
+// the node index -- the marching kernels read nodes n0 + 2 lane, so the 64 lanes of every access touch ONE contiguous kilobyte.
+// `plane` = doubles between two pair planes (what nodal_plane returns); nodal_off = where pair 0 of node n starts.
+__host__ __device__ __forceinline__ long nodal_plane(long nnodes)
+{
+#if NSDG_NODAL_LAYOUT == 0
+    return 2; // pair k at + 2 k
+#elif NSDG_NODAL_LAYOUT == 1
+    return 2 * nnodes;
+#else
+    return 4 * ((nnodes + 1) / 2); // [even nodes | odd nodes], two doubles each
+#endif
+}
+__host__ __device__ __forceinline__ long nodal_off(long n, long plane)
+{
+#if NSDG_NODAL_LAYOUT == 0
+    return n * 6;
+#elif NSDG_NODAL_LAYOUT == 1
+    return 2 * n;
+#else
+    return (n & 1) * (plane >> 1) + 2 * (n >> 1);
+#endif
+}
 
 struct NodalConsts {
     double k1, k2, k3;
@@ -484,7 +501,7 @@ __device__ __forceinline__ void node_update_packed(const NodalConsts& K, const d
 // plane = nodal_plane(number of nodes of the local array)
 __device__ __forceinline__ void load_nodal(const double* __restrict__ packed, long plane, long n, double (&c)[6])
 {
-    const double* p = packed + nodal_node(n);
+    const double* p = packed + nodal_off(n, plane);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const double2 t = *reinterpret_cast<const double2*>(p + k * plane);
@@ -495,7 +512,7 @@ __device__ __forceinline__ void load_nodal(const double* __restrict__ packed, lo
 
 __device__ __forceinline__ void store_nodal(double* __restrict__ packed, long plane, long n, const double (&c)[6])
 {
-    double* p = packed + nodal_node(n);
+    double* p = packed + nodal_off(n, plane);
 #pragma unroll
     for (int k = 0; k < 3; ++k)
         *reinterpret_cast<double2*>(p + k * plane) = make_double2(c[2 * k], c[2 * k + 1]);

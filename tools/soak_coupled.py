@@ -68,7 +68,7 @@ def dump(step):
     y0, y1, x0, x1 = max(iy - 2, 0), min(iy + 3, ny), max(ix - 2, 0), min(ix + 3, nx)
     Hw, Aw = core.H[:, y0:y1, x0:x1], core.A[:, y0:y1, x0:x1]
     Hg, Ag = torch.einsum("qc,cyx->qyx", GP, Hw), torch.einsum("qc,cyx->qyx", GP, Aw)
-    hnode = core.packed[:6 * (2 * ny + 1) * (2 * nx + 1)].view(2 * ny + 1, 2 * nx + 1, 6)[:, :, 0]  # h' = max(cgH, h_min) of the last packing
+    hnode = core.packed[:2 * (2 * ny + 1) * (2 * nx + 1)].view(2 * ny + 1, 2 * nx + 1, 2)[:, :, 0]  # h' = max(cgH, h_min) of the last packing: first entry of pair plane 0 (csrc/mevp_common.h, NSDG_NODAL_LAYOUT 1)
     pgw = abi.untile(core.pg, nx)[:, y0:y1, x0:x1]
     # strain rate at the element centres of the window from the nodal velocities (central differences over the element)
     U, V = core.u[2 * y0:2 * y1 + 1, 2 * x0:2 * x1 + 1], core.v[2 * y0:2 * y1 + 1, 2 * x0:2 * x1 + 1]
