@@ -74,6 +74,18 @@ def test_row_ranges_aliasing_and_sequence(ctx):
         ctx.mevp_iterate3(2, ny, s, so, (u, v), (un, vn), packed, pg)
     with pytest.raises(abi.NsdgError, match="two ghost rows above"):
         ctx.mevp_iterate3(0, ny - 1, s, so, (u, v), (un, vn), packed, pg)
+    with pytest.raises(abi.NsdgError, match="variant 4"):
+        ctx.mevp_iterate4(0, ny, s, so, (u, v), (un, vn), packed, pg)
+    ctx.set_mevp_variant(4)
+    with pytest.raises(abi.NsdgError, match="four ghost rows"):
+        ctx.mevp_iterate4(3, ny, s, so, (u, v), (un, vn), packed, pg)
+    with pytest.raises(abi.NsdgError, match="three ghost rows above"):
+        ctx.mevp_iterate4(0, ny - 2, s, so, (u, v), (un, vn), packed, pg)
+    with pytest.raises(abi.NsdgError, match="disjoint"):
+        ctx.mevp_iterate4_pair((0, ny), (4, ny), s, so, (u, v), (un, vn), packed, pg)
+    with pytest.raises(abi.NsdgError, match="must not alias"):
+        ctx.mevp_iterate4(0, ny, s, s, (u, v), (un, vn), packed, pg)
+    ctx.mevp_iterate3(0, ny, s, so, (u, v), (un, vn), packed, pg)  # a variant-4 context still serves the three-iteration pass (remainders)
     ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     with pytest.raises(abi.NsdgError, match="order must be"):
         ctx.prepare_advection(3, u, v, z(6, ny, nx), z(6, ny, nx), z(3, ny, nx + 1), z(3, ny + 1, nx))
