@@ -190,13 +190,21 @@ int nsdg_transport_stage(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, d
 int nsdg_transport_step(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields, double* const* phi,
     const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y, double* scratch);
 
-/* The same step OUT OF PLACE in ONE launch: all Runge-Kutta stages of a step fused, every workgroup performing the step on a
- * tile of 32 x 16 elements with the intermediate stages on a halo of (stages - 1) elements in LDS (redundancy instead of
- * synchronisation).  For meshes whose step is bound by launch latency (BASELINE config 2: 512 x 512 DG1) and for callers
- * that ping-pong their fields; the field is read once and written once per step.  phi_out must not alias phi_in.
- * Bit-identical to nsdg_transport_step. */
+/* The same step OUT OF PLACE in ONE launch: all Runge-Kutta stages of a step fused as a march -- a wave owns a window of
+ * 64 - 2 (order + 1) element columns and a strip of rows and walks up the rows, stage k running k rows behind the newest row
+ * read, the neighbours' edge traces taken from the adjacent lanes and from the rows the lane holds: every value is read once per
+ * step, nothing goes through LDS, and the columns / rows at the edges of a window / strip are recomputed instead of exchanged.
+ * For meshes whose step is bound by launch latency (BASELINE config 2: 512 x 512 DG1) and for callers that ping-pong their
+ * fields.  phi_out must not alias phi_in.  Bit-identical to nsdg_transport_step. */
 int nsdg_transport_step_oop(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields, const double* const* phi_in,
     double* const* phi_out, const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y);
+
+/* The fused step on the rows [j0, j1) of the local array only (a row block's own rows): phi_in must be valid on order + 2 rows
+ * below j0 and above j1 where the array has them (the ghost rows of a block whose ghost zone is at least that deep; the array
+ * boundary needs none: nothing flows in).  Rows outside [j0, j1) of phi_out are not written. */
+int nsdg_transport_step_oop_rows(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, double dt, int32_t nfields,
+    const double* const* phi_in, double* const* phi_out, const double* vx_dg, const double* vy_dg, const double* un_x,
+    const double* un_y);
 
 /* nodal average of a DG field on the CG2 lattice (mean thickness / concentration at the nodes) */
 int nsdg_dg_to_cg(nsdg_ctx* ctx, int32_t ncoef, const double* f_dg, double* f_cg);

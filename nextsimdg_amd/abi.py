@@ -90,6 +90,7 @@ SYMBOLS = {
     "nsdg_transport_stage": (C.c_int, [VP, I32, I32, I32, D, D, D, I32, C.POINTER(VP), C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
     "nsdg_transport_step": (C.c_int, [VP, I32, D, I32, C.POINTER(VP)] + [VP] * 5),
     "nsdg_transport_step_oop": (C.c_int, [VP, I32, D, I32, C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
+    "nsdg_transport_step_oop_rows": (C.c_int, [VP, I32, I32, I32, D, I32, C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
     "nsdg_dg_to_cg": (C.c_int, [VP, I32, VP, VP]),
     "nsdg_ice_strength": (C.c_int, [VP, I32, I32, VP, VP, VP]),
     "nsdg_boxtest_forcing": (C.c_int, [VP, D, D, VP, VP, VP, VP]),
@@ -531,6 +532,12 @@ class Context:
         _check_f64(*fields_in, *fields_out, *adv)
         self._call(self.lib.nsdg_transport_step_oop(self.h, order, float(dt), len(fields_in), _ptr_array(fields_in), _ptr_array(fields_out),
                                                     *[_ptr(t) for t in adv]))
+
+    def transport_step_oop_rows(self, order, j0, j1, dt, fields_in, fields_out, adv):
+        """the fused step on the rows [j0, j1) only (a row block's own rows; fields_in valid order + 2 rows around them)"""
+        _check_f64(*fields_in, *fields_out, *adv)
+        self._call(self.lib.nsdg_transport_step_oop_rows(self.h, order, j0, j1, float(dt), len(fields_in), _ptr_array(fields_in),
+                                                         _ptr_array(fields_out), *[_ptr(t) for t in adv]))
 
     def dg_to_cg(self, f_dg, f_cg):
         _check_f64(f_dg, f_cg)

@@ -577,25 +577,27 @@ int nsdg_rb_transport_run(nsdg_ctx* ctx, nsdg_rb_transport* p, double dt, int32_
         const int rc = nsdg_halo_start(ctx, plan);
         return rc != NSDG_OK ? rc : nsdg_halo_finish(ctx, plan);
     };
-    auto ext = [&](int e, int& a, int& b) {
-        a = p->deep ? std::max(g.j0 - e, 0) : g.j0;
-        b = p->deep ? std::min(g.j1 + e, g.ny) : g.j1;
-    };
-    // Shu-Osher SSP-RK3: out = a*phi0 + b*(phis + dt L(phis)); a stage reads one element row on each side of its rows
-    int a, b, rc;
-    ext(2, a, b);
-    if ((rc = nsdg_transport_stage(ctx, d.order, a, b, dt, 0.0, 1.0, d.nfields, cur, cur, nxt, d.vx_dg, d.vy_dg, d.un_x, d.un_y)) != NSDG_OK)
-        return rc;
-    if (!p->deep && (rc = exchange(p->new_plan[parity])) != NSDG_OK)
-        return rc;
-    ext(1, a, b);
-    if ((rc = nsdg_transport_stage(ctx, d.order, a, b, dt, 0.75, 0.25, d.nfields, cur, nxt, d.t2, d.vx_dg, d.vy_dg, d.un_x, d.un_y)) != NSDG_OK)
-        return rc;
-    if (!p->deep && (rc = exchange(p->t2_plan)) != NSDG_OK)
-        return rc;
-    if ((rc = nsdg_transport_stage(ctx, d.order, g.j0, g.j1, dt, 1.0 / 3.0, 2.0 / 3.0, d.nfields, cur, d.t2, nxt, d.vx_dg, d.vy_dg, d.un_x, d.un_y))
-        != NSDG_OK)
-        return rc;
+    int rc;
+    if (!g.multi() || p->deep) {
+        // ghost zones at least three rows deep (or no neighbour): the three stages as ONE launch on the block's own rows -- the
+        // march recomputes the stage values of the rows around them from the ghost rows of the state (bit-identical to the
+        // stage launches below) -- and one exchange
+        if ((rc = nsdg_transport_step_oop_rows(ctx, d.order, g.j0, g.j1, dt, d.nfields, cur, nxt, d.vx_dg, d.vy_dg, d.un_x, d.un_y)) != NSDG_OK)
+            return rc;
+    } else {
+        // Shu-Osher SSP-RK3: out = a*phi0 + b*(phis + dt L(phis)); a stage reads one element row on each side of its rows
+        if ((rc = nsdg_transport_stage(ctx, d.order, g.j0, g.j1, dt, 0.0, 1.0, d.nfields, cur, cur, nxt, d.vx_dg, d.vy_dg, d.un_x, d.un_y)) != NSDG_OK)
+            return rc;
+        if ((rc = exchange(p->new_plan[parity])) != NSDG_OK)
+            return rc;
+        if ((rc = nsdg_transport_stage(ctx, d.order, g.j0, g.j1, dt, 0.75, 0.25, d.nfields, cur, nxt, d.t2, d.vx_dg, d.vy_dg, d.un_x, d.un_y)) != NSDG_OK)
+            return rc;
+        if ((rc = exchange(p->t2_plan)) != NSDG_OK)
+            return rc;
+        if ((rc = nsdg_transport_stage(ctx, d.order, g.j0, g.j1, dt, 1.0 / 3.0, 2.0 / 3.0, d.nfields, cur, d.t2, nxt, d.vx_dg, d.vy_dg, d.un_x, d.un_y))
+            != NSDG_OK)
+            return rc;
+    }
     if ((rc = exchange(p->new_plan[parity])) != NSDG_OK)
         return rc;
     *parity_out = 1 - parity;

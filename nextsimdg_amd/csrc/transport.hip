@@ -360,180 +360,284 @@ __global__ __launch_bounds__(256, 2) void transport_pair_kernel(int nx, int ny, 
     }
 }
 
+// wave-uniform plane base + 32-bit byte offset of the lane: one address register per element instead of a 64-bit pair per load
+__device__ __forceinline__ double plane_load(const double* __restrict__ plane, unsigned byte_off)
+{
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(plane) + byte_off);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// ALL Runge-Kutta stages of a step in ONE launch (round 4; nsdg_transport_step_oop).  A 512 x 512 DG1 step is two stage
-// launches of ~11 us each whose arithmetic takes a few microseconds: the step is bound by launch latency, not by
-// memory (BASELINE config 2).  Here a workgroup owns a tile of TX x TY elements and performs the step on it without any
-// other workgroup: stage 1 is evaluated on the tile extended by `halo` = stages - 1 elements on every side (read from
-// memory), kept in LDS, stage 2 on the tile extended by halo - 1 from those values, ... and the last stage on the tile
-// itself (redundancy instead of synchronisation, as in the mEVP sub-cycle: 1.10 x the arithmetic for DG1 / RK2, 1.20 x
-// for DG2 / RK3 with 32 x 16 tiles).  The field is read once and written once per step instead of once per stage.
-// Out of place -- other workgroups read the halo of the input while this one writes its tile -- so callers ping-pong.
-// Every element evaluation is the same inlined transport_rhs with the same operands as in the stage kernels: the
-// result is bit-identical to the staged step.
+// ALL Runge-Kutta stages of a step in ONE launch, as a MARCH (round 4; nsdg_transport_step_oop[_rows]).  A 512 x 512 DG1 step
+// was two stage launches of ~11 us each (BASELINE config 2), a 2048 x 2048 DG2 step three of ~0.24 ms.  Two tile forms were
+// tried first -- 32 x 16 tiles with the intermediate stages on a halo in LDS, reading memory directly (14.5 us / 0.63 ms) or
+// through LDS-staged inputs (16.1 us / 0.95 ms) -- and lost to this one (11.5 us / 0.32 ms): profiles/r04_transport_fused_forms.md.
+// A wave owns a window of 64 - 2 S columns (S = the number of stages) and a
+// strip of R rows and walks up the rows.  A lane is an element column; the left / right neighbours' edge traces come from the
+// adjacent lanes (DPP), the bottom / top neighbours are the rows the lane itself holds, and stage k runs k rows behind the
+// newest row of the field, on the stage k-1 values of the three rows below it -- all in registers: no LDS, no barrier, every
+// value loaded once per step (NC field values, 2 NC + 2 NG velocities per element and march step instead of 5 NC + 2 NC + 4 NG
+// per element and STAGE).  S lanes on either side and S rows below / above a strip are recomputed instead of exchanged, as in
+// the mEVP sub-cycle.  Rows and columns outside the array are read at clamped addresses and ignored through the has* flags of
+// their neighbours: the march has no divergent branch.  Same inlined transport_rhs / rk_update on the same operands, with the
+// neighbour's trace formed on the neighbour's lane by the same sum: bit-identical to the staged step.
+__device__ __forceinline__ double dpp_from_left(double x) // the value of lane - 1 (0 in lane 0)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true); // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_right(double x) // the value of lane + 1 (0 in lane 63)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true); // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 template <int ORDER>
-struct Fused {
-    // (30 x 6 tiles for DG1, whose first-stage region is exactly one element per thread, measured slower: 15.4 against 14.6 us
-    // per 512 x 512 step)
-    static constexpr int TX = 32, TY = 16, STAGES = ORDER + 1, HALO = ORDER;
-    static constexpr int NC = DG<ORDER>::NC;
-    static constexpr int W0 = TX + 2 * HALO, H0 = TY + 2 * HALO; // region of stage 1
-    static constexpr int W1 = TX + 2, H1 = TY + 2; // region of stage 2 of three
-    static constexpr int LDS_DOUBLES = NC * (W0 * H0 + (STAGES == 3 ? W1 * H1 : 0));
+struct March {
+    static constexpr int S = ORDER + 1, NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
+    static constexpr int OWN = 64 - 2 * S; // columns a wave owns
+    static constexpr int NR0 = S + 1 > 3 ? S + 1 : 3; // rows of the field held: r - NR0 + 1 .. r
 };
 
-// coefficients of element (ix, iy) for the flux across one of its edges: from memory (stage 1) or from a stage buffer in LDS
-struct SrcGlobal {
-    const double* __restrict__ f;
-    long N;
-    int nx;
-    __device__ __forceinline__ double operator()(int k, int ix, int iy) const { return f[k * N + (long)iy * nx + ix]; }
-};
-struct SrcTile {
-    const double* buf; // [NC][H][W]
-    int x0, y0, W, H; // element (x0, y0) is the first of the region
-    __device__ __forceinline__ double operator()(int k, int ix, int iy) const { return buf[(k * H + (iy - y0)) * W + (ix - x0)]; }
+// velocities that belong to one element row: the element's DG velocity, its left edge, its bottom edge
+template <int ORDER>
+struct RowVel {
+    double vx[DG<ORDER>::NC], vy[DG<ORDER>::NC], el[DG<ORDER>::NG], eb[DG<ORDER>::NG];
 };
 
-template <int ORDER, class Src>
-__device__ __forceinline__ void fused_element(int nx, int ny, int ix, int iy, const Src& src, double ihx, double ihy, const double* __restrict__ vx_dg,
-    const double* __restrict__ vy_dg, const double* __restrict__ un_x, const double* __restrict__ un_y, double (&c)[DG<ORDER>::NC],
+// L(c) of the row `c` between `below` and `above`; eb_above = the bottom edge of the row above = this row's top edge
+template <int ORDER>
+__device__ __forceinline__ void march_rhs(const double (&below)[DG<ORDER>::NC], const double (&c)[DG<ORDER>::NC], const double (&above)[DG<ORDER>::NC],
+    const RowVel<ORDER>& V, const double (&eb_above)[DG<ORDER>::NG], bool hasL, bool hasR, bool hasB, bool hasT, double ihx, double ihy,
     double (&rhs)[DG<ORDER>::NC])
 {
     constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
-    const long N = (long)nx * ny, e = (long)iy * nx + ix;
-    const bool hasL = ix > 0, hasR = ix + 1 < nx, hasB = iy > 0, hasT = iy + 1 < ny;
-    double vx[NC], vy[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        vx[k] = ORDER > 0 ? vx_dg[k * N + e] * ihx : 0.;
-        vy[k] = ORDER > 0 ? vy_dg[k * N + e] * ihy : 0.;
-    }
-    const long NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
-    const long exl = (long)iy * (nx + 1) + ix, eyb = (long)iy * nx + ix;
+    NbTrace<NG> nb;
     EdgeVel<NG> E;
+    double mine_r[NG], mine_l[NG], w[NC];
+    trace_of_left<ORDER>(c, mine_r); // my right trace: what my right neighbour calls "the left neighbour's trace"
+    trace_of_right<ORDER>(c, mine_l);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        E.l[g] = un_x[g * NEX + exl], E.r[g] = un_x[g * NEX + exl + 1];
-        E.b[g] = un_y[g * NEY + eyb], E.t[g] = un_y[g * NEY + eyb + nx];
+        const double fl = dpp_from_left(mine_r[g]), fr = dpp_from_right(mine_l[g]);
+        nb.l[g] = hasL ? fl : 0., nb.r[g] = hasR ? fr : 0.;
+        E.l[g] = V.el[g], E.r[g] = dpp_from_right(V.el[g]), E.b[g] = V.eb[g], E.t[g] = eb_above[g];
     }
-    NbTrace<NG> nb;
-    double w[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k)
-        w[k] = hasL ? src(k, ix - 1, iy) : 0.;
-    trace_of_left<ORDER>(w, nb.l);
-#pragma unroll
-    for (int k = 0; k < NC; ++k)
-        w[k] = hasR ? src(k, ix + 1, iy) : 0.;
-    trace_of_right<ORDER>(w, nb.r);
-#pragma unroll
-    for (int k = 0; k < NC; ++k)
-        w[k] = hasB ? src(k, ix, iy - 1) : 0.;
+        w[k] = hasB ? below[k] : 0.;
     trace_of_bottom<ORDER>(w, nb.b);
 #pragma unroll
     for (int k = 0; k < NC; ++k)
-        w[k] = hasT ? src(k, ix, iy + 1) : 0.;
+        w[k] = hasT ? above[k] : 0.;
     trace_of_top<ORDER>(w, nb.t);
-#pragma unroll
-    for (int k = 0; k < NC; ++k)
-        c[k] = src(k, ix, iy);
-    transport_rhs<ORDER>(c, nb, vx, vy, E, ihx, ihy, rhs);
+    transport_rhs<ORDER>(c, nb, V.vx, V.vy, E, ihx, ihy, rhs);
 }
 
+#ifndef NSDG_MARCH_AHEAD
+#define NSDG_MARCH_AHEAD 2 // march steps between the request of a row and its use
+#endif
 template <int ORDER>
-__global__ __launch_bounds__(256) void transport_fused_kernel(int nx, int ny, int nfields, double ihx, double ihy, double dt, FieldPtrs fp,
+__global__ __launch_bounds__(64) void transport_march_kernel(int nx, int ny, int j0, int j1, int R, int ncw, int nfields, double ihx, double ihy, double dt, FieldPtrs fp,
     const double* __restrict__ vx_dg, const double* __restrict__ vy_dg, const double* __restrict__ un_x, const double* __restrict__ un_y)
 {
-    using F = Fused<ORDER>;
-    constexpr int NC = F::NC;
-    extern __shared__ double sh[];
-    double* buf0 = sh; // stage 1 on the tile + HALO
-    double* buf1 = sh + NC * F::W0 * F::H0; // RK3: stage 2 on the tile + 1
-    const int tx0 = blockIdx.x * F::TX, ty0 = blockIdx.y * F::TY;
-    const long N = (long)nx * ny;
+    using M = March<ORDER>;
+    constexpr int S = M::S, NC = M::NC, NG = M::NG, NR0 = M::NR0;
+    const int lane = threadIdx.x;
+    const int strip = blockIdx.x / ncw, cw = blockIdx.x - strip * ncw;
+    const int y0 = j0 + strip * R, y1 = min(y0 + R, j1); // the rows [j0, j1) of the array are advanced (a row block: its own rows)
+    const int x = cw * M::OWN - S + lane;
+    const bool hasL = x > 0, hasR = x + 1 < nx;
+    const bool own = lane >= S && lane < 64 - S && x < nx;
+    const long N = (long)nx * ny, NEX = (long)(nx + 1) * ny, NEY = (long)nx * (ny + 1);
+    const int xc = min(max(x, 0), nx - 1), xe = min(max(x, 0), nx);
+    // byte offsets of this lane in row `row` of an element plane / of the x-edge plane / of the y-edge plane (clamped rows)
+    auto off_el = [&](int row) { return 8u * (unsigned)(min(max(row, 0), ny - 1) * nx + xc); };
+    auto off_ex = [&](int row) { return 8u * (unsigned)(min(max(row, 0), ny - 1) * (nx + 1) + xe); };
+    auto off_ey = [&](int row) { return 8u * (unsigned)(min(max(row, 0), ny) * nx + xc); };
     for (int f = 0; f < nfields; ++f) {
         const double* __restrict__ phi = fp.phis[f]; // the field at the start of the step (phis == phi0)
         double* __restrict__ out = fp.out[f];
-        const SrcGlobal g = { phi, N, nx };
-        // ---- stage 1: t1 = phi + dt L(phi) on the tile + HALO (elements outside the array are skipped: nothing flows in)
-        for (int r = threadIdx.x; r < F::W0 * F::H0; r += 256) {
-            const int rx = r % F::W0, ry = r / F::W0, ix = tx0 - F::HALO + rx, iy = ty0 - F::HALO + ry;
-            if (ix < 0 || ix >= nx || iy < 0 || iy >= ny)
-                continue;
-            double c[NC], rhs[NC];
-            fused_element<ORDER>(nx, ny, ix, iy, g, ihx, ihy, vx_dg, vy_dg, un_x, un_y, c, rhs);
+        double PH[NR0][NC]; // the field in the rows r - NR0 + 1 .. r
+        double T1[3][NC], T2[3][NC]; // stage 1 in the rows r - 3 .. r - 1, stage 2 (RK3) in the rows r - 4 .. r - 2
+        RowVel<ORDER> VR[S]; // VR[k - 1]: the velocities of the row stage k works on, r - k
+        double ebn[NG]; // bottom edge of the row r
 #pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const double t1 = rk_update(0., 1., dt, IMASS[i], 0., c[i], rhs[i]);
-                if (F::STAGES == 1)
-                    out[i * N + (long)iy * nx + ix] = t1;
-                else
-                    buf0[(i * F::H0 + ry) * F::W0 + rx] = t1;
-            }
+        for (int k = 0; k < NC; ++k) {
+#pragma unroll
+            for (int i = 0; i < NR0; ++i)
+                PH[i][k] = 0.;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                T1[i][k] = T2[i][k] = 0.;
         }
-        if (F::STAGES == 1)
-            continue;
-        __syncthreads();
-        const SrcTile s0 = { buf0, tx0 - F::HALO, ty0 - F::HALO, F::W0, F::H0 };
-        if (F::STAGES == 2) {
-            // ---- Heun: out = phi / 2 + (t1 + dt L(t1)) / 2 on the tile
-            for (int r = threadIdx.x; r < F::TX * F::TY; r += 256) {
-                const int ix = tx0 + r % F::TX, iy = ty0 + r / F::TX;
-                if (ix >= nx || iy >= ny)
-                    continue;
-                double c[NC], rhs[NC];
-                fused_element<ORDER>(nx, ny, ix, iy, s0, ihx, ihy, vx_dg, vy_dg, un_x, un_y, c, rhs);
 #pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const long e = i * N + (long)iy * nx + ix;
-                    out[e] = rk_update(0.5, 0.5, dt, IMASS[i], phi[e], c[i], rhs[i]);
+        for (int j = 0; j < S; ++j) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                VR[j].vx[k] = VR[j].vy[k] = 0.;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                VR[j].el[g] = VR[j].eb[g] = 0.;
+        }
+        // requested ahead of the step that consumes them: the field in the row r + 1, the velocities of the row r, the bottom edge
+        // of the row r + 1 (what the step r + 1 consumes)
+        struct Ahead {
+            double pn[NC], ebnn[NG];
+            RowVel<ORDER> vn; // el, vx, vy as loaded (vx, vy are scaled when they are consumed, not behind the load)
+        };
+        const int r0 = y0 - S, r1 = y1 - 1 + S;
+        auto request = [&](int r, Ahead& Q) {
+            const unsigned a = off_el(r + 1), b = off_el(r), c = off_ex(r), d = off_ey(r + 1);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                Q.pn[k] = plane_load(phi + k * N, a);
+                Q.vn.vx[k] = ORDER > 0 ? plane_load(vx_dg + k * N, b) : 0.;
+                Q.vn.vy[k] = ORDER > 0 ? plane_load(vy_dg + k * N, b) : 0.;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                Q.vn.el[g] = plane_load(un_x + g * NEX, c);
+                Q.ebnn[g] = plane_load(un_y + g * NEY, d);
+            }
+        };
+        // the first row any stage works on is r0 + 1 (stage 1, at the step r0 + 2): the rows r0, r0 + 1 and what that step consumes
+        // are requested together -- one trip to memory instead of three before the first arithmetic
+        {
+            const unsigned a0 = off_el(r0), a1 = off_el(r0 + 1), d = off_ey(r0 + 1);
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                PH[NR0 - 2][k] = plane_load(phi + k * N, a0), PH[NR0 - 1][k] = plane_load(phi + k * N, a1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                ebn[g] = plane_load(un_y + g * NEY, d);
+        }
+        auto step = [&](int r, Ahead& Q) {
+            // ---- the rows move down by one; the requested values arrive
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+#pragma unroll
+                for (int i = 0; i + 1 < NR0; ++i)
+                    PH[i][k] = PH[i + 1][k];
+                PH[NR0 - 1][k] = Q.pn[k];
+                T1[0][k] = T1[1][k], T1[1][k] = T1[2][k];
+                T2[0][k] = T2[1][k], T2[1][k] = T2[2][k];
+            }
+#pragma unroll
+            for (int j = S - 1; j >= 1; --j)
+                VR[j] = VR[j - 1];
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                VR[0].vx[k] = Q.vn.vx[k] * ihx, VR[0].vy[k] = Q.vn.vy[k] * ihy; // row r - 1
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                VR[0].el[g] = Q.vn.el[g], VR[0].eb[g] = ebn[g], ebn[g] = Q.ebnn[g]; // ebn was the bottom edge of the row r - 1, becomes that of the row r
+            request(r + NSDG_MARCH_AHEAD - 1, Q); // consumed NSDG_MARCH_AHEAD steps from now (past the last step: clamped, unused)
+            // ---- stage 1 on the row r - 1: t1 = phi + dt L(phi)
+            {
+                const int a = r - 1;
+                if (a >= max(y0 - (S - 1), 0) && a <= min(y1 - 1 + (S - 1), ny - 1)) { // wave-uniform
+                    double rhs[NC];
+                    march_rhs<ORDER>(PH[NR0 - 3], PH[NR0 - 2], PH[NR0 - 1], VR[0], ebn, hasL, hasR, a > 0, a + 1 < ny, ihx, ihy, rhs);
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        const double t1 = rk_update(0., 1., dt, IMASS[i], 0., PH[NR0 - 2][i], rhs[i]);
+                        if (S == 1) {
+                            if (own)
+                                out[i * N + (long)a * nx + x] = t1;
+                        } else
+                            T1[2][i] = t1;
+                    }
                 }
             }
-        } else {
-            // ---- Shu-Osher RK3: t2 = 3/4 phi + (t1 + dt L(t1)) / 4 on the tile + 1, out = phi / 3 + 2 (t2 + dt L(t2)) / 3 on the tile
-            for (int r = threadIdx.x; r < F::W1 * F::H1; r += 256) {
-                const int rx = r % F::W1, ry = r / F::W1, ix = tx0 - 1 + rx, iy = ty0 - 1 + ry;
-                if (ix < 0 || ix >= nx || iy < 0 || iy >= ny)
-                    continue;
-                double c[NC], rhs[NC];
-                fused_element<ORDER>(nx, ny, ix, iy, s0, ihx, ihy, vx_dg, vy_dg, un_x, un_y, c, rhs);
+            if (S == 2) {
+                // ---- Heun on the row r - 2: out = phi / 2 + (t1 + dt L(t1)) / 2
+                const int a = r - 2;
+                if (a >= y0 && a <= y1 - 1) {
+                    double rhs[NC];
+                    march_rhs<ORDER>(T1[0], T1[1], T1[2], VR[S - 1], VR[S - 2].eb, hasL, hasR, a > 0, a + 1 < ny, ihx, ihy, rhs);
+                    if (own) {
 #pragma unroll
-                for (int i = 0; i < NC; ++i)
-                    buf1[(i * F::H1 + ry) * F::W1 + rx] = rk_update(0.75, 0.25, dt, IMASS[i], phi[i * N + (long)iy * nx + ix], c[i], rhs[i]);
-            }
-            __syncthreads();
-            const SrcTile s1 = { buf1, tx0 - 1, ty0 - 1, F::W1, F::H1 };
-            for (int r = threadIdx.x; r < F::TX * F::TY; r += 256) {
-                const int ix = tx0 + r % F::TX, iy = ty0 + r / F::TX;
-                if (ix >= nx || iy >= ny)
-                    continue;
-                double c[NC], rhs[NC];
-                fused_element<ORDER>(nx, ny, ix, iy, s1, ihx, ihy, vx_dg, vy_dg, un_x, un_y, c, rhs);
-#pragma unroll
-                for (int i = 0; i < NC; ++i) {
-                    const long e = i * N + (long)iy * nx + ix;
-                    out[e] = rk_update(1. / 3., 2. / 3., dt, IMASS[i], phi[e], c[i], rhs[i]);
+                        for (int i = 0; i < NC; ++i)
+                            out[i * N + (long)a * nx + x] = rk_update(0.5, 0.5, dt, IMASS[i], PH[NR0 - 3][i], T1[1][i], rhs[i]);
+                    }
                 }
             }
+            if (S == 3) {
+                // ---- Shu-Osher RK3: t2 = 3/4 phi + (t1 + dt L(t1)) / 4 on the row r - 2, out = phi / 3 + 2 (t2 + dt L(t2)) / 3 on the row r - 3
+                {
+                    const int a = r - 2;
+                    if (a >= max(y0 - 1, 0) && a <= min(y1, ny - 1)) {
+                        double rhs[NC];
+                        march_rhs<ORDER>(T1[0], T1[1], T1[2], VR[1], VR[0].eb, hasL, hasR, a > 0, a + 1 < ny, ihx, ihy, rhs);
+#pragma unroll
+                        for (int i = 0; i < NC; ++i)
+                            T2[2][i] = rk_update(0.75, 0.25, dt, IMASS[i], PH[NR0 - 3][i], T1[1][i], rhs[i]);
+                    }
+                }
+                {
+                    const int a = r - 3;
+                    if (a >= y0 && a <= y1 - 1) {
+                        double rhs[NC];
+                        march_rhs<ORDER>(T2[0], T2[1], T2[2], VR[S - 1], VR[S - 2].eb, hasL, hasR, a > 0, a + 1 < ny, ihx, ihy, rhs);
+                        if (own) {
+#pragma unroll
+                            for (int i = 0; i < NC; ++i)
+                                out[i * N + (long)a * nx + x] = rk_update(1. / 3., 2. / 3., dt, IMASS[i], PH[0][i], T2[1][i], rhs[i]);
+                        }
+                    }
+                }
+            }
+        };
+#if NSDG_MARCH_AHEAD == 1
+        Ahead Q;
+        request(r0 + 1, Q);
+        for (int r = r0 + 2; r <= r1; ++r)
+            step(r, Q);
+#else
+        Ahead Q0, Q1; // two steps ahead: at one wave per SIMD a march step is shorter than a trip to memory
+        request(r0 + 1, Q0);
+        request(r0 + 2, Q1);
+        int r = r0 + 2;
+        for (; r + 1 <= r1; r += 2) {
+            step(r, Q0);
+            step(r + 1, Q1);
         }
-        __syncthreads(); // the stage buffers are reused by the next field
+        if (r <= r1)
+            step(r, Q0);
+#endif
     }
 }
 
+#ifndef NSDG_MARCH_ROWS
+#define NSDG_MARCH_ROWS 0 // rows per strip of the march; 0: from the grid (A/B builds)
+#endif
+#ifndef NSDG_MARCH_WAVES
+#define NSDG_MARCH_WAVES 4 // waves per CU the strips are cut for
+#endif
 template <int ORDER>
-int launch_fused(nsdg_ctx* ctx, double dt, int nfields, const FieldPtrs& fp, const double* vx, const double* vy, const double* unx, const double* uny)
+int launch_march(nsdg_ctx* ctx, int j0, int j1, double dt, int nfields, const FieldPtrs& fp, const double* vx, const double* vy, const double* unx,
+    const double* uny)
 {
-    using F = Fused<ORDER>;
-    const dim3 grid(nsdg_div_up(ctx->nx, F::TX), nsdg_div_up(ctx->ny, F::TY));
-    const size_t lds = (size_t)F::LDS_DOUBLES * sizeof(double);
-    static bool attr_set = false; // DG2: 64 KB of stage buffers, above the default dynamic limit
-    if (!attr_set && lds > 48 * 1024) {
-        NSDG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&transport_fused_kernel<ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    NSDG_CHECK_ARG(8L * (ctx->nx + 1L) * (ctx->ny + 1L) < (1L << 32), "grid too large for 32-bit byte offsets within a coefficient plane");
+    using M = March<ORDER>;
+    const int ncw = nsdg_div_up(ctx->nx, M::OWN);
+    // strips: one wave per SIMD -- a strip of R rows takes R + 2 S - 2 march steps and recomputes up to 2 (S - 1) rows of the
+    // earlier stages, more waves than SIMDs make the last ones wait (512 x 512 DG1: 13.3 / 11.5 / 14.3 us per step for
+    // 2 / 4 / 8 waves per CU; 2048 x 2048 DG2: 514 / 319 / 330 us) -- at least 4 rows
+    int R = NSDG_MARCH_ROWS;
+    if (R <= 0) {
+        const int want = (NSDG_MARCH_WAVES * ctx->num_cus) / ncw;
+        R = nsdg_div_up(j1 - j0, want < 1 ? 1 : want);
+        if (R < 4)
+            R = 4;
     }
-    hipLaunchKernelGGL(transport_fused_kernel<ORDER>, grid, dim3(256), lds, ctx->stream, ctx->nx, ctx->ny, nfields, 1. / ctx->hx, 1. / ctx->hy, dt, fp, vx,
-        vy, unx, uny);
+    const int ns = nsdg_div_up(j1 - j0, R);
+    hipLaunchKernelGGL(transport_march_kernel<ORDER>, dim3(ncw * ns), dim3(64), 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, R, ncw, nfields, 1. / ctx->hx,
+        1. / ctx->hy, dt, fp, vx, vy, unx, uny);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }
@@ -730,27 +834,37 @@ int nsdg_transport_step(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields
     return NSDG_OK;
 }
 
-int nsdg_transport_step_oop(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields, const double* const* phi_in, double* const* phi_out,
-    const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y)
+int nsdg_transport_step_oop_rows(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, double dt, int32_t nfields, const double* const* phi_in,
+    double* const* phi_out, const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y)
 {
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(order >= 0 && order <= 2, "order must be 0, 1 or 2");
+    NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
     NSDG_CHECK_ARG(nfields >= 1 && nfields <= MAXF, "nfields must be 1..4");
     NSDG_CHECK_ARG(phi_in && phi_out && vx_dg && vy_dg && un_x && un_y, "null pointer");
     FieldPtrs fp;
     for (int f = 0; f < MAXF; ++f) {
         const int s = f < nfields ? f : 0;
         NSDG_CHECK_ARG(phi_in[s] && phi_out[s], "null field pointer");
-        NSDG_CHECK_ARG(phi_out[s] != phi_in[s], "phi_out must not alias phi_in (other workgroups read the halo of the input)");
+        NSDG_CHECK_ARG(phi_out[s] != phi_in[s], "phi_out must not alias phi_in (other waves read the rows and columns around theirs)");
         fp.phi0[f] = fp.phis[f] = phi_in[s];
         fp.out[f] = phi_out[s];
     }
+    if (j0 == j1)
+        return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     switch (order) {
-    case 0: return launch_fused<0>(ctx, dt, nfields, fp, vx_dg, vy_dg, un_x, un_y);
-    case 1: return launch_fused<1>(ctx, dt, nfields, fp, vx_dg, vy_dg, un_x, un_y);
-    default: return launch_fused<2>(ctx, dt, nfields, fp, vx_dg, vy_dg, un_x, un_y);
+    case 0: return launch_march<0>(ctx, j0, j1, dt, nfields, fp, vx_dg, vy_dg, un_x, un_y);
+    case 1: return launch_march<1>(ctx, j0, j1, dt, nfields, fp, vx_dg, vy_dg, un_x, un_y);
+    default: return launch_march<2>(ctx, j0, j1, dt, nfields, fp, vx_dg, vy_dg, un_x, un_y);
     }
+}
+
+int nsdg_transport_step_oop(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields, const double* const* phi_in, double* const* phi_out,
+    const double* vx_dg, const double* vy_dg, const double* un_x, const double* un_y)
+{
+    NSDG_NEED_GRID(ctx);
+    return nsdg_transport_step_oop_rows(ctx, order, 0, ctx->ny, dt, nfields, phi_in, phi_out, vx_dg, vy_dg, un_x, un_y);
 }
 
 } // extern "C"

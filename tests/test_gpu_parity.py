@@ -949,10 +949,12 @@ def test_hip_path_matches_the_independent_restatement(ctx, variant):
 
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_fused_stages_transport_step_equals_staged_step_bitwise(ctx, order):
-    """nsdg_transport_step_oop performs all Runge-Kutta stages of a step in ONE launch (tiles of 32 x 16 elements, the
-    intermediate stages on a halo in LDS); it must reproduce nsdg_transport_step -- one launch per stage -- bit for bit, for
-    grids that are not multiples of the tile, smaller than a tile, for several fields, over several steps"""
-    for (nx, ny, nf) in ((70, 37, 1), (33, 17, 2), (5, 3, 1), (128, 64, 3), (31, 50, 4)):
+    """nsdg_transport_step_oop performs all Runge-Kutta stages of a step in ONE launch (a march: a wave owns a window of
+    64 - 2 (order + 1) columns and a strip of rows, stage k runs k rows behind the newest row); it must reproduce
+    nsdg_transport_step -- one launch per stage -- bit for bit, for grids around the window width, narrower than a window, with
+    fewer rows than a strip or than the stages need, for several fields, over several steps"""
+    for (nx, ny, nf) in ((70, 37, 1), (33, 17, 2), (5, 3, 1), (128, 64, 3), (31, 50, 4), (58, 9, 1), (59, 2, 1), (60, 1, 2), (61, 4, 1), (62, 5, 1),
+                         (63, 7, 1), (64, 8, 1), (117, 1, 1), (1, 1, 1), (1, 40, 1), (2, 3, 2), (300, 260, 1)):
         rng = np.random.default_rng(77 + order)
         nc = basis.NCOEF[order]
         ctx.set_grid(nx, ny, 1.0 / nx, 1.3 / ny)
@@ -972,3 +974,27 @@ def test_fused_stages_transport_step_equals_staged_step_bitwise(ctx, order):
         assert float((staged[0] - fields[0]).abs().max()) > 0
     with pytest.raises(abi.NsdgError, match="alias"):
         ctx.transport_step_oop(order, 1e-3, [a[0]], [a[0]], adv)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_fused_transport_step_on_a_row_range_equals_the_full_step_there(ctx, order):
+    """nsdg_transport_step_oop_rows advances the rows [j0, j1) only, from the rows around them (a row block's own rows and its
+    ghost rows): there it must equal the step on the whole array bit for bit, and it must not write any other row"""
+    rng = np.random.default_rng(5 + order)
+    nc = basis.NCOEF[order]
+    for (nx, ny, ranges) in ((70, 41, ((0, 41), (3, 38), (5, 6), (12, 29), (0, 7), (36, 41), (20, 20))), (130, 23, ((4, 19), (3, 4)))):
+        ctx.set_grid(nx, ny, 1.0 / nx, 1.3 / ny)
+        u, v = 0.3 * rng.standard_normal((2 * ny + 1, 2 * nx + 1)), 0.3 * rng.standard_normal((2 * ny + 1, 2 * nx + 1))
+        adv = adv_on_device(ctx, nx, ny, order, u, v)
+        fields = [dev(np.concatenate([1.0 + 0.2 * rng.standard_normal((1, ny, nx)), 0.1 * rng.standard_normal((nc - 1, ny, nx))])) for _ in range(2)]
+        dt = 0.02 / max(nx, ny)
+        full = [torch.zeros_like(f) for f in fields]
+        ctx.transport_step_oop(order, dt, fields, full, adv)
+        for (j0, j1) in ranges:
+            part = [torch.full_like(f, 7.0) for f in fields]
+            ctx.transport_step_oop_rows(order, j0, j1, dt, fields, part, adv)
+            for k in range(2):
+                assert torch.equal(part[k][:, j0:j1], full[k][:, j0:j1]), (order, nx, ny, j0, j1, k)
+                assert bool((part[k][:, :j0] == 7.0).all()) and bool((part[k][:, j1:] == 7.0).all()), (order, nx, ny, j0, j1, k)
+    with pytest.raises(abi.NsdgError, match="row range"):
+        ctx.transport_step_oop_rows(order, 3, ny + 1, dt, fields, full, adv)
