@@ -417,7 +417,7 @@ __device__ __forceinline__ void march_rhs(const double (&below)[DG<ORDER>::NC], 
     constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG;
     NbTrace<NG> nb;
     EdgeVel<NG> E;
-    double mine_r[NG], mine_l[NG], w[NC];
+    double mine_r[NG], mine_l[NG];
     trace_of_left<ORDER>(c, mine_r); // my right trace: what my right neighbour calls "the left neighbour's trace"
     trace_of_right<ORDER>(c, mine_l);
 #pragma unroll
@@ -426,14 +426,22 @@ __device__ __forceinline__ void march_rhs(const double (&below)[DG<ORDER>::NC], 
         nb.l[g] = hasL ? fl : 0., nb.r[g] = hasR ? fr : 0.;
         E.l[g] = V.el[g], E.r[g] = dpp_from_right(V.el[g]), E.b[g] = V.eb[g], E.t[g] = eb_above[g];
     }
+    // hasB / hasT are wave-uniform (a row of the array): a branch instead of NC selects; the trace of "no neighbour" is the sum over
+    // zero coefficients of the other kernels, +0
+    if (hasB)
+        trace_of_bottom<ORDER>(below, nb.b);
+    else {
 #pragma unroll
-    for (int k = 0; k < NC; ++k)
-        w[k] = hasB ? below[k] : 0.;
-    trace_of_bottom<ORDER>(w, nb.b);
+        for (int g = 0; g < NG; ++g)
+            nb.b[g] = 0.;
+    }
+    if (hasT)
+        trace_of_top<ORDER>(above, nb.t);
+    else {
 #pragma unroll
-    for (int k = 0; k < NC; ++k)
-        w[k] = hasT ? above[k] : 0.;
-    trace_of_top<ORDER>(w, nb.t);
+        for (int g = 0; g < NG; ++g)
+            nb.t[g] = 0.;
+    }
     transport_rhs<ORDER>(c, nb, V.vx, V.vy, E, ihx, ihy, rhs);
 }
 
