@@ -24,7 +24,7 @@ def load(d):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         key = None
-        for k in ("mevp_fused_kernel", "mevp_fused2_kernel", "mevp_fused3_kernel", "mevp_fused4_kernel", "transport_stage_kernel<2>", "transport_pair_kernel<2>", "wind_stress_kernel", "ice_strength_kernel",
+        for k in ("mevp_fused_kernel", "mevp_fused2_kernel", "mevp_fused3_kernel", "mevp_fused4_kernel", "transport_stage_kernel<2>", "transport_pair_kernel<2>", "transport_march_kernel<2>", "mevp_prepare_kernel", "wind_stress_kernel", "ice_strength_kernel",
                   "mevp_pack_nodal_kernel", "mevp_stress_kernel", "mevp_velocity_kernel", "column_step_kernel"):
             if k in name:
                 key = k
