@@ -600,23 +600,23 @@ __global__ __launch_bounds__(64) void transport_march_kernel(int nx, int ny, int
                 }
             }
         };
-#if NSDG_MARCH_AHEAD == 1
-        Ahead Q;
-        request(r0 + 1, Q);
-        for (int r = r0 + 2; r <= r1; ++r)
-            step(r, Q);
-#else
-        Ahead Q0, Q1; // two steps ahead: at one wave per SIMD a march step is shorter than a trip to memory
-        request(r0 + 1, Q0);
-        request(r0 + 2, Q1);
+        // NSDG_MARCH_AHEAD request sets in rotation: the set a step has consumed is requested again for the step that many steps
+        // later (two: at one wave per SIMD a march step is shorter than a trip to memory)
+        Ahead Q[NSDG_MARCH_AHEAD];
+#pragma unroll
+        for (int i = 0; i < NSDG_MARCH_AHEAD; ++i)
+            request(r0 + 1 + i, Q[i]);
         int r = r0 + 2;
-        for (; r + 1 <= r1; r += 2) {
-            step(r, Q0);
-            step(r + 1, Q1);
+        for (; r + NSDG_MARCH_AHEAD - 1 <= r1; r += NSDG_MARCH_AHEAD) {
+#pragma unroll
+            for (int i = 0; i < NSDG_MARCH_AHEAD; ++i)
+                step(r + i, Q[i]);
         }
-        if (r <= r1)
-            step(r, Q0);
-#endif
+#pragma unroll
+        for (int i = 0; i + 1 < NSDG_MARCH_AHEAD; ++i) {
+            if (r + i <= r1)
+                step(r + i, Q[i]);
+        }
     }
 }
 
