@@ -1,4 +1,5 @@
 #!/bin/bash
+# (a pass with TCP_*_STALL / TA_* counters stopped answering on this pool once: keep custom sets to SQ / SQC / TCC counters)
 # SQ counters of the fused transport kernel: bash tools/sq_counters_transport.sh TAG BUILD [bench args]   (on the GPU box;
 # BUILD = default or the name of an alt build under nextsimdg_amd/lib/alt)
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
