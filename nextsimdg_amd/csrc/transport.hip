@@ -448,14 +448,21 @@ __device__ __forceinline__ void march_rhs(const double (&below)[DG<ORDER>::NC], 
 #ifndef NSDG_MARCH_AHEAD
 #define NSDG_MARCH_AHEAD 2 // march steps between the request of a row and its use
 #endif
+#ifndef NSDG_MARCH_WG_WAVES
+#define NSDG_MARCH_WG_WAVES 4 // independent waves per workgroup (fewer, larger workgroups are dispatched faster)
+#endif
 template <int ORDER>
-__global__ __launch_bounds__(64) void transport_march_kernel(int nx, int ny, int j0, int j1, int R, int ncw, int nfields, double ihx, double ihy, double dt, FieldPtrs fp,
-    const double* __restrict__ vx_dg, const double* __restrict__ vy_dg, const double* __restrict__ un_x, const double* __restrict__ un_y)
+__global__ __launch_bounds__(64 * NSDG_MARCH_WG_WAVES) void transport_march_kernel(int nx, int ny, int j0, int j1, int R, int ncw, int nwaves, int nfields, double ihx,
+    double ihy, double dt, FieldPtrs fp, const double* __restrict__ vx_dg, const double* __restrict__ vy_dg, const double* __restrict__ un_x,
+    const double* __restrict__ un_y)
 {
     using M = March<ORDER>;
     constexpr int S = M::S, NC = M::NC, NG = M::NG, NR0 = M::NR0;
-    const int lane = threadIdx.x;
-    const int strip = blockIdx.x / ncw, cw = blockIdx.x - strip * ncw;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * NSDG_MARCH_WG_WAVES + (threadIdx.x >> 6); // the waves of a workgroup share nothing
+    if (wave >= nwaves)
+        return;
+    const int strip = wave / ncw, cw = wave - strip * ncw;
     const int y0 = j0 + strip * R, y1 = min(y0 + R, j1); // the rows [j0, j1) of the array are advanced (a row block: its own rows)
     const int x = cw * M::OWN - S + lane;
     const bool hasL = x > 0, hasR = x + 1 < nx;
@@ -644,8 +651,9 @@ int launch_march(nsdg_ctx* ctx, int j0, int j1, double dt, int nfields, const Fi
             R = 4;
     }
     const int ns = nsdg_div_up(j1 - j0, R);
-    hipLaunchKernelGGL(transport_march_kernel<ORDER>, dim3(ncw * ns), dim3(64), 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, R, ncw, nfields, 1. / ctx->hx,
-        1. / ctx->hy, dt, fp, vx, vy, unx, uny);
+    const int nwaves = ncw * ns;
+    hipLaunchKernelGGL(transport_march_kernel<ORDER>, dim3(nsdg_div_up(nwaves, NSDG_MARCH_WG_WAVES)), dim3(64 * NSDG_MARCH_WG_WAVES), 0, ctx->stream, ctx->nx,
+        ctx->ny, j0, j1, R, ncw, nwaves, nfields, 1. / ctx->hx, 1. / ctx->hy, dt, fp, vx, vy, unx, uny);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }
