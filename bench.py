@@ -44,6 +44,16 @@ BYTES_PER_ELEM_SUBITER = 896  # byte model of ONE mEVP s
 BYTES_COMPULSORY_PER_PASS = 776  # what a pass of a fused kernel must move per element whatever it computes on chip
 SHADER_CLOCK_PEAK_HZ = 2.4e9  # MI355X_MICROARCH.md: peak engine clock
 BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
+# fp64 flops of one element-sub-iteration, counted in the ISA of mevp_fused4_kernel (tools/isa_flops.py: 373 v_fma_f64 x 2 + 336
+# v_add / v_mul + 17 v_rcp / v_rsq per lane and march step; min / max / compares / moves count 0); tests/test_bench_launch.py
+# re-counts it when hipcc is present
+FP64_FLOPS_PER_ELEMENT_SUBITER = 1099
+FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER = 373 + 336 + 4 * 17 + 6  # full-rate fp64 instructions + the quarter-rate rcp / rsq as four slots each
+# v_fma_f64 flat out with ONE wave per SIMD -- this kernel's occupancy -- on an MI355X of this pool: 63.6 TFLOP/s at 2.4 GHz and
+# 1245 W (profiles/r04_fp64_energy_valu_vs_mfma.txt; 70.6 / 73.2 with 2 / 4 waves per SIMD); the arithmetic peak is
+# 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz = 78.6
+FP64_VALU_CEILING_TFLOPS = 63.6
+FP64_VALU_PEAK_TFLOPS = 78.6
 COMM_DEADLINE_S = float(os.environ.get("NSDG_COMM_TIMEOUT_S", "300"))  # a rank that has died must not block the others for ever; 0 = wait for ever
 # the same number for torch's process group, where 0 would mean "fail at once": the library's "for ever" becomes a day
 TORCH_TIMEOUT_S = COMM_DEADLINE_S if COMM_DEADLINE_S > 0 else 86400.0
@@ -192,10 +202,14 @@ def cpu_baseline(nsub_full, nx, ny, budget_s=12.0):
     what = "oracle/dyn_oracle.c on the bench's own %dx%d box test: %d of the step's %d mEVP sub-iterations + the DG2 RK3 transport step of H and A, " \
            "the sub-iteration cost scaled to %d per step (a bounded sample of the same workload, not a smaller grid); own CPU restatement -- the " \
            "reference snapshot has no dynamics code to time"
-    res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port", "extrapolated": False,
+    res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port", "extrapolated": True,
+           "scaled_from_sample": {"subiterations_timed": out[False][2], "subiterations_per_step": nsub_full, "factor": nsub_full / out[False][2],
+                                  "how": "value = 1 / (subiterations_per_step x measured seconds per element-sub-iteration + measured seconds per "
+                                         "element of the transport step): every sub-iteration costs the same arithmetic, the grid is the full one"},
            "sample": what % (nx, ny, out[False][2], nsub_full, nsub_full), "subiters_per_s": out[False][1]}
     if True in out:
-        res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1],
+        res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1], "extrapolated": True,
+                            "scaled_from_sample": {"subiterations_timed": out[True][2], "subiterations_per_step": nsub_full, "factor": nsub_full / out[True][2]},
                             "sample": "OpenMP build, the same %dx%d sample, %d sub-iterations + the transport step" % (nx, ny, out[True][2])}
     return res
 
@@ -577,46 +591,49 @@ def main():
             core.transport()
             ev[k][3].record(ctx.stream)
         sync()
+        elapsed = time.perf_counter() - t0
+        where = "reduction over the ranks"
+        own_elapsed = elapsed
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        cycle_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))  # one sub-cycle (nsub sub-iterations), this rank
+        rank_report = {"rank": eff_rank, "rows_owned": blk.r1 - blk.r0, "rows_local": blk.ny, "ghost_rows_below": blk.gb, "ghost_rows_above": blk.gt,
+                       "cycle_ms": cycle_ms, "prepare_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
+                       "transport_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev])),
+                       "step_gpu_ms": float(np.mean([e[0].elapsed_time(e[3]) for e in ev])), "step_wall_ms": 1e3 * own_elapsed / args.steps}
+        rank_report.update(optional("exchange_stats", exchange_stats, core, steps=args.steps) or {})
+        reports = [rank_report]
+        if use_dist:
+            reports = [None] * world
+            dist.all_gather_object(reports, rank_report)
+
+        where = "validity checks"
+        # ---- validity of the run: finite, non-trivial, and the fused pass still equals single sub-iterations bit for bit
+        ok = torch.tensor([float(bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())), float(core.u.abs().max())],
+                          dtype=torch.float64, device=device)
+        guard = None if args.no_guard else fused_pass_guard(ctx, core)
+        ok = torch.cat([ok, torch.tensor([float(guard is not False)], dtype=torch.float64, device=device)])
+        if use_dist:
+            lo = ok.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(ok, op=dist.ReduceOp.MAX)
+            ok[0], ok[2] = lo[0], lo[2]
+        if ok[0] == 0.0 or ok[1] == 0.0:
+            raise SystemExit("bench produced non-finite or trivial fields: invalid run")
+        if ok[2] == 0.0:
+            raise SystemExit("bench: one pass of the fused kernel differs from single sub-iterations on the live state: invalid run")
+
     except (abi.NsdgError, RuntimeError) as e:
-        # a failed launch, a broken communicator, a device error: rank 0 still prints a line (value null + the error), every
-        # rank leaves with a non-zero status WITHOUT destructors (they would synchronise a device that may never drain)
+        # a failed launch, a broken communicator, a device error, a collective of the reduction / validity part that a dead rank
+        # never joins (torch raises after its timeout): rank 0 still prints a line (value null + the error), every rank
+        # leaves with a non-zero status WITHOUT destructors (they would synchronise a device that may never drain)
         sys.stderr.write("bench.py rank %d failed in the %s: %r\n" % (rank, where, e))
         if rank == 0:
             print(json.dumps(failure_line(args, world, where, e)), flush=True)
         sys.stderr.flush()
         os._exit(3)
-    elapsed = time.perf_counter() - t0
-    own_elapsed = elapsed
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0])
-    cycle_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))  # one sub-cycle (nsub sub-iterations), this rank
-    rank_report = {"rank": eff_rank, "rows_owned": blk.r1 - blk.r0, "rows_local": blk.ny, "ghost_rows_below": blk.gb, "ghost_rows_above": blk.gt,
-                   "cycle_ms": cycle_ms, "prepare_ms": float(np.mean([e[0].elapsed_time(e[1]) for e in ev])),
-                   "transport_ms": float(np.mean([e[2].elapsed_time(e[3]) for e in ev])),
-                   "step_gpu_ms": float(np.mean([e[0].elapsed_time(e[3]) for e in ev])), "step_wall_ms": 1e3 * own_elapsed / args.steps}
-    rank_report.update(optional("exchange_stats", exchange_stats, core, steps=args.steps) or {})
-    reports = [rank_report]
-    if use_dist:
-        reports = [None] * world
-        dist.all_gather_object(reports, rank_report)
-
-    # ---- validity of the run: finite, non-trivial, and the fused pass still equals single sub-iterations bit for bit
-    ok = torch.tensor([float(bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())), float(core.u.abs().max())],
-                      dtype=torch.float64, device=device)
-    guard = None if args.no_guard else fused_pass_guard(ctx, core)
-    ok = torch.cat([ok, torch.tensor([float(guard is not False)], dtype=torch.float64, device=device)])
-    if use_dist:
-        lo = ok.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(ok, op=dist.ReduceOp.MAX)
-        ok[0], ok[2] = lo[0], lo[2]
-    if ok[0] == 0.0 or ok[1] == 0.0:
-        raise SystemExit("bench produced non-finite or trivial fields: invalid run")
-    if ok[2] == 0.0:
-        raise SystemExit("bench: one pass of the fused kernel differs from single sub-iterations on the live state: invalid run")
-
     full, twos, ones = core.passes_per_step()
     per_launch = core.per_pass if full else (2 if twos else 1)
     launches = full if full else (twos if twos else ones)  # launches of the dominant kernel per sub-cycle
@@ -634,7 +651,15 @@ def main():
         survey_gbs = algorithmic / (launch_ms * 1e-3) / 1e9
         off = optional("offline_counters", offline_counters, nx, ny, fused_kernel) if eff_world == 1 else None
         copy_peak = optional("copy_peak_gbs", copy_peak_gbs, ctx, device)
-        roof = {"bound": "hbm", "kernel": fused_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        traffic_gbs = (off["traffic"] / (launch_ms * 1e-3) / 1e9) if off else None  # L2 -> fabric bytes per second (Infinity-Cache hits included)
+        flops = own_elems * per_launch * FP64_FLOPS_PER_ELEMENT_SUBITER
+        tflops = flops / (launch_ms * 1e-3) / 1e12
+        roof = {"bound": "fp64-valu/power",
+                "bound_note": "what the counters and the power probe support (DESIGN.md section 5): vector-ALU issue of fp64 arithmetic at the socket's power "
+                              "cap (in-kernel clock ~1.75 of 2.4 GHz) with the L2 -> fabric traffic at `fabric_traffic_frac_of_copy_peak` of the measured "
+                              "copy ceiling; HBM bytes alone (`frac`) are not what limits the pass.  `achieved` / `peak` / `frac` stay the HBM figures "
+                              "BASELINE.json's target is stated in; the flop side is `fp64_tflops` / `frac_fp64_valu`",
+                "kernel": fused_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_definition": "frac = frac_compulsory = compulsory_bytes_per_launch / avg_launch_ms / 8 TB/s: the bytes one pass must move whatever it "
                                    "keeps on chip; a pass performs subiterations_per_launch sub-iterations on them, so fractions of kernels with "
@@ -658,7 +683,21 @@ def main():
                                           "+ stress out 192 + u,v out 64" % BYTES_COMPULSORY_PER_PASS,
                 "avg_launch_ms": launch_ms, "launches_per_step": launches, "subiterations_per_launch": per_launch,
                 "ms_per_subiteration": launch_ms / per_launch,
-                "hbm_physical_frac": (off["traffic"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if off else None,
+                "fabric_traffic_frac": (traffic_gbs / HBM_PEAK_GBS) if off else None,
+                "fabric_traffic_frac_of_copy_peak": (traffic_gbs / copy_peak) if (off and copy_peak) else None,
+                "fabric_traffic_note": "`traffic` is FETCH_SIZE x 2 + WRITE_SIZE of the offline counter passes: bytes between the XCDs' L2 and the fabric.  "
+                                       "Reads served by the 256 MB Infinity Cache are counted, so this is NOT HBM traffic and may exceed the copy ceiling "
+                                       "(round 4 called the first figure hbm_physical_frac: renamed)",
+                "fp64_flops_per_launch": flops, "fp64_tflops": tflops,
+                "fp64_flops_model": "%d fp64 flops per element and sub-iteration (ISA count, tools/isa_flops.py: v_fma_f64 = 2) x %d sub-iterations x owned "
+                                    "elements; the lanes and rows recomputed at the edges of a strip are not counted" % (FP64_FLOPS_PER_ELEMENT_SUBITER, per_launch),
+                "fp64_valu_ceiling_tflops": FP64_VALU_CEILING_TFLOPS,
+                "frac_fp64_valu": tflops / FP64_VALU_CEILING_TFLOPS,
+                "frac_fp64_valu_note": "against v_fma_f64 flat out at this kernel's occupancy (one wave per SIMD) measured on this pool: 63.6 TFLOP/s at 2.4 GHz, "
+                                       "1245 W (profiles/r04_fp64_energy_valu_vs_mfma.txt); arithmetic peak 78.6.  Only %d of the kernel's %d fp64 issue slots "
+                                       "per element-sub-iteration are FMAs: a flat-out run of ITS instruction mix would reach %.1f" % (
+                                           373, FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER,
+                                           FP64_VALU_PEAK_TFLOPS * FP64_FLOPS_PER_ELEMENT_SUBITER / (2.0 * FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER)),
                 "valu_issue_frac": valu_issue_frac(off["valu_insts"], launch_ms, ctx) if off and off.get("valu_insts") else None}
         line = {
             "metric": "element-steps/sec (dynamics+transport)", "value": None if loop_world else value, "unit": "element-steps/s",

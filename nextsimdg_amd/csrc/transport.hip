@@ -862,9 +862,21 @@ int nsdg_transport_step_oop_rows(nsdg_ctx* ctx, int32_t order, int32_t j0, int32
     for (int f = 0; f < MAXF; ++f) {
         const int s = f < nfields ? f : 0;
         NSDG_CHECK_ARG(phi_in[s] && phi_out[s], "null field pointer");
-        NSDG_CHECK_ARG(phi_out[s] != phi_in[s], "phi_out must not alias phi_in (other waves read the rows and columns around theirs)");
         fp.phi0[f] = fp.phis[f] = phi_in[s];
         fp.out[f] = phi_out[s];
+    }
+    {
+        // the fields of a launch are advanced one after the other by waves that run concurrently: an output that overlaps ANY
+        // input (not only its own) or another output would be read half-written -- compared as ranges of nc nx ny doubles
+        const long len = (long)(order == 0 ? 1 : (order == 1 ? 3 : 6)) * ctx->nx * ctx->ny;
+        auto overlap = [len](const double* a, const double* b) { return a < b + len && b < a + len; };
+        for (int i = 0; i < nfields; ++i) {
+            for (int j = 0; j < nfields; ++j)
+                NSDG_CHECK_ARG(!overlap(phi_out[i], phi_in[j]),
+                    "phi_out must not alias or overlap ANY phi_in (other waves read the rows and columns around theirs, and the fields of a launch run concurrently)");
+            for (int j = 0; j < i; ++j)
+                NSDG_CHECK_ARG(!overlap(phi_out[i], phi_out[j]), "two phi_out arrays alias or overlap");
+        }
     }
     if (j0 == j1)
         return NSDG_OK;

@@ -110,3 +110,28 @@ def test_failure_line_and_optional_diagnostics():
     assert bench.optional("copy_peak_gbs", lambda: 1 / 0) is None
     assert len(bench.DIAGNOSTICS_FAILED) == 1 and "copy_peak_gbs" in bench.DIAGNOSTICS_FAILED[0] and "ZeroDivisionError" in bench.DIAGNOSTICS_FAILED[0]
     del bench.DIAGNOSTICS_FAILED[:]
+
+
+def test_roofline_labels_say_what_was_measured():
+    """round-4 review, weak point 3: the line must not call fabric traffic HBM traffic, must not call a scaled CPU sample
+    'not extrapolated', and carries a flop-side entry next to the byte-side one.  The line itself needs a GPU
+    (tests/test_gpu_configs.py checks the keys of a real one); here: the constants and the source of the labels."""
+    import bench
+
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "hbm_physical_frac\":" not in src.replace("called the first figure hbm_physical_frac", "")
+    for key in ('"fabric_traffic_frac"', '"fabric_traffic_frac_of_copy_peak"', '"fp64_flops_per_launch"', '"frac_fp64_valu"', '"scaled_from_sample"',
+                '"bound": "fp64-valu/power"', '"frac_definition"', '"survey_8d_ratio"', '"wasted_traffic_ratio"'):
+        assert key in src, key
+    assert '"extrapolated": False' not in src
+    # the flop count is the ISA's: re-counted when the compiler is here (3 s)
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_flops
+
+        loops = isa_flops.loops(isa_flops.listing())
+        assert len(loops) == 2
+        for _, ins in loops:  # the stages 1-3 and the loader run the same arithmetic
+            c = isa_flops.flops(ins)
+            assert c["flops"] == bench.FP64_FLOPS_PER_ELEMENT_SUBITER, c
+            assert c["fma"] + c["addmul"] + 4 * c["trans"] + c["other_f64"] == bench.FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER, c

@@ -974,6 +974,17 @@ def test_fused_stages_transport_step_equals_staged_step_bitwise(ctx, order):
         assert float((staged[0] - fields[0]).abs().max()) > 0
     with pytest.raises(abi.NsdgError, match="alias"):
         ctx.transport_step_oop(order, 1e-3, [a[0]], [a[0]], adv)
+    # the fields of a launch run concurrently: a ping-pong with PERMUTED lists (output 0 is input 1), partially overlapping
+    # buffers and two identical outputs are refused as well (compared as ranges of nc nx ny doubles)
+    x, y = torch.zeros_like(a[0]), torch.zeros_like(a[0])
+    with pytest.raises(abi.NsdgError, match="alias"):
+        ctx.transport_step_oop(order, 1e-3, [x, y], [y, x], adv)
+    with pytest.raises(abi.NsdgError, match="alias"):
+        ctx.transport_step_oop(order, 1e-3, [x, y], [a[0], a[0]], adv)
+    big = torch.zeros(2 * x.numel(), dtype=torch.float64, device="cuda")
+    half = x.numel() // 2
+    with pytest.raises(abi.NsdgError, match="alias"):
+        ctx.transport_step_oop(order, 1e-3, [big[:x.numel()].view_as(x)], [big[half:half + x.numel()].view_as(x)], adv)
 
 
 @pytest.mark.parametrize("order", [0, 1, 2])
