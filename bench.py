@@ -427,6 +427,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="native driver: replay the launches between two exchanges as one hipGraph")
     ap.add_argument("--no-guard", action="store_true", help="skip the fused-pass == single-iterations check (timing experiments with "
                     "deliberately wrong diagnostic builds only; the line then says 'finite fields' as its self-check)")
+    ap.add_argument("--no-closure", action="store_true", help="the bare scheme of rounds 1-4: no ridging cap / scaling limiter in the transport, no "
+                    "ice-free-node rule (A/B of what the closure costs; the default run has it ON, as the hosts do)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (gloo): launch, rendezvous, planning; no metric")
     args = ap.parse_args()
 
@@ -499,7 +501,7 @@ def main():
             c.set_mevp_occupancy(args.occupancy)
         if args.transport_variant is not None:
             c.set_transport_variant(args.transport_variant)
-        c.set_mevp_params(c.mevp_default_params(alpha=alpha, beta=alpha))
+        c.set_mevp_params(c.mevp_default_params(alpha=alpha, beta=alpha, **(dict(min_conc=0.0, min_thick=0.0) if args.no_closure else {})))
         b, d = plan_blocks(c.mevp_variant, kpass, nx, ny, eff_rank, eff_world)
         ex = None
         if eff_world > 1 or os.environ.get("NSDG_FORCE_DIST"):
@@ -509,7 +511,7 @@ def main():
                 c.comm_deadline(COMM_DEADLINE_S)
         nat = args.driver == "native" and (ex is None or isinstance(ex, rowblock.NativeHaloExchanger))
         co = (rowblock.CoupledCore if coupled else rowblock.DynamicsCore)(c, b, L / nx, L / ny, dt, nsub, device, exchanger=ex, native=nat,
-                                                                          use_graph=args.graph)
+                                                                          use_graph=args.graph, closure=not args.no_closure)
         if coupled:
             co.load_column(column)
         co.load_global(H, A, uo, vo, ua, va)
@@ -714,6 +716,8 @@ def main():
                                args.halo) if eff_world > 1 else ""),
                        "mevp_passes": "%s sub-iteration%s per kernel pass" % ({4: "four", 3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
                        "mevp_variant": args.variant if args.variant is not None else "default",
+                       "closure": "off (--no-closure: the bare scheme)" if args.no_closure else
+                                  "on: ridging cap + scaling limiter in the transport epilogue, free drift at ice-free nodes (include/nsdg.h)",
                        "driver": ("native (nsdg_rb_mevp_run / nsdg_rb_transport_run)" + (" + hipGraph replay" if args.graph else "")) if native else "python sequence",
                        "parity": "dynamics parity unpinned (the reference snapshot has no DG/mEVP code); self-check of this run: "
                                  + ("fused pass == single sub-iterations bitwise on the live state" if guard else "finite fields")},

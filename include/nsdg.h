@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define NSDG_ABI_VERSION 4
+#define NSDG_ABI_VERSION 5
 
 typedef enum {
     NSDG_OK = 0,
@@ -130,14 +130,21 @@ int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hice, double* 
 
 /* ---- dynamics: DG transport + mEVP (no counterpart in the reference snapshot: CMakeLists.txt:43-46
  *      comments the dynamics component out; built from the published formulation)
- * VALID INPUT DOMAIN (round 4, profiles/r04_soak_divergence_cause.md).  The scheme has no redistribution closure (nothing caps
- * the concentration at 1: the reference has none either, physics/src/modules/HiblerConcentration.cpp:32-38), no limiter in the
- * DG2 transport and no treatment of nodes without ice.  It is valid for a compact cover that starts at A = 1 (the box test: the
- * clamp of A in the ice strength makes dP/dA = 0) and for any run that ends before a row of elements at a closed boundary has
- * converged to A = 1.  Beyond that a one-element-wide band piles up at the wall, breaks into converging and diverging cells,
- * the transport undershoots beside it, the nodal mass reaches h_min and the velocity of such a node runs away -- after 22
- * model hours from a uniform A = 0.9 at 4096 x 4096, after 34-43 hours at 1024 x 1024.  A larger alpha = beta only delays the
- * sequence.  The calls do not check this; both hosts stop loudly on non-finite fields. */
+ * INPUT DOMAIN AND CLOSURE (round 5; the failure it answers: profiles/r04_soak_divergence_cause.md, the runs that now complete:
+ * profiles/r05_closure.md).  Without a closure the scheme leaves the physical range once ice converging against a closed wall
+ * reaches A = 1 (a one-element band piles up, the unlimited DG2 transport undershoots beside it, a node of floor mass between full
+ * elements runs away).  Three pieces close it; none of them has a counterpart in the reference, whose concentration model has no
+ * cap either (physics/src/modules/HiblerConcentration.cpp:32-47) -- the shape followed is the column model's own cut-off rule
+ * (physics/src/modules/NextsimPhysics.cpp:210-219):
+ *   1. ridging: the cell mean of a field with cap_mean != 0 (the concentration, hi = 1) is capped at hi at the end of a transport
+ *      step; the mean thickness -- the conserved volume -- is a field of its own and is not touched, so convergence beyond a
+ *      closed cover turns into (true) thickness;
+ *   2. a Zhang-Shu scaling limiter at the end of a transport step keeps the values of a bounded field at the scheme's quadrature
+ *      points (volume and edge Gauss points) inside [lo, hi] by scaling its higher coefficients; cell means are never changed;
+ *   3. ice-free nodes (nsdg_mevp_params.min_conc / min_thick) are in free drift and do not feel their neighbours' stress.
+ * 1 and 2 are per-field properties the host states with nsdg_transport_bounds_set (they are OFF until it does: the library does
+ * not know which field is a concentration); 3 is ON by default.  The calls still do not check their inputs; both hosts stop
+ * loudly on non-finite fields. */
 typedef struct {
     double rho_ice, rho_atm, rho_ocean;
     double c_atm, c_ocean;
@@ -145,7 +152,12 @@ typedef struct {
     double delta_min;
     double fc;
     double alpha, beta;
-    double h_min;
+    double h_min; /* floor of the nodal mean thickness in the nodal mass */
+    /* ice-free-node rule: a node with mean concentration < min_conc or true thickness cgH / cgA < min_thick is in free drift (full
+     * exposure to wind and ocean drag, Coriolis, floor mass) and the stress divergence of the neighbouring elements is weighted by
+     * 2^-100 there.  Defaults: the column model's cut-off values 1e-12 and 0.01 m (nextsim_thermo.min_conc / min_thick,
+     * physics/src/modules/NextsimPhysics.cpp:81-82).  Both 0: rule off. */
+    double min_conc, min_thick;
 } nsdg_mevp_params;
 
 void nsdg_mevp_default_params(nsdg_mevp_params* p);
@@ -205,6 +217,21 @@ int nsdg_transport_step_oop(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfi
 int nsdg_transport_step_oop_rows(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, double dt, int32_t nfields,
     const double* const* phi_in, double* const* phi_out, const double* vx_dg, const double* vy_dg, const double* un_x,
     const double* un_y);
+
+/* Closure of a transport step (see "INPUT DOMAIN AND CLOSURE" above): bounds of the advected fields, in the order in which the
+ * step entry points receive them.  nfields = 0 (default): no closure.  Once set, nsdg_transport_step, nsdg_transport_step_oop[_rows]
+ * and nsdg_rb_transport_run apply cap + limiter to the new state before they return it (the marching launch in its epilogue, at
+ * no extra memory traffic); they then require the same number of fields.  nsdg_transport_stage never limits. */
+typedef struct {
+    double lo, hi; /* bounds at the quadrature points; hi = +infinity (HUGE_VAL): no upper bound */
+    int32_t cap_mean; /* != 0: a cell mean above hi is set to hi (needs a finite hi) */
+    int32_t reserved;
+} nsdg_field_bounds;
+int nsdg_transport_bounds_set(nsdg_ctx* ctx, int32_t nfields, const nsdg_field_bounds* bounds);
+
+/* cap + limiter as a pass of its own, in place on the element rows [j0, j1) -- for callers that compose a step from
+ * nsdg_transport_stage calls; bit-identical to what the step entry points apply.  NSDG_ERR_STATE without bounds. */
+int nsdg_transport_limit(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, int32_t nfields, double* const* phi);
 
 /* nodal average of a DG field on the CG2 lattice (mean thickness / concentration at the nodes) */
 int nsdg_dg_to_cg(nsdg_ctx* ctx, int32_t ncoef, const double* f_dg, double* f_cg);

@@ -30,7 +30,17 @@ class ColumnParams(C.Structure):
 class MevpParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "rho_ice", "rho_atm", "rho_ocean", "c_atm", "c_ocean", "pstar", "compaction", "delta_min", "fc",
-        "alpha", "beta", "h_min")]
+        "alpha", "beta", "h_min", "min_conc", "min_thick")]
+
+
+class FieldBounds(C.Structure):
+    """nsdg_field_bounds: closure of a transport step for one advected field"""
+    _fields_ = [("lo", C.c_double), ("hi", C.c_double), ("cap_mean", C.c_int32), ("reserved", C.c_int32)]
+
+
+# the closure of the dynamics' two advected fields (include/nsdg.h "INPUT DOMAIN AND CLOSURE"): mean thickness H >= 0; concentration
+# 0 <= A <= 1 with the cell mean capped at 1 (ridging: further convergence raises the true thickness H / A)
+H_A_BOUNDS = ((0.0, float("inf"), False), (0.0, 1.0, True))
 
 
 class HaloSeg(C.Structure):
@@ -91,6 +101,8 @@ SYMBOLS = {
     "nsdg_transport_step": (C.c_int, [VP, I32, D, I32, C.POINTER(VP)] + [VP] * 5),
     "nsdg_transport_step_oop": (C.c_int, [VP, I32, D, I32, C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
     "nsdg_transport_step_oop_rows": (C.c_int, [VP, I32, I32, I32, D, I32, C.POINTER(VP), C.POINTER(VP)] + [VP] * 4),
+    "nsdg_transport_bounds_set": (C.c_int, [VP, I32, C.POINTER(FieldBounds)]),
+    "nsdg_transport_limit": (C.c_int, [VP, I32, I32, I32, I32, C.POINTER(VP)]),
     "nsdg_dg_to_cg": (C.c_int, [VP, I32, VP, VP]),
     "nsdg_ice_strength": (C.c_int, [VP, I32, I32, VP, VP, VP]),
     "nsdg_boxtest_forcing": (C.c_int, [VP, D, D, VP, VP, VP, VP]),
@@ -538,6 +550,21 @@ class Context:
         _check_f64(*fields_in, *fields_out, *adv)
         self._call(self.lib.nsdg_transport_step_oop_rows(self.h, order, j0, j1, float(dt), len(fields_in), _ptr_array(fields_in),
                                                          _ptr_array(fields_out), *[_ptr(t) for t in adv]))
+
+    def set_transport_bounds(self, bounds):
+        """closure of a transport step: one (lo, hi, cap_mean) per advected field, in the order of the step calls' field lists;
+        () or None = none.  abi.H_A_BOUNDS: the dynamics' H and A"""
+        bounds = tuple(bounds or ())
+        arr = (FieldBounds * max(len(bounds), 1))()
+        for k, (lo, hi, cap) in enumerate(bounds):
+            arr[k].lo, arr[k].hi, arr[k].cap_mean = float(lo), float(hi), int(bool(cap))
+        self._call(self.lib.nsdg_transport_bounds_set(self.h, len(bounds), arr))
+        self.transport_bounds = bounds
+
+    def transport_limit(self, order, j0, j1, fields):
+        """cap + scaling limiter in place on the rows [j0, j1) (what the step entry points apply themselves)"""
+        _check_f64(*fields)
+        self._call(self.lib.nsdg_transport_limit(self.h, order, j0, j1, len(fields), _ptr_array(fields)))
 
     def dg_to_cg(self, f_dg, f_cg):
         _check_f64(f_dg, f_cg)

@@ -182,10 +182,19 @@ __device__ __forceinline__ void pack_node(const nsdg_mevp_params& P, double dt, 
     double uoc, double voc, double cgh, double cga, double* __restrict__ packed, long plane, long n)
 {
     const double h = fmax(cgh, P.h_min);
-    const double a = fmin(fmax(cga, 0.), 1.);
+    // Ice-free-node rule (round 5; the shape of the column model's cut-off  c_new < minc || hi < minh,
+    // physics/src/modules/NextsimPhysics.cpp:210-219): a node whose mean concentration is below min_conc or whose TRUE thickness
+    // cgH / cgA is below min_thick is in FREE DRIFT -- full exposure (a = 1) to wind stress and ocean drag, Coriolis, its floor mass
+    // -- and does not feel the stress divergence of the neighbouring elements.  That costs the sub-cycle NOTHING: the update is
+    //   u' = (K1 h' u + c2 + drag u_o + K3 h' v + div_x / M) / (K2 h' + drag),  drag = cd |v_o - v|,
+    // homogeneous of degree 0 in (h', cd, c2, c3, div): scaling the four packed coefficients by 2^100 (exact: a power of two)
+    // leaves every other term as it is and weights the divergence by 2^-100 -- below the last bit of the sum.  Both 0: rule off.
+    const bool ice_free = (P.min_conc > 0. || P.min_thick > 0.) && (cga < P.min_conc || cgh < P.min_thick * cga);
+    const double a = ice_free ? 1. : fmin(fmax(cga, 0.), 1.);
     const double mdt = P.rho_ice * h / dt;
     const double cor = P.rho_ice * h * P.fc;
-    const double c[6] = { h, a * (P.c_ocean * P.rho_ocean), mdt * u0 + a * tax - cor * voc, mdt * v0 + a * tay + cor * uoc, uoc, voc };
+    const double w = ice_free ? 0x1p100 : 1.;
+    const double c[6] = { w * h, w * (a * (P.c_ocean * P.rho_ocean)), w * (mdt * u0 + a * tax - cor * voc), w * (mdt * v0 + a * tay + cor * uoc), uoc, voc };
     store_nodal(packed, plane, n, c);
 }
 

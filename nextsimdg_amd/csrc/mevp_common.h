@@ -460,6 +460,7 @@ __device__ __forceinline__ void node_contrib(const double (&s11)[8], const doubl
 //   [0] h'                                      [3] c3 = (m/dt)*v0 + a*tau_y + cor*u_ocean
 //   [1] cd = a * C_o * rho_o                    [4] u_ocean
 //   [2] c2 = (m/dt)*u0 + a*tau_x - cor*v_ocean  [5] v_ocean
+// (an ice-free node -- mevp.hip: pack_node -- stores [0]..[3] scaled by 2^100 with a = 1: free drift, the divergence weighted by 2^-100)
 // and three launch constants K1 = rho_ice*beta/dt, K2 = rho_ice*(1+beta)/dt, K3 = rho_ice*f_c, so that
 // the update of DESIGN.md section 3.2 reads
 //   drag = cd*|v_o - v|;  u' = (K1 h' u + c2 + drag*u_o + K3 h' v + div_x/M) / (K2 h' + drag)

@@ -131,6 +131,17 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     const bool active = rowraw >= G.first && rowraw <= G.last; // wave-uniform
     const int row = min(max(rowraw, G.first), G.last);
     const int nrow = min(max(rowraw + 1, G.first), G.last); // the row this stage works on in the NEXT step: its inputs are requested during this one
+    // TIMING-ONLY builds (tools/ab_build.sh NAME -DNSDG_F4_TIMING=bits; wrong results: bench.py --no-guard; never defined in the
+    // product): what the re-reads of ice strength (P) and nodal coefficients (c) by the stages 1-3 cost.  bit 0: they read P of a
+    // FIXED row (same instructions, L1 / L2 hits, no fabric traffic); bit 1: the same for c; bit 2: P is not re-read at all;
+    // bit 3: c is not re-read at all
+#ifdef NSDG_F4_TIMING
+    const int prow = (!FIRST && (NSDG_F4_TIMING & 1)) ? G.first : nrow, crow = (!FIRST && (NSDG_F4_TIMING & 2)) ? G.first : nrow;
+    constexpr bool skipP = !FIRST && (NSDG_F4_TIMING & 4), skipC = !FIRST && (NSDG_F4_TIMING & 8);
+#else
+    const int prow = nrow, crow = nrow;
+    constexpr bool skipP = false, skipC = false;
+#endif
     const int ix = M.ix, nn = M.nn;
     NSDG_STAMP(0);
     if (!FIRST && !active) { // ------------------------------------------------------------------- idle step: meet the barrier, touch nothing
@@ -177,7 +188,8 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
     __builtin_amdgcn_sched_barrier(0);
     NSDG_STAMP(3);
-    request_P4(M, nrow, f, pg); // P, and in stage 0 u, v, of the next row
+    if (!skipP)
+        request_P4(M, prow, f, pg); // P, and in stage 0 u, v, of the next row
     if (FIRST) {
         if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
 #pragma unroll
@@ -233,7 +245,8 @@ __device__ __forceinline__ void march_step4(const MarchConst3& M, const Stage4& 
     // instead -- 48 registers fewer across the step in the stages 1-3, whose coefficients come from L2 / the Infinity Cache --
     // measured slower twice, alternating runs on one box: 1.000-1.002 against 0.994-0.998 ms per pass in the first structure,
     // 1.005-1.008 against 0.962-0.964 in the final one: the L2 / Infinity-Cache latency is then exposed.)
-    request_c4(M, nrow, f.c, packed);
+    if (!skipC)
+        request_c4(M, crow, f.c, packed);
     NSDG_STAMP(11);
     if (!FIRST && bar == 2)
         handover_barrier();

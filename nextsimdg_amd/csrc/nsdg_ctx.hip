@@ -59,6 +59,10 @@ void nsdg_mevp_default_params(nsdg_mevp_params* p)
     p->alpha = 1500.;
     p->beta = 1500.;
     p->h_min = 1e-4;
+    // ice-free-node rule ON, with the column model's own cut-off values (nextsim_thermo.min_conc / min_thick,
+    // physics/src/modules/NextsimPhysics.cpp:81-82, applied there as  c_new < minc || hi < minh,  :210-219)
+    p->min_conc = 1e-12;
+    p->min_thick = 0.01;
 }
 
 int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
@@ -91,6 +95,7 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     // (profiles/r03_transport_ab.log; bit-identical); march 1.51-1.76 against 1.55 ms for two fields in round 1
     c->transport_variant = 2;
     c->transport_rows = 0;
+    c->nbounds = 0;
     c->pack_dt = 0.;
     c->d_ptrs = nullptr;
     c->comm = nullptr;

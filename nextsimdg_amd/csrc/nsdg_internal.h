@@ -23,6 +23,8 @@ struct nsdg_ctx {
     double pack_dt; // time step the packed nodal coefficients were built for (0 = never packed)
     int transport_variant, transport_rows; // transport stage kernel: 0 one element per lane / 2 two elements per lane; rows per workgroup
     int fused_min_waves; // register budget of the fused kernel: 1 or 2 waves per SIMD
+    int nbounds; // closure of a transport step: bounds of the advected fields (0 = none), nsdg_transport_bounds_set
+    nsdg_field_bounds bounds[4];
     // device scratch for small host->device tables (field pointer lists of the transport stage)
     double** d_ptrs;
     nsdg_comm* comm; // row-block communicator (halo.hip), null until nsdg_comm_init*

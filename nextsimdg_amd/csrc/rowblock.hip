@@ -597,6 +597,9 @@ int nsdg_rb_transport_run(nsdg_ctx* ctx, nsdg_rb_transport* p, double dt, int32_
         if ((rc = nsdg_transport_stage(ctx, d.order, g.j0, g.j1, dt, 1.0 / 3.0, 2.0 / 3.0, d.nfields, cur, d.t2, nxt, d.vx_dg, d.vy_dg, d.un_x, d.un_y))
             != NSDG_OK)
             return rc;
+        // the closure of the step on the block's own rows (the march applies it in its epilogue); the ghost rows receive limited values
+        if (ctx->nbounds > 0 && (rc = nsdg_transport_limit(ctx, d.order, g.j0, g.j1, d.nfields, nxt)) != NSDG_OK)
+            return rc;
     }
     if ((rc = exchange(p->new_plan[parity])) != NSDG_OK)
         return rc;

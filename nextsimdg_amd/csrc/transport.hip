@@ -13,6 +13,7 @@
 // quadrature points are compile-time constants (tools/gen_tables.py) folded into the instruction
 // stream by full unrolling; zero entries cost nothing.  HBM-bound: 1008 B / element-step for
 // DG2 x 2 fields x RK3.
+#include <cmath>
 #include <cstdint>
 
 #include "dg_tables.h"
@@ -46,6 +47,11 @@ struct FieldPtrs {
     const double* phi0[MAXF];
     const double* phis[MAXF];
     double* out[MAXF];
+    // closure of a full step (nsdg_transport_bounds_set; unused by a bare stage): bounds of field f at the quadrature points and
+    // whether its cell mean is capped at hi; limit == 0: none
+    double lo[MAXF], hi[MAXF];
+    int cap[MAXF];
+    int limit;
 };
 
 // acc += tab * val where tab is a compile-time table entry: after full unrolling the load of the
@@ -62,6 +68,82 @@ struct FieldPtrs {
 __device__ __forceinline__ double rk_update(double a, double b, double dt, double imass, double phi0, double c, double rhs)
 {
     return a != 0. ? a * phi0 + b * (c + dt * imass * rhs) : b * (c + dt * imass * rhs);
+}
+
+// Closure of a transport step on ONE element (oracle_transport_limit): cap of the cell mean (ridging, for a
+// field with cap != 0: a mean above hi becomes hi), then the Zhang-Shu scaling limiter -- the higher coefficients are scaled by
+// the largest theta <= 1 that keeps the values at the scheme's own quadrature points, the NQ volume Gauss points and the NG Gauss
+// points of each edge, inside [lo, hi]; the cell mean is never changed by the limiter.  ONE function for the marching kernel's
+// epilogue and for the stand-alone kernel behind nsdg_transport_limit: the two round identically (fused step == staged step).
+// The division runs only on lanes whose element leaves the range (rare: a handful of elements of a model step).
+template <int ORDER>
+__device__ __forceinline__ void limit_cell(double (&c)[DG<ORDER>::NC], double lo, double hi, bool cap)
+{
+    constexpr int NC = DG<ORDER>::NC, NG = DG<ORDER>::NG, NQ = DG<ORDER>::NQ;
+    if (cap)
+        c[0] = fmin(c[0], hi);
+    if constexpr (ORDER > 0) {
+        // deviations from the mean at the points (the basis functions 1.. have zero mean: value = mean + deviation)
+        double dmin = 0., dmax = 0.; // the mean itself is a convex combination of the volume-point values: the extrema straddle 0
+        if constexpr (ORDER == 2) {
+            // sum-factorised: d(x, y) = X(x) + Y(y) + c5 x y with X = c1 x + c3 (x^2 - 1/12), Y = c2 y + c4 (y^2 - 1/12) at the abscissae
+            // -g, 0, g (Gauss) and -1/2, 1/2 (edges) -- seven distinct fp64 literals instead of the ~100 of the dense point tables,
+            // which the marching kernel has no scalar registers left for (literals live in scalar register pairs)
+            constexpr double G = 0.3872983346207417, P2E = 1. / 15., P2M = -1. / 12., P2H = 1. / 6.; // sqrt(3/5)/2; x^2 - 1/12 at g, 0, 1/2
+            double X[5], Y[5];
+            X[0] = c[3] * P2E - G * c[1], X[1] = c[3] * P2M, X[2] = c[3] * P2E + G * c[1], X[3] = c[3] * P2H - 0.5 * c[1], X[4] = c[3] * P2H + 0.5 * c[1];
+            Y[0] = c[4] * P2E - G * c[2], Y[1] = c[4] * P2M, Y[2] = c[4] * P2E + G * c[2], Y[3] = c[4] * P2H - 0.5 * c[2], Y[4] = c[4] * P2H + 0.5 * c[2];
+            const double GG = (G * G) * c[5], GH = (0.5 * G) * c[5];
+#pragma unroll
+            for (int qy = 0; qy < 3; ++qy)
+#pragma unroll
+                for (int qx = 0; qx < 3; ++qx) {
+                    const int sg = (qx - 1) * (qy - 1);
+                    const double d = sg == 0 ? X[qx] + Y[qy] : (sg > 0 ? (X[qx] + Y[qy]) + GG : (X[qx] + Y[qy]) - GG);
+                    dmin = fmin(dmin, d), dmax = fmax(dmax, d);
+                }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double e = q == 1 ? 0. : (q == 2 ? GH : -GH); // c5 x y on an edge x = 1/2 (y = 1/2) at the Gauss point q of the edge
+                const double dr = (X[4] + Y[q]) + e, dl = (X[3] + Y[q]) - e, dt = (X[q] + Y[4]) + e, db = (X[q] + Y[3]) - e;
+                dmin = fmin(dmin, fmin(fmin(dr, dl), fmin(dt, db)));
+                dmax = fmax(dmax, fmax(fmax(dr, dl), fmax(dt, db)));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                double d = 0.;
+#pragma unroll
+                for (int k = 1; k < NC; ++k)
+                    FMA_TAB(d, t_psi<ORDER>(q, k), c[k]);
+                dmin = fmin(dmin, d), dmax = fmax(dmax, d);
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                double dr = 0., dl = 0., dt = 0., db = 0.;
+#pragma unroll
+                for (int k = 1; k < NC; ++k) {
+                    FMA_TAB(dr, t_r<ORDER>(g, k), c[k]);
+                    FMA_TAB(dl, t_l<ORDER>(g, k), c[k]);
+                    FMA_TAB(dt, t_t<ORDER>(g, k), c[k]);
+                    FMA_TAB(db, t_b<ORDER>(g, k), c[k]);
+                }
+                dmin = fmin(dmin, fmin(fmin(dr, dl), fmin(dt, db)));
+                dmax = fmax(dmax, fmax(fmax(dr, dl), fmax(dt, db)));
+            }
+        }
+        const double mean = c[0];
+        if (mean + dmin < lo || mean + dmax > hi) {
+            double theta = 1.;
+            if (mean + dmin < lo)
+                theta = fmin(theta, mean > lo ? (mean - lo) / -dmin : 0.);
+            if (mean + dmax > hi)
+                theta = fmin(theta, mean < hi ? (hi - mean) / dmax : 0.);
+#pragma unroll
+            for (int k = 1; k < NC; ++k)
+                c[k] *= theta;
+        }
+    }
 }
 
 // edge-normal velocities of one element at the NG edge Gauss points
@@ -557,14 +639,22 @@ __global__ __launch_bounds__(64 * NSDG_MARCH_WG_WAVES) void transport_march_kern
                 if (a >= max(y0 - (S - 1), 0) && a <= min(y1 - 1 + (S - 1), ny - 1)) { // wave-uniform
                     double rhs[NC];
                     march_rhs<ORDER>(PH[NR0 - 3], PH[NR0 - 2], PH[NR0 - 1], VR[0], ebn, hasL, hasR, a > 0, a + 1 < ny, ihx, ihy, rhs);
+                    if (S == 1) {
+                        double o[NC];
 #pragma unroll
-                    for (int i = 0; i < NC; ++i) {
-                        const double t1 = rk_update(0., 1., dt, IMASS[i], 0., PH[NR0 - 2][i], rhs[i]);
-                        if (S == 1) {
-                            if (own)
-                                out[i * N + (long)a * nx + x] = t1;
-                        } else
-                            T1[2][i] = t1;
+                        for (int i = 0; i < NC; ++i)
+                            o[i] = rk_update(0., 1., dt, IMASS[i], 0., PH[NR0 - 2][i], rhs[i]);
+                        if (fp.limit) // wave-uniform
+                            limit_cell<ORDER>(o, fp.lo[f], fp.hi[f], fp.cap[f] != 0);
+                        if (own) {
+#pragma unroll
+                            for (int i = 0; i < NC; ++i)
+                                out[i * N + (long)a * nx + x] = o[i];
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NC; ++i)
+                            T1[2][i] = rk_update(0., 1., dt, IMASS[i], 0., PH[NR0 - 2][i], rhs[i]);
                     }
                 }
             }
@@ -574,10 +664,16 @@ __global__ __launch_bounds__(64 * NSDG_MARCH_WG_WAVES) void transport_march_kern
                 if (a >= y0 && a <= y1 - 1) {
                     double rhs[NC];
                     march_rhs<ORDER>(T1[0], T1[1], T1[2], VR[S - 1], VR[S - 2].eb, hasL, hasR, a > 0, a + 1 < ny, ihx, ihy, rhs);
+                    double o[NC];
+#pragma unroll
+                    for (int i = 0; i < NC; ++i)
+                        o[i] = rk_update(0.5, 0.5, dt, IMASS[i], PH[NR0 - 3][i], T1[1][i], rhs[i]);
+                    if (fp.limit) // wave-uniform
+                        limit_cell<ORDER>(o, fp.lo[f], fp.hi[f], fp.cap[f] != 0);
                     if (own) {
 #pragma unroll
                         for (int i = 0; i < NC; ++i)
-                            out[i * N + (long)a * nx + x] = rk_update(0.5, 0.5, dt, IMASS[i], PH[NR0 - 3][i], T1[1][i], rhs[i]);
+                            out[i * N + (long)a * nx + x] = o[i];
                     }
                 }
             }
@@ -598,10 +694,16 @@ __global__ __launch_bounds__(64 * NSDG_MARCH_WG_WAVES) void transport_march_kern
                     if (a >= y0 && a <= y1 - 1) {
                         double rhs[NC];
                         march_rhs<ORDER>(T2[0], T2[1], T2[2], VR[S - 1], VR[S - 2].eb, hasL, hasR, a > 0, a + 1 < ny, ihx, ihy, rhs);
+                        double o[NC];
+#pragma unroll
+                        for (int i = 0; i < NC; ++i)
+                            o[i] = rk_update(1. / 3., 2. / 3., dt, IMASS[i], PH[0][i], T2[1][i], rhs[i]);
+                        if (fp.limit) // wave-uniform
+                            limit_cell<ORDER>(o, fp.lo[f], fp.hi[f], fp.cap[f] != 0);
                         if (own) {
 #pragma unroll
                             for (int i = 0; i < NC; ++i)
-                                out[i * N + (long)a * nx + x] = rk_update(1. / 3., 2. / 3., dt, IMASS[i], PH[0][i], T2[1][i], rhs[i]);
+                                out[i * N + (long)a * nx + x] = o[i];
                         }
                     }
                 }
@@ -624,6 +726,31 @@ __global__ __launch_bounds__(64 * NSDG_MARCH_WG_WAVES) void transport_march_kern
             if (r + i <= r1)
                 step(r + i, Q[i]);
         }
+    }
+}
+
+// the closure as a pass of its own, in place on the rows [j0, j1): for callers that compose a step from stage launches (the staged
+// nsdg_transport_step, a row block whose ghost zones are too shallow for the march).  One lane per element; 2 x NC x 8 bytes per
+// element and field against the march's none
+template <int ORDER>
+__global__ __launch_bounds__(256) void transport_limit_kernel(int nx, int ny, int j0, int j1, int nfields, FieldPtrs fp)
+{
+    constexpr int NC = DG<ORDER>::NC;
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy = j0 + blockIdx.y * 4 + threadIdx.y;
+    if (ix >= nx || iy >= j1)
+        return;
+    const long N = (long)nx * ny, e = (long)iy * nx + ix;
+    for (int f = 0; f < nfields; ++f) {
+        double* __restrict__ phi = fp.out[f];
+        double c[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            c[k] = phi[k * N + e];
+        limit_cell<ORDER>(c, fp.lo[f], fp.hi[f], fp.cap[f] != 0);
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            phi[k * N + e] = c[k];
     }
 }
 
@@ -750,9 +877,69 @@ int stage_dispatch(nsdg_ctx* ctx, int order, int j0, int j1, double dt, double a
     }
 }
 
+// the context's bounds for the nfields fields of a full step (nsdg_transport_bounds_set); false: the field counts disagree
+bool bounds_into(const nsdg_ctx* ctx, int nfields, FieldPtrs& fp)
+{
+    fp.limit = ctx->nbounds > 0;
+    for (int f = 0; f < MAXF; ++f) {
+        const int s = (fp.limit && f < ctx->nbounds) ? f : 0;
+        fp.lo[f] = fp.limit ? ctx->bounds[s].lo : 0.;
+        fp.hi[f] = fp.limit ? ctx->bounds[s].hi : 0.;
+        fp.cap[f] = fp.limit ? ctx->bounds[s].cap_mean : 0;
+    }
+    return !fp.limit || ctx->nbounds == nfields;
+}
+#define NSDG_BOUNDS_MISMATCH "nsdg_transport_bounds_set was given a different number of fields than this call advances"
+
 } // namespace
 
 extern "C" {
+
+int nsdg_transport_bounds_set(nsdg_ctx* ctx, int32_t nfields, const nsdg_field_bounds* b)
+{
+    NSDG_CHECK_ARG(ctx != nullptr, "null context");
+    NSDG_CHECK_ARG(nfields >= 0 && nfields <= MAXF, "nfields must be 0 (no closure) .. 4");
+    NSDG_CHECK_ARG(nfields == 0 || b != nullptr, "null bounds");
+    for (int f = 0; f < nfields; ++f) {
+        NSDG_CHECK_ARG(b[f].lo <= b[f].hi, "bounds need lo <= hi (hi = +infinity: no upper bound)"); // false for a NaN
+        NSDG_CHECK_ARG(!b[f].cap_mean || b[f].hi < HUGE_VAL, "a capped cell mean needs a finite upper bound");
+    }
+    ctx->nbounds = nfields;
+    for (int f = 0; f < nfields; ++f)
+        ctx->bounds[f] = b[f];
+    return NSDG_OK;
+}
+
+int nsdg_transport_limit(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, int32_t nfields, double* const* phi)
+{
+    NSDG_NEED_GRID(ctx);
+    NSDG_CHECK_ARG(order >= 0 && order <= 2, "order must be 0, 1 or 2");
+    NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
+    NSDG_CHECK_ARG(nfields >= 1 && nfields <= MAXF && phi, "nfields must be 1..4");
+    if (ctx->nbounds == 0) {
+        nsdg_set_error("nsdg_transport_limit: no bounds set (nsdg_transport_bounds_set)");
+        return NSDG_ERR_STATE;
+    }
+    FieldPtrs fp;
+    NSDG_CHECK_ARG(bounds_into(ctx, nfields, fp), NSDG_BOUNDS_MISMATCH);
+    for (int f = 0; f < MAXF; ++f) {
+        const int s = f < nfields ? f : 0;
+        NSDG_CHECK_ARG(phi[s] != nullptr, "null field pointer");
+        fp.phi0[f] = fp.phis[f] = fp.out[f] = phi[s];
+    }
+    if (j0 == j1)
+        return NSDG_OK;
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    const dim3 block(64, 4), grid(nsdg_div_up(ctx->nx, 64), nsdg_div_up(j1 - j0, 4));
+    if (order == 0)
+        hipLaunchKernelGGL(transport_limit_kernel<0>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, nfields, fp);
+    else if (order == 1)
+        hipLaunchKernelGGL(transport_limit_kernel<1>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, nfields, fp);
+    else
+        hipLaunchKernelGGL(transport_limit_kernel<2>, grid, block, 0, ctx->stream, ctx->nx, ctx->ny, j0, j1, nfields, fp);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
 
 int nsdg_transport_variant_set(nsdg_ctx* ctx, int32_t variant, int32_t strip_rows)
 {
@@ -802,7 +989,9 @@ int nsdg_transport_stage(nsdg_ctx* ctx, int32_t order, int32_t j0, int32_t j1, d
         fp.phi0[f] = phi0[s];
         fp.phis[f] = phis[s];
         fp.out[f] = out[s];
+        fp.lo[f] = fp.hi[f] = 0., fp.cap[f] = 0;
     }
+    fp.limit = 0; // a bare stage: the closure belongs to the END of a step (nsdg_transport_limit, or the step entry points)
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     return stage_dispatch(ctx, order, j0, j1, dt, a, b, nfields, fp, vx_dg, vy_dg, un_x, un_y);
 }
@@ -847,6 +1036,8 @@ int nsdg_transport_step(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields
         for (int f = 0; f < nfields; ++f) ps[f] = t2[f];
         if ((rc = nsdg_transport_stage(ctx, order, 0, ny, dt, 1. / 3., 2. / 3., nfields, p0, ps, ph, vx_dg, vy_dg, un_x, un_y))) return rc;
     }
+    if (ctx->nbounds > 0) // the closure of the step (nsdg_transport_bounds_set): one more pass over the new state
+        return nsdg_transport_limit(ctx, order, 0, ny, nfields, phi);
     return NSDG_OK;
 }
 
@@ -878,6 +1069,7 @@ int nsdg_transport_step_oop_rows(nsdg_ctx* ctx, int32_t order, int32_t j0, int32
                 NSDG_CHECK_ARG(!overlap(phi_out[i], phi_out[j]), "two phi_out arrays alias or overlap");
         }
     }
+    NSDG_CHECK_ARG(bounds_into(ctx, nfields, fp), NSDG_BOUNDS_MISMATCH); // the closure runs in the epilogue of the march
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));

@@ -86,6 +86,8 @@ private:
     double L = 512e3, alpha = 0, beta = 0;
     int nsub = 120, rowBlocks = 1, passesPerExchange = 3, loopbackWorld = 0;
     bool thermo = false, overlap = true, graph = false, m_inited = false;
+    bool closure = true; // ridging cap + scaling limiter in the transport, free drift at ice-free nodes (dynamics.closure)
+    double minConc = 1e-12, minThick = 0.01; // ice-free-node rule (dynamics.min_conc / min_thick; the column model's cut-off values)
     std::string forcing = "host", devices;
     int m_world = 1, m_rank = 0; // multi-process run (one block per process)
     long m_steps = 0;

@@ -90,7 +90,8 @@ template <>
 const std::map<int, std::string> Configured<DynamicsStep>::keyMap = { { 0, "dynamics.domain_size" }, { 1, "dynamics.nsub" },
     { 2, "dynamics.alpha" }, { 3, "dynamics.beta" }, { 4, "dynamics.thermodynamics" }, { 5, "dynamics.row_blocks" },
     { 6, "dynamics.passes_per_exchange" }, { 7, "dynamics.overlap" }, { 8, "dynamics.graph" }, { 9, "dynamics.forcing" },
-    { 10, "dynamics.devices" }, { 11, "dynamics.loopback_world" } };
+    { 10, "dynamics.devices" }, { 11, "dynamics.loopback_world" }, { 12, "dynamics.closure" }, { 13, "dynamics.min_conc" },
+    { 14, "dynamics.min_thick" } };
 
 DynamicsStep::DynamicsStep() = default;
 DynamicsStep::~DynamicsStep() { release(); }
@@ -125,6 +126,12 @@ void DynamicsStep::configure()
     forcing = getConfiguration(keyMap.at(9), std::string("host"));
     devices = getConfiguration(keyMap.at(10), std::string(""));
     loopbackWorld = getConfiguration(keyMap.at(11), 0);
+    // the closure that keeps the dynamics inside the physical range (include/nsdg.h "INPUT DOMAIN AND CLOSURE"): ridging cap and
+    // scaling limiter at the end of a transport step, free drift at ice-free nodes with the column model's cut-off values
+    // (nextsim_thermo.min_conc / min_thick, physics/src/modules/NextsimPhysics.cpp:81-82); closure = false: the bare scheme
+    closure = getConfiguration(keyMap.at(12), true);
+    minConc = getConfiguration(keyMap.at(13), 1e-12);
+    minThick = getConfiguration(keyMap.at(14), 0.01);
     if (rowBlocks < 1 || passesPerExchange < 1 || nsub < 0)
         throw std::invalid_argument("dynamics.row_blocks and dynamics.passes_per_exchange must be >= 1, dynamics.nsub >= 0");
     if (forcing != "host" && forcing != "dummy" && forcing != "winter")
@@ -325,6 +332,9 @@ void DynamicsStep::start(const Iterator::TimePoint& startTime)
         t.phi[0] = b.d[H0], t.phi[1] = b.d[A0], t.t1[0] = b.d[H1], t.t1[1] = b.d[A1], t.t2[0] = b.d[T2H], t.t2[1] = b.d[T2A];
         t.vx_dg = b.d[VXDG], t.vy_dg = b.d[VYDG], t.un_x = b.d[UNX], t.un_y = b.d[UNY];
         check(nsdg_rb_transport_create(b.ctx, &t, &b.transport), "nsdg_rb_transport_create");
+        // bounds of the two advected fields: mean thickness H >= 0; concentration in [0, 1] with the cell mean capped at 1
+        const nsdg_field_bounds bounds[2] = { { 0., HUGE_VAL, 0, 0 }, { 0., 1., 1, 0 } };
+        check(nsdg_transport_bounds_set(b.ctx, closure ? 2 : 0, bounds), "nsdg_transport_bounds_set");
         b.par = b.tpar = 0;
     });
 }
@@ -340,6 +350,8 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
     const double a = alpha > 0 ? alpha : stableAlpha(std::min(L / nxf, L / nyf), dt);
     p.alpha = a;
     p.beta = beta > 0 ? beta : a;
+    p.min_conc = closure ? minConc : 0.;
+    p.min_thick = closure ? minThick : 0.;
     const double t = m_time;
     const int kind = forcing == "winter" ? NSDG_FORCING_WINTER : NSDG_FORCING_DUMMY;
     forEachBlock([&](DynamicsBlock& b) {

@@ -262,10 +262,17 @@ class DynamicsCore:
     one SSP-RK3 DG2 transport step of H and A (element halo after each stage)."""
 
     ORDER = 2
+    # closure of the transported fields (include/nsdg.h "INPUT DOMAIN AND CLOSURE"): mean thickness H >= 0; concentration
+    # 0 <= A <= 1 at the quadrature points with the cell mean capped at 1 (ridging) -- (lo, hi, cap_mean) per field
+    BOUNDS = ((0.0, float("inf"), False), (0.0, 1.0, True))
 
-    def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None, overlap=True, native=False, use_graph=False):
+    def __init__(self, ops, blk, hx, hy, dt, nsub, device, exchanger=None, overlap=True, native=False, use_graph=False, closure=True):
         self.ops, self.blk, self.hx, self.hy, self.dt, self.nsub = ops, blk, hx, hy, dt, nsub
         self.overlap = overlap
+        # closure: cap + scaling limiter at the end of every transport step (the ice-free-node rule is a parameter of the
+        # sub-cycle, on by default).  False: the bare scheme of rounds 1-4 (frozen fixtures of that scheme)
+        self.closure = closure
+        ops.set_transport_bounds(self.BOUNDS if closure else ())
         # native: the sub-cycle and the transport of a step are ONE C call each (csrc/rowblock.hip runs the same
         # sequence of passes and exchanges as subcycle() / transport() below); needs the C-ABI ops and, with
         # neighbours, a NativeHaloExchanger (it owns the communicator).  use_graph: replay the launches between
@@ -518,6 +525,8 @@ class DynamicsCore:
         if not deep:
             self.halo.element(self.t2)
         ops.transport_stage(self.ORDER, b.j0, b.j1, self.dt, 1.0 / 3.0, 2.0 / 3.0, f, self.t2, self.t1, self.adv)
+        if self.closure:  # the step entry points of the library do this themselves; a step composed of stages calls it
+            ops.transport_limit(self.ORDER, b.j0, b.j1, self.t1)
         self.halo.element(self.t1)
         # the new state is t1 (ghost rows refreshed); swap buffers instead of copying
         self.H, self.t1[0] = self.t1[0], self.H

@@ -182,6 +182,9 @@ void oracle_mevp_default_params(oracle_mevp_params* p)
     p->alpha = 1500.;
     p->beta = 1500.;
     p->h_min = 1e-4;
+    /* the column model's own cut-off values (nextsim_thermo.min_conc / min_thick, physics/src/modules/NextsimPhysics.cpp:81-82) */
+    p->min_conc = 1e-12;
+    p->min_thick = 0.01;
 }
 
 int oracle_dg_ncoef(int order) { return order == 0 ? 1 : (order == 1 ? 3 : 6); }
@@ -334,6 +337,44 @@ void oracle_transport_step(int nx, int ny, double hx, double hy, int order, doub
         oracle_transport_stage(nx, ny, 0, ny, hx, hy, order, dt, 1. / 3., 2. / 3., phi, t2, t1, vx_dg, vy_dg, un_x, un_y);
         memcpy(phi, t1, M * sizeof(double));
     }
+}
+
+/* ------------------------------------------------------------------ closure of the transport: cap + scaling limiter */
+void oracle_transport_limit(int nx, int ny, int j0, int j1, int order, double* phi, double lo, double hi, int cap)
+{
+    const int nc = oracle_dg_ncoef(order), ng = order + 1;
+    const long N = (long)nx * ny;
+    double gp[4], gw[4];
+    gauss(ng, gp, gw);
+    for (int iy = j0; iy < j1; ++iy)
+        for (int ix = 0; ix < nx; ++ix) {
+            const long e = (long)iy * nx + ix;
+            if (cap && phi[e] > hi)
+                phi[e] = hi;
+            if (order == 0)
+                continue;
+            const double mean = phi[e];
+            double mn = INFINITY, mx = -INFINITY;
+            for (int qy = 0; qy < ng; ++qy)
+                for (int qx = 0; qx < ng; ++qx) {
+                    const double v = dg_eval(phi, N, e, nc, gp[qx], gp[qy]);
+                    mn = fmin(mn, v), mx = fmax(mx, v);
+                }
+            for (int g = 0; g < ng; ++g) {
+                const double v[4] = { dg_eval(phi, N, e, nc, 0.5, gp[g]), dg_eval(phi, N, e, nc, -0.5, gp[g]),
+                    dg_eval(phi, N, e, nc, gp[g], 0.5), dg_eval(phi, N, e, nc, gp[g], -0.5) };
+                for (int k = 0; k < 4; ++k)
+                    mn = fmin(mn, v[k]), mx = fmax(mx, v[k]);
+            }
+            double theta = 1.;
+            if (mn < lo)
+                theta = fmin(theta, mean > lo ? (mean - lo) / (mean - mn) : 0.);
+            if (mx > hi)
+                theta = fmin(theta, mean < hi ? (hi - mean) / (mx - mean) : 0.);
+            if (theta < 1.)
+                for (int c = 1; c < nc; ++c)
+                    phi[c * N + e] *= theta;
+        }
 }
 
 /* ------------------------------------------------------------------ DG -> CG2 nodal average */
@@ -495,13 +536,17 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
             const double du = uo[n] - uu, dv = vo[n] - vv;
             const double absocn = sqrt(du * du + dv * dv);
             const double h = fmax(cgh[n], p->h_min);
-            const double a_ = fmin(fmax(cga[n], 0.), 1.);
+            /* ice-free-node rule (dyn_oracle.h): free drift at full exposure, the neighbours' stress divergence weighted by 2^-100 */
+            const int rule = p->min_conc > 0. || p->min_thick > 0.;
+            const int ice_free = rule && (cga[n] < p->min_conc || cgh[n] < p->min_thick * cga[n]);
+            const double a_ = ice_free ? 1. : fmin(fmax(cga[n], 0.), 1.);
+            const double wdiv = ice_free ? 0x1p-100 : 1.;
             const double mdt = p->rho_ice * h / dt;
             const double cdrag = a_ * f_ocean * absocn;
             const double denom = 1. / (mdt * (1. + p->beta) + cdrag);
             const double cor = p->rho_ice * h * p->fc;
-            u_new[n] = denom * (mdt * (p->beta * uu + u0[n]) + a_ * tax[n] + cdrag * uo[n] + cor * (vv - vo[n]) + divx / lumped);
-            v_new[n] = denom * (mdt * (p->beta * vv + v0[n]) + a_ * tay[n] + cdrag * vo[n] - cor * (uu - uo[n]) + divy / lumped);
+            u_new[n] = denom * (mdt * (p->beta * uu + u0[n]) + a_ * tax[n] + cdrag * uo[n] + cor * (vv - vo[n]) + wdiv * (divx / lumped));
+            v_new[n] = denom * (mdt * (p->beta * vv + v0[n]) + a_ * tay[n] + cdrag * vo[n] - cor * (uu - uo[n]) + wdiv * (divy / lumped));
         }
     if (j1 == ny) /* the right column and the top row are boundary nodes: keep them at zero */
         for (int gx = 0; gx < nn; ++gx) {

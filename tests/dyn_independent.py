@@ -14,6 +14,10 @@ different routes wherever the mathematics allows one:
   * the viscous-plastic law is written with zeta, eta and the ellipse ratio e (sigma = 2 eta eps + (zeta - eta) tr(eps) I
     - P/2 I), not with the 5/8, 3/8, 1/4 the kernels use;
   * L2 projections solve with the FULL mass matrix from a 6-point quadrature (orthogonality of the basis is not assumed);
+  * the ice-free-node rule (round 5) is decided on the TRUE thickness cgH / cgA where the kernels compare cgH with min_thick cgA, and
+    the free-drift node simply has no stress-divergence term (the kernels weight it by 2^-100); the scaling limiter finds its
+    theta as the minimum of the admissible scalings of every quadrature point, each from its own value (the kernels take the
+    extrema first);
   * the nodal divergence is the weak form -(sigma, grad phi_n) integrated over each adjacent element with a 5-point rule,
     the lumped mass the integral of phi_n; the volume term of the transport is integrated with a 5-point rule as well
     (the scheme's 3-point rule is exact for it); only where the scheme's quadrature IS the definition -- the Gauss points
@@ -187,13 +191,51 @@ def mevp_velocity(par, hx, hy, dt, S, u, v, u0, v0, tax, tay, uo, vo, cgh, cga):
         for gx in range(1, nn - 1):
             m = par["rho_ice"] * max(cgh[gy, gx], par["h_min"])
             a = min(max(cga[gy, gx], 0.0), 1.0)
+            fx, fy = divx[gy, gx] / lump[gy, gx], divy[gy, gx] / lump[gy, gx]
+            if ice_free(par, cgh[gy, gx], cga[gy, gx]):  # free drift: full exposure, no stress from the neighbours
+                a, fx, fy = 1.0, 0.0, 0.0
             c = a * par["c_ocean"] * par["rho_ocean"] * np.hypot(uo[gy, gx] - u[gy, gx], vo[gy, gx] - v[gy, gx])
             den = (m / dt) * (1.0 + par["beta"]) + c
             un[gy, gx] = ((m / dt) * (par["beta"] * u[gy, gx] + u0[gy, gx]) + a * tax[gy, gx] + c * uo[gy, gx]
-                          + m * par["fc"] * (v[gy, gx] - vo[gy, gx]) + divx[gy, gx] / lump[gy, gx]) / den
+                          + m * par["fc"] * (v[gy, gx] - vo[gy, gx]) + fx) / den
             vn[gy, gx] = ((m / dt) * (par["beta"] * v[gy, gx] + v0[gy, gx]) + a * tay[gy, gx] + c * vo[gy, gx]
-                          - m * par["fc"] * (u[gy, gx] - uo[gy, gx]) + divy[gy, gx] / lump[gy, gx]) / den
+                          - m * par["fc"] * (u[gy, gx] - uo[gy, gx]) + fy) / den
     return un, vn
+
+
+def ice_free(par, h_node, a_node):
+    """no ice to speak of at this node -- concentration below min_conc, or a true thickness (mean thickness
+    over concentration) below min_thick; the shape of the column model's cut-off"""
+    if par.get("min_conc", 0.0) <= 0.0 and par.get("min_thick", 0.0) <= 0.0:
+        return False
+    if a_node < par["min_conc"]:
+        return True
+    return h_node / a_node < par["min_thick"]  # a_node >= min_conc > 0 here (min_conc = 0: a_node >= 0, 0 / 0 and x / 0 compare False / as inf)
+
+
+# ------------------------------------------------------------------------------------------------ closure of the transport
+def limit(F, lo, hi, cap):
+    """DESIGN.md section 3.3 on a DG2 field [6, ny, nx], returns a new array: cell means above hi are set to hi (cap), then the
+    higher coefficients are scaled by the largest theta <= 1 that keeps the values at the 9 volume and 12 edge Gauss points in [lo, hi]"""
+    _, ny, nx = F.shape
+    g, _ = gauss_unit(3)
+    pts = [(x, y) for y in g for x in g] + [(0.5, s) for s in g] + [(-0.5, s) for s in g] + [(s, 0.5) for s in g] + [(s, -0.5) for s in g]
+    out = F.copy()
+    for iy in range(ny):
+        for ix in range(nx):
+            c = out[:, iy, ix]
+            if cap and c[0] > hi:
+                c[0] = hi
+            mean = c[0]
+            theta = 1.0
+            for (x, y) in pts:
+                dev = dg_value(c, x, y) - mean  # what theta scales
+                if mean + dev < lo:
+                    theta = min(theta, (mean - lo) / -dev if mean > lo else 0.0)
+                if mean + dev > hi:
+                    theta = min(theta, (hi - mean) / dev if mean < hi else 0.0)
+            c[1:] *= theta
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ DG2 transport
@@ -266,13 +308,14 @@ def transport_stage(hx, hy, dt, a, b, phi0, phis, adv):
 
 # ------------------------------------------------------------------------------------------------ the fixture's case
 PARAMS = dict(rho_ice=900.0, rho_atm=1.3, rho_ocean=1026.0, c_atm=1.2e-3, c_ocean=5.5e-3, pstar=27.5e3, compaction=20.0,
-              delta_min=2e-9, fc=1.46e-4, alpha=300.0, beta=300.0, h_min=1e-4)
+              delta_min=2e-9, fc=1.46e-4, alpha=300.0, beta=300.0, h_min=1e-4, min_conc=1e-12, min_thick=0.01)
 CASE = dict(nx=6, ny=5, hx=700.0, hy=900.0, dt=120.0, seed=20261004, rk_a=0.75, rk_b=0.25)
 
 
 def case_inputs():
     """seeded random fields on the 6 x 5 grid: every term of the scheme is exercised (A above 1 and H below 0 at some
-    Gauss points for the clamps, a node with a thickness below h_min, hx != hy, non-zero Coriolis, ocean and wind)"""
+    Gauss points for the clamps and the limiter, cell means of A above 1 for the cap, a node with a thickness below h_min and
+    ice-free nodes around two thin elements, hx != hy, non-zero Coriolis, ocean and wind)"""
     c = CASE
     nx, ny = c["nx"], c["ny"]
     rng = np.random.default_rng(c["seed"])
@@ -318,4 +361,7 @@ def case_outputs(inp=None):
     adv = advection_velocity(inp["u"], inp["v"], c["nx"], c["ny"])
     out["vx_dg"], out["vy_dg"], out["un_x"], out["un_y"] = adv
     out["phi_stage"] = transport_stage(c["hx"], c["hy"], c["dt"], c["rk_a"], c["rk_b"], inp["phi0"], inp["phi"], adv)
+    # the closure of the transport on the case's thickness (bounded below) and concentration (both bounds, capped mean)
+    out["H_limited"] = limit(inp["H"], 0.0, np.inf, False)
+    out["A_limited"] = limit(inp["A"], 0.0, 1.0, True)
     return out

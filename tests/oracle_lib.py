@@ -25,7 +25,7 @@ class ColumnParams(C.Structure):
 class MevpParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "rho_ice", "rho_atm", "rho_ocean", "c_atm", "c_ocean", "pstar", "compaction", "delta_min", "fc",
-        "alpha", "beta", "h_min")]
+        "alpha", "beta", "h_min", "min_conc", "min_thick")]
 
 
 ALBEDO = {"smu": 0, "smu2": 1, "ccsm": 2}
@@ -70,6 +70,7 @@ def lib(omp=False):
     L.oracle_prepare_advection.argtypes = [C.c_int] * 3 + [c_double_p] * 6
     L.oracle_transport_stage.argtypes = [C.c_int] * 4 + [C.c_double] * 2 + [C.c_int] + [C.c_double] * 3 + [c_double_p] * 7
     L.oracle_transport_step.argtypes = [C.c_int] * 2 + [C.c_double] * 2 + [C.c_int, C.c_double] + [c_double_p] * 6
+    L.oracle_transport_limit.argtypes = [C.c_int] * 5 + [c_double_p] + [C.c_double] * 2 + [C.c_int]
     L.oracle_dg_to_cg.argtypes = [C.c_int] * 3 + [c_double_p] * 2
     L.oracle_ice_strength.argtypes = [C.c_int] * 4 + [C.POINTER(MevpParams)] + [c_double_p] * 3
     L.oracle_mevp_stress.argtypes = [C.c_int] * 4 + [C.c_double] * 2 + [C.POINTER(MevpParams)] + [c_double_p] * 6
@@ -137,6 +138,11 @@ def transport_step(nx, ny, hx, hy, order, dt, phi, adv, omp=False):
     vx, vy, unx, uny = adv
     scratch = np.zeros(2 * phi.size)
     lib(omp).oracle_transport_step(nx, ny, hx, hy, order, dt, dp(phi), dp(vx), dp(vy), dp(unx), dp(uny), dp(scratch))
+
+
+def transport_limit(nx, ny, order, phi, lo, hi, cap, j0=0, j1=None):
+    """closure of the transport on rows [j0, j1), in place: cell-mean cap (cap) + scaling limiter to [lo, hi]"""
+    lib().oracle_transport_limit(nx, ny, j0, ny if j1 is None else j1, order, dp(phi), float(lo), float(hi), int(bool(cap)))
 
 
 def dg_to_cg(nx, ny, f_dg):

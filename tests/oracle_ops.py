@@ -130,6 +130,14 @@ class OracleOps:
         for dst, src in zip((vx, vy, unx, uny), res):
             _np(dst)[:] = src
 
+    def set_transport_bounds(self, bounds):
+        self.transport_bounds = tuple(bounds or ())
+
+    def transport_limit(self, order, j0, j1, fields):
+        assert len(fields) == len(self.transport_bounds)
+        for f, (lo, hi, cap) in zip(fields, self.transport_bounds):
+            O.transport_limit(self.nx, self.ny, order, _np(f), lo, hi, cap, j0, j1)
+
     def transport_stage(self, order, j0, j1, dt, a, b, phi0, phis, out, adv):
         advn = tuple(_np(x) for x in adv)
         for p0, ps, o in zip(phi0, phis, out):

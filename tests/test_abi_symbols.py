@@ -42,7 +42,7 @@ def test_header_is_plain_c():
 
 
 def test_abi_version_and_default_params(lib):
-    assert lib.nsdg_abi_version() == 4  # 2: nsdg_comm_* / nsdg_halo_* (row-block ghost exchange); 3: bounded waits, exchange statistics, nsdg_copy_f64; 4: nsdg_mevp_iterate4*, nsdg_comm_simulate_wire
+    assert lib.nsdg_abi_version() == 5  # 5: nsdg_transport_bounds_set / nsdg_transport_limit, nsdg_mevp_params.min_conc / min_thick; 2: nsdg_comm_* / nsdg_halo_* (row-block ghost exchange); 3: bounded waits, exchange statistics, nsdg_copy_f64; 4: nsdg_mevp_iterate4*, nsdg_comm_simulate_wire
     p = abi.ColumnParams()
     lib.nsdg_column_default_params(C.byref(p))
     # defaults of the reference: NextsimPhysics.cpp:76-82, ThermoIce0.cpp:30-31, HiblerConcentration.cpp:28-29
@@ -52,6 +52,10 @@ def test_abi_version_and_default_params(lib):
     m = abi.MevpParams()
     lib.nsdg_mevp_default_params(C.byref(m))
     assert (m.alpha, m.beta, m.pstar, m.delta_min) == (1500.0, 1500.0, 27.5e3, 2e-9)
+    # the ice-free-node rule is ON by default, with the column model's cut-off values (physics/src/modules/NextsimPhysics.cpp:81-82)
+    assert (m.h_min, m.min_conc, m.min_thick) == (1e-4, p.min_conc, p.min_thick)
+    # closure entry points without a context: argument errors, never a crash
+    assert lib.nsdg_transport_bounds_set(None, 0, None) == -1 and lib.nsdg_transport_limit(None, 2, 0, 0, 1, None) == -1
 
 
 def test_param_struct_layout_matches_oracle():

@@ -33,9 +33,11 @@ def check_physical(res, mass0, nx, ny):
         assert float(f[0].abs().max()) == 0 and float(f[-1].abs().max()) == 0
         assert float(f[:, 0].abs().max()) == 0 and float(f[:, -1].abs().max()) == 0
     assert 1e-6 < float(u.abs().max()) < 1.0
-    if mass0 is not None:  # transport alone conserves the cell means in the closed box
+    assert float(A[0].max()) <= 1.0  # the ridging cap of the closure (cell means; on by default in the drivers)
+    if mass0 is not None:  # transport alone conserves the cell means in the closed box: the volume (H) exactly; the area (A) up to
+        # what the cap turned into thickness where the cover closed -- a loss, never a gain, and small over a few steps
         assert abs(float(H[0].sum()) - mass0[0]) <= 1e-12 * abs(mass0[0])
-        assert abs(float(A[0].sum()) - mass0[1]) <= 1e-12 * abs(mass0[1])
+        assert -1e-6 * abs(mass0[1]) <= float(A[0].sum()) - mass0[1] <= 1e-12 * abs(mass0[1])
 
 
 def test_config3_1024_transport_and_mevp_120_subiterations(gpu):

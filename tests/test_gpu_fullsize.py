@@ -21,6 +21,14 @@ def ctx(gpu):
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _no_closure_left_on_the_shared_context(ctx):
+    """a DynamicsCore states the closure's bounds (H, A) on its context; tests that call the transport entry points with other field
+    lists on the SAME context must not inherit them"""
+    yield
+    ctx.set_transport_bounds(())
+
+
 def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
@@ -100,11 +108,13 @@ def test_config4_2048_dynamics_step_properties(ctx):
             assert float(f[:, 0].abs().max()) == 0 and float(f[:, -1].abs().max()) == 0
         assert float(core.u.abs().max()) > 1e-6
         assert abs(float(core.H[0].sum()) - mH) <= 1e-12 * abs(mH)
-        assert abs(float(core.A[0].sum()) - mA) <= 1e-12 * abs(mA)
+        # the area is conserved up to what the ridging cap (closure, on by default) turned into thickness: a loss, never a gain
+        assert -1e-6 * abs(mA) <= float(core.A[0].sum()) - mA <= 1e-12 * abs(mA) and float(core.A[0].max()) <= 1.0
         results[variant] = (core.u.clone(), core.v.clone(), core.s[0].clone(), core.H.clone())
         del core
     ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
     ctx.set_mevp_params(ctx.mevp_default_params())
+    ctx.set_transport_bounds(())  # the cores set the closure's bounds on the shared context
     for a, b in zip(results[0], results[1]):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 1e-10 * scale
@@ -181,3 +191,4 @@ def test_config5_coupled_run_stays_physical(ctx):
     assert 0.9 < float(core.A[0].min()) and float(core.A[0].max()) < 1.01  # convergent drift piles concentration up slightly above 1
     assert -40.0 < float(core.col["tice0"].min()) and float(core.col["tice0"].max()) <= 0.0
     ctx.set_mevp_params(ctx.mevp_default_params())
+    ctx.set_transport_bounds(())

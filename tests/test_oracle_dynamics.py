@@ -339,13 +339,13 @@ def test_oracle_agrees_with_the_independent_restatement():
     """tests/dyn_independent.py restates DESIGN.md section 3 a second time, in dense numpy, from the formulas only and by
     different routes (zeta / eta form of the VP law, strain from the derivative of the biquadratic instead of the projected
     coefficients, full-mass-matrix projections, weak divergence by quadrature).  Its outputs on a 6 x 5 case are committed
-    (tests/golden/dyn_independent_v1.npz, tools/gen_dyn_independent.py); the oracle must reproduce every one of them --
-    ice strength, nodal means, wind stress, ONE mEVP sub-iteration (stress and velocity), advection velocity, ONE DG2
-    transport stage -- to 1e-12.  NOT reference parity: the snapshot has no dynamics code (/root/reference/CMakeLists.txt:43-46).
+    (tests/golden/dyn_independent_v2.npz, tools/gen_dyn_independent.py); the oracle must reproduce every one of them --
+    ice strength, nodal means, wind stress, ONE mEVP sub-iteration (stress and velocity, with the ice-free-node rule), advection
+    velocity, ONE DG2 transport stage, the closure of the transport (cap + scaling limiter) on H and A -- to 1e-12.  NOT reference parity: the snapshot has no dynamics code (/root/reference/CMakeLists.txt:43-46).
     A fresh evaluation of the restatement must equal the committed file (the file is not an opaque blob)."""
     import dyn_independent as D
 
-    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v1.npz"))
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v2.npz"))
     inp = D.case_inputs()
     for k, v in inp.items():
         v = np.stack(v) if isinstance(v, list) else v
@@ -370,9 +370,56 @@ def test_oracle_agrees_with_the_independent_restatement():
     out = np.zeros_like(inp["phi"])
     O.transport_stage(nx, ny, 0, ny, c["hx"], c["hy"], 2, c["dt"], c["rk_a"], c["rk_b"], inp["phi0"], inp["phi"], out, adv)
     got["phi_stage"] = out
+    got["H_limited"], got["A_limited"] = inp["H"].copy(), inp["A"].copy()
+    O.transport_limit(nx, ny, 2, got["H_limited"], 0.0, np.inf, False)
+    O.transport_limit(nx, ny, 2, got["A_limited"], 0.0, 1.0, True)
     assert sorted(got) == sorted(fresh)
     for k, v in got.items():
         assert rel(v, fix["out_" + k]) < 1e-12, (k, rel(v, fix["out_" + k]))
     # the case exercises the clamps and the floor: concentration above 1 and thickness below 0 at Gauss points, a node thinner than h_min
     assert float(fix["out_cga"].max()) > 1.0 and float(fix["out_cgh"].min()) < D.PARAMS["h_min"] and float(np.abs(fix["out_u_new"]).max()) > 0.05
     assert float((fix["out_pg"] == 0.0).sum()) > 0  # max(h, 0) was active
+    # ... and the round-5 closure: ice-free nodes exist (and others do not), the cap and both sides of the limiter were active
+    free = np.array([[D.ice_free(D.PARAMS, fix["out_cgh"][gy, gx], fix["out_cga"][gy, gx]) for gx in range(2 * nx + 1)] for gy in range(2 * ny + 1)])
+    assert 0 < int(free[1:-1, 1:-1].sum()) < free[1:-1, 1:-1].size // 2
+    assert int((inp["A"][0] > 1.0).sum()) > 0 and float(fix["out_A_limited"][0].max()) == 1.0
+    assert np.array_equal(fix["out_H_limited"][0], inp["H"][0])  # the limiter never touches a cell mean
+    scaled = lambda a, b: int((np.abs(a[1:] - b[1:]).max(axis=0) > 0).sum())
+    assert scaled(fix["out_H_limited"], inp["H"]) > 0 and scaled(fix["out_A_limited"], inp["A"]) > 0
+    assert scaled(fix["out_H_limited"], inp["H"]) < nx * ny  # ... and most elements were left alone
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_oracle_limiter_properties(order):
+    """oracle_transport_limit: cell means untouched (the cap aside), point values inside the bounds afterwards, elements inside the
+    bounds untouched bit for bit, theta = the LARGEST admissible scaling (the binding point lands on the bound)"""
+    nx, ny = 23, 17
+    nc = O.ncoef(order)
+    rng = np.random.default_rng(order)
+    f = np.zeros((nc, ny, nx))
+    f[0] = 0.5 + 0.3 * rng.standard_normal((ny, nx))
+    f[1:] = 0.2 * rng.standard_normal((nc - 1, ny, nx)) * (rng.random((ny, nx)) < 0.7)
+    g = [-0.5 / np.sqrt(3.0), 0.5 / np.sqrt(3.0)] if order == 1 else [-0.5 * np.sqrt(0.6), 0.0, 0.5 * np.sqrt(0.6)]
+    pts = [(x, y) for y in g for x in g] + [(0.5, s) for s in g] + [(-0.5, s) for s in g] + [(s, 0.5) for s in g] + [(s, -0.5) for s in g]
+    psi = lambda x, y: (1.0, x, y, x * x - 1.0 / 12.0, y * y - 1.0 / 12.0, x * y)[:nc]
+    P = np.array([psi(x, y) for (x, y) in pts])
+    vals = lambda a: np.einsum("pc,cyx->pyx", P, a)
+    out = f.copy()
+    O.transport_limit(nx, ny, order, out, 0.0, 1.0, True)
+    assert np.array_equal(out[0], np.minimum(f[0], 1.0))
+    v0, v1 = vals(f), vals(out)
+    ok = (f[0] >= 0.0)
+    assert v1[:, ok].min() >= -1e-15 and v1.max() <= 1.0 + 1e-15
+    inside = (v0.min(axis=0) >= 0.0) & (v0.max(axis=0) <= 1.0)
+    assert 10 < int(inside.sum()) < nx * ny - 10 and np.array_equal(out[:, inside], f[:, inside])
+    scaled = ~inside & ok & (f[0] < 1.0) & (np.abs(f[1:]).max(axis=0) > 0)
+    touch = np.minimum(np.abs(v1[:, scaled].min(axis=0) - 0.0), np.abs(v1[:, scaled].max(axis=0) - 1.0))
+    assert int(scaled.sum()) > 10 and touch.max() <= 1e-14  # a scaled element touches one of its bounds
+    # no upper bound, no cap: only the lower side acts
+    out2 = f.copy()
+    O.transport_limit(nx, ny, order, out2, 0.0, np.inf, False)
+    assert np.array_equal(out2[0], f[0]) and vals(out2)[:, ok].min() >= -1e-15 and vals(out2).max() > 1.0
+    # a row range
+    out3 = f.copy()
+    O.transport_limit(nx, ny, order, out3, 0.0, 1.0, True, 4, 9)
+    assert np.array_equal(out3[:, 4:9], out[:, 4:9]) and np.array_equal(out3[:, :4], f[:, :4]) and np.array_equal(out3[:, 9:], f[:, 9:])

@@ -26,14 +26,22 @@ from nextsimdg_amd import abi, rowblock, synthetic
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 720
 nx = ny = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 forcing = sys.argv[3] if len(sys.argv) > 3 else "winter"
-L, dt, nsub = 512e3, float(os.environ.get("NSDG_SOAK_DT", "120")), 120  # NSDG_SOAK_DT: model time step (experiments on the strength / concentration coupling)
+L, dt, nsub = 512e3, float(os.environ.get("NSDG_SOAK_DT", "120")), int(os.environ.get("NSDG_SOAK_NSUB", "120"))  # NSDG_SOAK_DT: model time step (experiments on the strength / concentration coupling); NSDG_SOAK_NSUB: sub-iterations per step (how far the sub-cycle is from converged)
+delta_min = float(os.environ.get("NSDG_SOAK_DELTA_MIN", "2e-9"))  # NSDG_SOAK_DELTA_MIN: the regularisation of Delta; alpha = beta follows it (the stability bound goes with 1 / sqrt(Delta_min))
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
-alpha = bt.stable_alpha(dt) * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # NSDG_ALPHA_SCALE: a wider stability margin than the default 2.4 x the bound
-ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+alpha = bt.stable_alpha(dt, delta_min=delta_min) * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # NSDG_ALPHA_SCALE: a wider stability margin than the default 2.4 x the bound
+# NSDG_SOAK_CLOSURE: 1 (default) the closure of the product -- ridging cap + scaling limiter in the transport, free drift at ice-free
+# nodes; 0 the bare scheme of rounds 1-4; "transport" / "nodes": only one of the two halves (which one a run needs)
+mode = os.environ.get("NSDG_SOAK_CLOSURE", "1")
+rule = {} if mode in ("1", "nodes") else dict(min_conc=0.0, min_thick=0.0)
+ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha, delta_min=delta_min, **rule))
+print("nsub %d, alpha = beta = %.0f, Delta_min %.1e: the sub-cycle relaxes %.1f %% of the way per model step" % (nsub, alpha, delta_min, 100.0 * min(1.0, nsub / alpha)), flush=True)
 blk = rowblock.RowBlock(nx, ny, 0, 1)
-core = rowblock.CoupledCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, native=True, forcing=None if forcing == "host" else forcing)
+core = rowblock.CoupledCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, native=True, forcing=None if forcing == "host" else forcing,
+                            closure=mode in ("1", "transport"))
+print("closure: %s (transport cap + limiter %s, ice-free-node rule %s)" % (mode, core.closure, not rule), flush=True)
 cs, cf = synthetic.column_fields_smooth(nx, ny, L)  # initial snow / ice temperature; sst at the freezing point (see the docstring there)
 H, A = bt.dg_fields()
 if os.environ.get("NSDG_SOAK_INIT") == "const":  # the constant initial state of the C++ host's [init] keys (tools/r03_config5_day.sh)
@@ -69,6 +77,7 @@ def dump(step):
     Hw, Aw = core.H[:, y0:y1, x0:x1], core.A[:, y0:y1, x0:x1]
     Hg, Ag = torch.einsum("qc,cyx->qyx", GP, Hw), torch.einsum("qc,cyx->qyx", GP, Aw)
     hnode = core.packed[:2 * (2 * ny + 1) * (2 * nx + 1)].view(2 * ny + 1, 2 * nx + 1, 2)[:, :, 0]  # h' = max(cgH, h_min) of the last packing: first entry of pair plane 0 (csrc/mevp_common.h, NSDG_NODAL_LAYOUT 1)
+    hnode = torch.where(hnode > 1e20, hnode * 2.0 ** -100, hnode)  # ice-free nodes store it scaled by 2^100 (csrc/mevp.hip: pack_node)
     pgw = abi.untile(core.pg, nx)[:, y0:y1, x0:x1]
     # strain rate at the element centres of the window from the nodal velocities (central differences over the element)
     U, V = core.u[2 * y0:2 * y1 + 1, 2 * x0:2 * x1 + 1], core.v[2 * y0:2 * y1 + 1, 2 * x0:2 * x1 + 1]
@@ -157,6 +166,8 @@ for step in range(steps):
                  float(core.A[0].min()), float(core.A[0].max()), float(core.col["tice0"].min()), float(core.col["tice0"].max()),
                  float(core.col["hsnow"].min()), float(core.col["hsnow"].max()), float(core.col["wind"].max()), float(core.col["qsw"].max()),
                  float(core.newice.max())), flush=True)
+        nfree = int((core.packed[:2 * (2 * ny + 1) * (2 * nx + 1)].view(-1, 2)[:, 0] > 1e20).sum())
+        print("           ice-free nodes (free drift) in the last packing: %d of %d" % (nfree, (2 * ny + 1) * (2 * nx + 1)), flush=True)
         tot = {k: float(v) for k, v in made.items()}
         print("           A > 1: excess sum(max(A - 1, 0)) = %.4e; produced so far by the column step (uncapped Hibler freeze) %.4e, by the DG2 "
               "transport (no limiter) %.4e; since the last report %.3e / %.3e; max A right after the column step %.6f, after the transport %.6f"
