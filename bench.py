@@ -214,7 +214,7 @@ def cpu_baseline(nsub_full, nx, ny, budget_s=12.0):
     return res
 
 
-KERNEL_SOURCES = ("mevp_fused4.hip", "mevp_pipeline.h", "mevp_fused3.hip", "mevp_fused2.hip", "mevp_fused.hip", "mevp_common.h", "transport.hip")
+KERNEL_SOURCES = ("mevp_fused4.hip", "mevp_fused4p.hip", "mevp_pipeline.h", "mevp_fused3.hip", "mevp_fused2.hip", "mevp_fused.hip", "mevp_common.h", "transport.hip")
 
 
 def kernel_source_hash():

@@ -1,0 +1,404 @@
+// mevp_fused4p.hip -- variant 4 of the mEVP sub-cycle, round 5: FOUR sub-iterations per kernel pass, one pipeline stage per wave,
+// hand-over POINT TO POINT.
+//
+// The round-4 kernel (mevp_fused4.hip) synchronises its four stage waves with ONE workgroup barrier per march step.  A barrier is
+// a rendez-vous of all four waves, so a link of the pipeline can only be as short as "write, barrier, read": every link was three
+// march steps deep, a strip of R rows took R + 16 steps, a row's ice strength and nodal coefficients were in flight for ten steps
+// -- re-read from the Infinity Cache by each of the stages 1-3 (3.4 of the 6.7 GB a pass moves, -13.5 % without them) -- and the
+// three rotating slots per link filled the LDS (144 of 160 KB).  Here a stage waits for exactly what it needs and nothing else:
+//
+//   * every link has two counters in LDS.  done[k] = the last row stage k has handed over, read[k] = the last row stage k + 1 has
+//     taken.  Stage k + 1 starts row r when done[k] >= r + 1 (it needs the bottom nodes of the row above); stage k writes row r
+//     into slot r % 2 when read[k] >= r - 2.  A link is TWO steps deep -- the minimum the scheme allows: the velocity of the top
+//     node row of element row r is updated by row r + 1 -- a strip takes R + 13 steps (R + 7 rows of stage 0, six steps of lag),
+//     and two slots per link are enough: 96 KB for the three hand-overs.
+//   * the freed LDS holds a RING of the ice strength: the loader (stage 0) reads a row's nine Gauss-point values from memory
+//     once and writes them to the ring, the stages 1-3 take them from there (8 rows x 4.6 KB = 37 KB).  The packed nodal
+//     coefficients (192 B per element) are still re-read by every stage: a ring for them needs another 8 x 12 KB
+//     (profiles/r05_fused4_p2p.md: what fits, what was measured).
+//   * no barrier after the prologue: the waves run as far apart as their dependencies allow, idle steps do not exist.
+//
+// Memory ordering.  All hand-over traffic is LDS traffic of ONE compute unit; the LDS executes the instructions of a wave in order.
+// A producer waits for its own LDS writes (s_waitcnt lgkmcnt(0)) before it raises its counter; a consumer reads the counter,
+// waits for that read, and only then issues its reads of the slot -- the pattern of an LDS-scope release / acquire, written out
+// with compiler barriers around it.  Counters only ever increase.  Every wait is on an event that is strictly earlier in the
+// dependency graph of the march (row r of stage k + 1 waits for row r + 1 of stage k; row r of stage k waits for row r - 2 of stage
+// k + 1, which waited for row r - 1 of stage k), so no wave can wait for ever -- and, should that reasoning ever be wrong, a
+// wait gives up after NSDG_P2P_SPIN_LIMIT polls, raises a sticky flag that releases every other wait of the workgroup, and counts
+// the event in a device counter the tests read (nsdg_debug_p2p_timeouts): a wrong result, never a hung GPU.
+//
+// The arithmetic is the same sequence of inlined functions as in every other variant: bit-identical to four passes of variant 1.
+#include "mevp_pipeline.h"
+
+namespace nsdg_mevp_detail {
+
+__device__ unsigned nsdg_p2p_timeouts_dev = 0;
+
+struct StressPtrsP {
+    const double *i11, *i12, *i22;
+    double *o11, *o12, *o22;
+};
+
+constexpr int P4_OWNED = 57, P4_LEFT = 4; // lanes 4 .. 60 own a column (as in mevp_fused4.hip: four sub-iterations reach four columns / rows)
+constexpr int P4_HAND = 32; // doubles per lane and hand-over slot: 24 stress coefficients + u, v at the 4 owned nodes
+constexpr int P4_SLOT = P4_HAND * 64; // value k of lane l at (k / 2) * 128 + 2 l + k % 2 (16-byte pairs)
+constexpr int P4_HSLOTS = 2; // slots per link
+constexpr int P4_PRING = 8; // rows of ice strength in the ring
+constexpr int P4_PSLOT = 9 * 64; // pairs k < 4 of lane l at k * 128 + 2 l, the ninth value at 512 + l
+constexpr int P4_LDS = 3 * P4_HSLOTS * P4_SLOT + P4_PRING * P4_PSLOT; // doubles: 96 KB + 36 KB
+constexpr int P4_STEPS_EXTRA = 13; // a strip of R rows takes about R + 13 march steps
+#ifndef NSDG_P2P_SPIN_LIMIT
+#define NSDG_P2P_SPIN_LIMIT (1 << 20) // polls of ~0.2 us: a fifth of a second; a legitimate wait is a few march steps (a few microseconds)
+#endif
+
+struct FetchP {
+    double P[9]; // ice strength at the Gauss points of the row the stage works on next
+    double c[4][6]; // packed momentum coefficients of its 4 owned nodes
+    double s11[8], s12[8], s22[8]; // stage 0 only: the stress the pass starts from
+    double ub[3], vb[3], um[3], vm[3], ut[3], vt[3]; // stage 0 only: u, v of the pass's start on the three node rows
+};
+
+struct StageP {
+    int s; // pipeline stage of this wave = sub-iteration p + s
+    int first, last; // element rows this stage works on
+    int last_prev; // last row of the previous stage
+    int last3; // last row of stage 3 (the loader's ring wait)
+    int upd0; // node updates from this row on
+};
+
+// counters: done[k] at k, read[k] at 3 + k, the sticky give-up flag at 6
+struct FlagsP {
+    int v[8];
+};
+
+// the counters are accessed through LDS-typed pointers: a volatile access through a generic pointer would be a FLAT instruction, which
+// counts on vmcnt as well and so waits for every global load in flight
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ int flag_peek(const volatile lds_int* p)
+{
+    asm volatile("" ::: "memory");
+    const int x = *p;
+    asm volatile("" ::: "memory");
+    return __builtin_amdgcn_readfirstlane(x);
+}
+// the counter *p has reached `need` (or the workgroup has given up)
+__device__ __forceinline__ void flag_wait(volatile lds_int* flags, int which, int need)
+{
+    if (flag_peek(flags + which) >= need)
+        return;
+    for (int spin = 0; spin < NSDG_P2P_SPIN_LIMIT; ++spin) {
+        __builtin_amdgcn_s_sleep(1);
+        if (flag_peek(flags + which) >= need || flag_peek(flags + 6) != 0)
+            return;
+    }
+    flags[6] = 1; // give up: release everybody, count the event
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(&nsdg_p2p_timeouts_dev, 1u);
+}
+// everything this wave has written to LDS so far is visible before the counter moves
+__device__ __forceinline__ void flag_publish(volatile lds_int* flags, int which, int value)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    flags[which] = value;
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ double2 lds_pair_p(const double* slot, int k) { return *reinterpret_cast<const double2*>(slot + k * 128); }
+__device__ __forceinline__ void lds_pair_p(double* slot, int k, double a, double b) { *reinterpret_cast<double2*>(slot + k * 128) = make_double2(a, b); }
+
+typedef double nsdg_pair8p __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void fetch_nodes_p(const double* __restrict__ w, long n, double (&o)[3])
+{
+    const nsdg_pair8p a = *reinterpret_cast<const nsdg_pair8p*>(w + n);
+    o[0] = a.x, o[1] = a.y, o[2] = w[n + 2];
+}
+
+__device__ __forceinline__ void request_c_p(const MarchConst3& M, int nrow, double (&c)[4][6], const double* __restrict__ packed)
+{
+    const long nVn = (long)(2 * nrow) * M.nn + 2 * M.ix;
+    load_nodal(packed, M.nplane, nVn, c[0]);
+    load_nodal(packed, M.nplane, nVn + 1, c[1]);
+    load_nodal(packed, M.nplane, nVn + M.nn, c[2]);
+    load_nodal(packed, M.nplane, nVn + M.nn + 1, c[3]);
+}
+// ice strength of a row from / to the ring
+__device__ __forceinline__ void ring_read_P(const double* __restrict__ ring, int row, int lane, double (&P)[9])
+{
+    const double* s = ring + (row & (P4_PRING - 1)) * P4_PSLOT;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double2 t = *reinterpret_cast<const double2*>(s + k * 128 + 2 * lane);
+        P[2 * k] = t.x, P[2 * k + 1] = t.y;
+    }
+    P[8] = s[512 + lane];
+}
+__device__ __forceinline__ void ring_write_P(double* __restrict__ ring, int row, int lane, const double (&P)[9])
+{
+    double* s = ring + (row & (P4_PRING - 1)) * P4_PSLOT;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<double2*>(s + k * 128 + 2 * lane) = make_double2(P[2 * k], P[2 * k + 1]);
+    s[512 + lane] = P[8];
+}
+
+// One row of one stage.  FIRST: the loader (stage 0): inputs from memory, ice strength into the ring.
+template <bool FIRST>
+__device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, int row, FetchP& f, TopCarry3& carry, double* __restrict__ lds,
+    volatile lds_int* flags, const StressPtrsP& S, const double* __restrict__ u_old, const double* __restrict__ v_old,
+    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+{
+    const int stage = FIRST ? 0 : G.s;
+    const int nrow = min(row + 1, G.last); // the row this stage works on next: its inputs are requested during this one
+    const int ix = M.ix, nn = M.nn;
+    double* const ring = lds + 3 * P4_HSLOTS * P4_SLOT;
+    const long nVn = (long)(2 * nrow) * nn + 2 * ix; // vertex node of the next row
+    double s11[8], s12[8], s22[8], uu[4], vv[4], ul[9], vl[9], un[4], vn[4];
+    // ------------------------------------------------------------------------------------------ inputs of the row
+    if (FIRST) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ul[a] = f.ub[a], ul[3 + a] = f.um[a], ul[6 + a] = f.ut[a];
+            vl[a] = f.vb[a], vl[3 + a] = f.vm[a], vl[6 + a] = f.vt[a];
+        }
+        uu[0] = ul[0], uu[1] = ul[1], uu[2] = ul[3], uu[3] = ul[4];
+        vv[0] = vl[0], vv[1] = vl[1], vv[2] = vl[3], vv[3] = vl[4];
+    } else {
+        // the previous stage has handed over this row and the row above it (whose bottom nodes are this row's top nodes)
+        flag_wait(flags, stage - 1, min(row + 1, G.last_prev));
+        if (row == G.first) { // wave-uniform: the first row of the stage has no predecessor that requested its inputs
+            ring_read_P(ring, row, M.lane, f.P);
+            request_c_p(M, row, f.c, packed);
+        }
+        const double* in = lds + ((stage - 1) * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
+        const double* top = lds + ((stage - 1) * P4_HSLOTS + ((row + 1) & 1)) * P4_SLOT + 2 * M.lane;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double2 a = lds_pair_p(in, 12 + k), b = lds_pair_p(in, 14 + k);
+            uu[2 * k] = a.x, uu[2 * k + 1] = a.y, vv[2 * k] = b.x, vv[2 * k + 1] = b.y;
+        }
+        double2 tu = lds_pair_p(top, 12), tv = lds_pair_p(top, 14);
+        if (row + 1 > G.last_prev) // wave-uniform: node row 2*ny is the top boundary
+            tu = tv = make_double2(0., 0.);
+        gather_nodes(M, uu, tu.x, tu.y, ul);
+        gather_nodes(M, vv, tv.x, tv.y, vl);
+    }
+    // ------------------------------------------------------------------------------------------ stress update
+    double r11[8], r12[8], r22[8];
+    stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
+    __builtin_amdgcn_sched_barrier(0);
+    if (FIRST) {
+        // the ice strength of this row goes to the ring for the stages 1-3 (slot of row - 8: stage 3 has passed it), then the
+        // register set takes the next row's; u, v of the next row
+        flag_wait(flags, 3 + 2, min(row - P4_PRING, G.last3));
+        ring_write_P(ring, row, M.lane, f.P);
+        tile_load9(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P);
+        if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                f.ub[a] = f.ut[a], f.vb[a] = f.vt[a];
+        }
+        fetch_nodes_p(u_old, nVn + nn, f.um);
+        fetch_nodes_p(v_old, nVn + nn, f.vm);
+        fetch_nodes_p(u_old, nVn + 2 * nn, f.ut);
+        fetch_nodes_p(v_old, nVn + 2 * nn, f.vt);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            s11[i] = f.s11[i], s12[i] = f.s12[i], s22[i] = f.s22[i];
+    } else {
+        ring_read_P(ring, nrow, M.lane, f.P); // written by the loader before it handed row nrow over: done[stage - 1] >= row + 1 implies done[0] >= nrow
+        const double* in = lds + ((stage - 1) * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double2 a = lds_pair_p(in, k), b = lds_pair_p(in, 4 + k), c = lds_pair_p(in, 8 + k);
+            s11[2 * k] = a.x, s11[2 * k + 1] = a.y, s12[2 * k] = b.x, s12[2 * k + 1] = b.y, s22[2 * k] = c.x, s22[2 * k + 1] = c.y;
+        }
+        // this row's slot (stress, u, v) and the next row's ice strength have been taken: the producer may write row + 2 into the slot
+        flag_publish(flags, 3 + stage - 1, row);
+    }
+    stress_relax(M.ialpha, r11, r12, r22, s11, s12, s22);
+    __builtin_amdgcn_sched_barrier(0);
+    if (FIRST) { // stress of the next row
+        const long ts = tile_off(ix, nrow, M.ntx, 8);
+        tile_load8(S.i11, ts, f.s11);
+        tile_load8(S.i12, ts, f.s12);
+        tile_load8(S.i22, ts, f.s22);
+    }
+    // ------------------------------------------------------------------------------------------ contributions, node updates
+    {
+        double cx[9], cy[9];
+        node_contrib_all(s11, s12, s22, M.hx, M.hy, cx, cy);
+        owned_node_updates(M, row > 0, f.c, uu, vv, carry, cx, cy, un, vn);
+        if (row < G.upd0) { // wave-uniform: the first row of a stage only feeds the carried contributions
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                un[k] = vn[k] = 0.;
+        }
+        carry_top(carry, cx, cy);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    request_c_p(M, nrow, f.c, packed); // nodal coefficients of the next row
+    // ------------------------------------------------------------------------------------------ outputs
+    if (FIRST || stage < 3) {
+        flag_wait(flags, 3 + stage, row - P4_HSLOTS); // the consumer has taken the row this slot held
+        double* out = lds + (stage * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lds_pair_p(out, k, s11[2 * k], s11[2 * k + 1]);
+            lds_pair_p(out, 4 + k, s12[2 * k], s12[2 * k + 1]);
+            lds_pair_p(out, 8 + k, s22[2 * k], s22[2 * k + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            lds_pair_p(out, 12 + k, un[2 * k], un[2 * k + 1]);
+            lds_pair_p(out, 14 + k, vn[2 * k], vn[2 * k + 1]);
+        }
+        flag_publish(flags, stage, row);
+    } else if (M.own && row >= M.y0) { // the last stage runs on rows y0-1 .. y1-1
+        const long ts = tile_off(ix, row, M.ntx, 8);
+        const long nV = (long)(2 * row) * nn + 2 * ix;
+        tile_store8(S.o11, ts, s11);
+        tile_store8(S.o12, ts, s12);
+        tile_store8(S.o22, ts, s22);
+        u_new[nV] = un[0], v_new[nV] = vn[0];
+        u_new[nV + 1] = un[1], v_new[nV + 1] = vn[1];
+        u_new[nV + nn] = un[2], v_new[nV + nn] = vn[2];
+        u_new[nV + nn + 1] = un[3], v_new[nV + nn + 1] = vn[3];
+        if (M.lastcol) {
+            u_new[nV + 2] = 0., v_new[nV + 2] = 0.;
+            u_new[nV + nn + 2] = 0., v_new[nV + nn + 2] = 0.;
+        }
+        if (row == M.ny - 1) {
+            u_new[nV + 2 * nn] = 0., v_new[nV + 2 * nn] = 0.;
+            u_new[nV + 2 * nn + 1] = 0., v_new[nV + 2 * nn + 1] = 0.;
+            if (M.lastcol)
+                u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mevp_fused4p_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw,
+    double hx, double hy, double ialpha, double dmin2, StressPtrsP S, const double* __restrict__ u_old, const double* __restrict__ v_old,
+    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+{
+    __shared__ __attribute__((aligned(16))) double lds[P4_LDS]; // 96 KB of hand-over slots + 36 KB of ice-strength ring
+    __shared__ FlagsP flagmem;
+    volatile lds_int* flags = (volatile lds_int*)flagmem.v;
+    const int lane = threadIdx.x & 63;
+    const int group = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    int strip = group / ncw;
+    const int cw = group - strip * ncw;
+    if (strip >= nsA) { // workgroup-uniform: a strip of the second range
+        strip -= nsA;
+        j0 = j0b, j1 = j1b;
+    }
+    MarchConst3 M;
+    M.y0 = j0 + strip * R;
+    if (M.y0 >= j1)
+        return; // workgroup-uniform: no wave of this workgroup reaches the barrier or a counter
+    M.y1 = min(M.y0 + R, j1);
+    const int ixr = cw * P4_OWNED - P4_LEFT + lane;
+    const bool valid = ixr >= 0 && ixr < nx;
+    M.K = K;
+    M.nx = nx, M.ny = ny, M.lane = lane;
+    M.own = valid && lane >= P4_LEFT && lane < P4_LEFT + P4_OWNED;
+    M.ix = min(max(ixr, 0), nx - 1);
+    M.hasL = M.ix > 0, M.lastcol = M.ix == nx - 1;
+    M.ntx = tiles_per_row(nx);
+    M.nn = 2 * nx + 1;
+    M.nplane = nodal_plane((long)M.nn * (2 * ny + 1));
+    M.hx = hx, M.hy = hy, M.ihx = 1. / hx, M.ihy = 1. / hy, M.iarea = M.ihx * M.ihy;
+    M.ialpha = ialpha, M.dmin2 = dmin2;
+    M.tbeg = M.tendA = M.tendB = 0; // (fields of the other pipelines)
+
+    StageP G;
+    G.s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto first_of = [&](int s) { return max(M.y0 - 4 + s, 0); };
+    auto last_of = [&](int s) { return min(M.y1 + 2 - s, ny - 1); };
+    G.first = first_of(G.s);
+    G.last = last_of(G.s);
+    G.last_prev = last_of(G.s - 1);
+    G.last3 = last_of(3);
+    G.upd0 = G.s == 0 ? 0 : M.y0 - 3 + G.s;
+
+    // counters: done[k] = first row of stage k - 1 (nothing handed over yet), read[k] = first row of stage k + 1 - 1 (every row
+    // below the consumer's first one counts as taken: the consumer never looks at it)
+    if (threadIdx.x < 3) {
+        flags[threadIdx.x] = first_of(threadIdx.x) - 1;
+        flags[3 + threadIdx.x] = first_of(threadIdx.x + 1) - 1;
+    }
+    if (threadIdx.x == 6)
+        flags[6] = 0;
+    __syncthreads(); // the only barrier of the kernel
+
+    FetchP f;
+    TopCarry3 carry;
+    if (G.s == 0) {
+        const int row = G.first;
+        const long nV = (long)(2 * row) * M.nn + 2 * M.ix, ts = tile_off(M.ix, row, M.ntx, 8);
+        fetch_nodes_p(u_old, nV, f.ub);
+        fetch_nodes_p(v_old, nV, f.vb);
+        fetch_nodes_p(u_old, nV + M.nn, f.um);
+        fetch_nodes_p(v_old, nV + M.nn, f.vm);
+        fetch_nodes_p(u_old, nV + 2 * M.nn, f.ut);
+        fetch_nodes_p(v_old, nV + 2 * M.nn, f.vt);
+        tile_load8(S.i11, ts, f.s11);
+        tile_load8(S.i12, ts, f.s12);
+        tile_load8(S.i22, ts, f.s22);
+        tile_load9(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
+        request_c_p(M, row, f.c, packed);
+        for (int row = G.first; row <= G.last; ++row)
+            p2p_row<true>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new);
+    } else {
+        for (int row = G.first; row <= G.last; ++row)
+            p2p_row<false>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new);
+    }
+}
+
+} // namespace nsdg_mevp_detail
+
+using namespace nsdg_mevp_detail;
+
+// events in which a wait of the point-to-point pipeline gave up since the last call (0 in a correct program); resets the counter
+extern "C" int nsdg_debug_p2p_timeouts(unsigned* out)
+{
+    unsigned zero = 0;
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nsdg_p2p_timeouts_dev), sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipMemcpyToSymbol(HIP_SYMBOL(nsdg_p2p_timeouts_dev), &zero, sizeof(unsigned));
+    return (int)e;
+}
+
+int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
+    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
+    const double* pg)
+{
+    const int ncw = nsdg_div_up(ctx->nx, P4_OWNED);
+    const int rowsB = j0b < j1b ? j1b - j0b : 0;
+    int R = ctx->strip_rows;
+    if (R <= 0) {
+        // a strip of R rows takes about R + 13 march steps; one resident workgroup per CU (LDS)
+        const long slots = ctx->num_cus;
+        double best = 1e30;
+        R = 64;
+        for (int r = 1; r <= 4096; ++r) {
+            const long groups = ((long)nsdg_div_up(j1 - j0, r) + nsdg_div_up(rowsB, r)) * ncw;
+            const long rounds = (groups + slots - 1) / slots;
+            const double cost = rounds * (r + (double)P4_STEPS_EXTRA);
+            if (cost < best) {
+                best = cost;
+                R = r;
+            }
+            if (groups <= ncw * (rowsB ? 2 : 1))
+                break; // one strip per range: taller strips change nothing
+        }
+    }
+    const int nsA = nsdg_div_up(j1 - j0, R), nsB = nsdg_div_up(rowsB, R);
+    const long ngroups = (long)ncw * (nsA + nsB);
+    const StressPtrsP S = { s11i, s12i, s22i, s11, s12, s22 };
+    const nsdg_mevp_params& P = ctx->mevp;
+    const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
+    hipLaunchKernelGGL(mevp_fused4p_kernel, dim3(ngroups), dim3(256), 0, ctx->stream, K, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
+        ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg, u_new, v_new);
+    NSDG_CHECK_LAUNCH();
+    return NSDG_OK;
+}
