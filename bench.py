@@ -429,6 +429,8 @@ def main():
                     "deliberately wrong diagnostic builds only; the line then says 'finite fields' as its self-check)")
     ap.add_argument("--no-closure", action="store_true", help="the bare scheme of rounds 1-4: no ridging cap / scaling limiter in the transport, no "
                     "ice-free-node rule (A/B of what the closure costs; the default run has it ON, as the hosts do)")
+    ap.add_argument("--delta-min", type=float, default=None, help="regularisation of Delta [1/s]; alpha = beta then follow from the stability bound "
+                    "of the sub-cycle (2e-9: the configuration of rounds 1-4).  Default: alpha = beta = 1500 with the Delta_min the mesh needs for it")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (gloo): launch, rendezvous, planning; no metric")
     args = ap.parse_args()
 
@@ -469,7 +471,11 @@ def main():
     L = 512e3
     dt = 120.0
     bt = synthetic.BoxTest(nx, ny, L)
-    alpha = bt.stable_alpha(dt)  # alpha = beta from the linear-stability bound of the sub-cycle on this mesh
+    # alpha = beta = 1500 as BASELINE / SURVEY 8(d) name it, with the regularisation Delta_min this mesh needs for that alpha to be stable
+    # (synthetic.BoxTest.stable_delta_min); --delta-min X: that regularisation instead, with the alpha its stability bound asks for
+    # (2e-9: the rounds 1-4 configuration, alpha = 28 875 at 2048^2)
+    sub = bt.subcycle_parameters(dt, delta_min=args.delta_min)
+    alpha = sub["alpha"]
     coupled = args.workload == "coupled"
     # One-GPU rehearsal of the WHOLE N-rank code path (NSDG_BENCH_LOOPBACK_WORLD=W): this process plays the interior block W/2
     # of W, both neighbours are the rank itself, every exchange a real RCCL send/recv group -- the values wrap around, so
@@ -501,7 +507,7 @@ def main():
             c.set_mevp_occupancy(args.occupancy)
         if args.transport_variant is not None:
             c.set_transport_variant(args.transport_variant)
-        c.set_mevp_params(c.mevp_default_params(alpha=alpha, beta=alpha, **(dict(min_conc=0.0, min_thick=0.0) if args.no_closure else {})))
+        c.set_mevp_params(c.mevp_default_params(**sub, **(dict(min_conc=0.0, min_thick=0.0) if args.no_closure else {})))
         b, d = plan_blocks(c.mevp_variant, kpass, nx, ny, eff_rank, eff_world)
         ex = None
         if eff_world > 1 or os.environ.get("NSDG_FORCE_DIST"):
@@ -706,9 +712,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("column thermodynamics + " if coupled else "") + "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
-                                   "512 km box test, dt=120 s, alpha=beta=%.0f (the linear-stability bound of the sub-cycle on this mesh; SURVEY 8(d) "
-                                   "names 1500, which is unstable here; with %d sub-iterations the stress is under-converged towards the VP state -- "
-                                   "flops and bytes do not depend on alpha)" % (nx, ny, nsub, alpha, nsub),
+                                   "512 km box test, dt=120 s, alpha=beta=%.0f, Delta_min=%.2e 1/s (%s; the %d sub-iterations move the sub-cycle "
+                                   "%.1f %% of the way per model step; flops and bytes do not depend on either)" % (
+                                       nx, ny, nsub, alpha, sub["delta_min"],
+                                       "SURVEY 8(d)'s alpha with the smallest regularisation for which it satisfies the sub-cycle's stability bound on this mesh"
+                                       if args.delta_min is None else "--delta-min: alpha from the stability bound of the sub-cycle on this mesh",
+                                       nsub, 100.0 * min(1.0, nsub / alpha)),
                        "decomposition": "%d row block(s), ghost-row send/recv" % eff_world + (
                            ", ghost depth %d/%d rows, one exchange per %d mEVP passes%s, halo=%s" % (
                                depth[0], depth[1], core.group_passes,

@@ -140,7 +140,8 @@ int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hice, double* 
  *      step; the mean thickness -- the conserved volume -- is a field of its own and is not touched, so convergence beyond a
  *      closed cover turns into (true) thickness;
  *   2. a Zhang-Shu scaling limiter at the end of a transport step keeps the values of a bounded field at the scheme's quadrature
- *      points (volume and edge Gauss points) inside [lo, hi] by scaling its higher coefficients; cell means are never changed;
+ *      points (volume and edge Gauss points) and at its corners -- together: at every CG2 node of the element too -- inside [lo, hi]
+ *      by scaling its higher coefficients; cell means are never changed;
  *   3. ice-free nodes (nsdg_mevp_params.min_conc / min_thick) are in free drift and do not feel their neighbours' stress.
  * 1 and 2 are per-field properties the host states with nsdg_transport_bounds_set (they are OFF until it does: the library does
  * not know which field is a concentration); 3 is ON by default.  The calls still do not check their inputs; both hosts stop
@@ -153,7 +154,8 @@ typedef struct {
     double fc;
     double alpha, beta;
     double h_min; /* floor of the nodal mean thickness in the nodal mass */
-    /* ice-free-node rule: a node with mean concentration < min_conc or true thickness cgH / cgA < min_thick is in free drift (full
+    /* ice-free-node rule: a node with mean concentration < min_conc, true thickness cgH / cgA < min_thick or a mean thickness at the
+     * mass floor (cgH <= h_min: its mass would be made up) is in free drift (full
      * exposure to wind and ocean drag, Coriolis, floor mass) and the stress divergence of the neighbouring elements is weighted by
      * 2^-100 there.  Defaults: the column model's cut-off values 1e-12 and 0.01 m (nextsim_thermo.min_conc / min_thick,
      * physics/src/modules/NextsimPhysics.cpp:81-82).  Both 0: rule off. */

@@ -183,13 +183,13 @@ __device__ __forceinline__ void pack_node(const nsdg_mevp_params& P, double dt, 
 {
     const double h = fmax(cgh, P.h_min);
     // Ice-free-node rule (round 5; the shape of the column model's cut-off  c_new < minc || hi < minh,
-    // physics/src/modules/NextsimPhysics.cpp:210-219): a node whose mean concentration is below min_conc or whose TRUE thickness
-    // cgH / cgA is below min_thick is in FREE DRIFT -- full exposure (a = 1) to wind stress and ocean drag, Coriolis, its floor mass
+    // physics/src/modules/NextsimPhysics.cpp:210-219): a node whose mean concentration is below min_conc, whose TRUE thickness
+    // cgH / cgA is below min_thick or whose mean thickness is at the mass floor h_min (a made-up mass) is in FREE DRIFT -- full exposure (a = 1) to wind stress and ocean drag, Coriolis, its floor mass
     // -- and does not feel the stress divergence of the neighbouring elements.  That costs the sub-cycle NOTHING: the update is
     //   u' = (K1 h' u + c2 + drag u_o + K3 h' v + div_x / M) / (K2 h' + drag),  drag = cd |v_o - v|,
     // homogeneous of degree 0 in (h', cd, c2, c3, div): scaling the four packed coefficients by 2^100 (exact: a power of two)
     // leaves every other term as it is and weights the divergence by 2^-100 -- below the last bit of the sum.  Both 0: rule off.
-    const bool ice_free = (P.min_conc > 0. || P.min_thick > 0.) && (cga < P.min_conc || cgh < P.min_thick * cga);
+    const bool ice_free = (P.min_conc > 0. || P.min_thick > 0.) && (cga < P.min_conc || cgh < P.min_thick * cga || cgh <= P.h_min);
     const double a = ice_free ? 1. : fmin(fmax(cga, 0.), 1.);
     const double mdt = P.rho_ice * h / dt;
     const double cor = P.rho_ice * h * P.fc;
@@ -355,6 +355,9 @@ int nsdg_launch_mevp_fused3_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j
 // defined in mevp_fused4.hip
 int nsdg_launch_mevp_fused4(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
     double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
+int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
+    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
+    const double* pg);
 int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg);
@@ -537,6 +540,8 @@ int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (ctx->mevp_variant >= 2 && ctx->f4_p2p) // a pass of the stage-per-wave pipeline with two stages
+        return nsdg_launch_mevp_fused4p_ranges(ctx, 2, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     if (ctx->mevp_variant >= 2)
         return nsdg_launch_mevp_fused2(ctx, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     nsdg_set_error("nsdg_mevp_iterate2: select variant 2, 3 or 4 (nsdg_mevp_variant_set) or call nsdg_mevp_iterate twice");
@@ -563,6 +568,8 @@ int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (ctx->mevp_variant >= 3 && ctx->f4_p2p) // ... with three stages
+        return nsdg_launch_mevp_fused4p_ranges(ctx, 3, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     if (ctx->mevp_variant >= 3)
         return nsdg_launch_mevp_fused3(ctx, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     nsdg_set_error("nsdg_mevp_iterate3: select variant 3 or 4 (nsdg_mevp_variant_set)");
@@ -594,6 +601,8 @@ int nsdg_mevp_iterate3_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
         return NSDG_ERR_STATE;
     }
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    if (ctx->f4_p2p)
+        return nsdg_launch_mevp_fused4p_ranges(ctx, 3, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     return nsdg_launch_mevp_fused3_ranges(ctx, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
 }
 

@@ -396,7 +396,7 @@ extern "C" int nsdg_debug_read_stamps4(unsigned* host_out)
 // four sub-iterations on the rows [j0, j1) of the local array and, if j0b < j1b, on a second disjoint range [j0b, j1b)
 // in the same launch
 // mevp_fused4p.hip: the same pass with the hand-over point to point
-int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
+int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg);
 
@@ -405,7 +405,7 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j
     const double* pg)
 {
     if (ctx->f4_p2p)
-        return nsdg_launch_mevp_fused4p_ranges(ctx, j0, j1, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
+        return nsdg_launch_mevp_fused4p_ranges(ctx, 4, j0, j1, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     const int ncw = nsdg_div_up(ctx->nx, F4_OWNED);
     const int rowsB = j0b < j1b ? j1b - j0b : 0;
     int R = ctx->strip_rows;

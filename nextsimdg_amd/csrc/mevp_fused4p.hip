@@ -12,10 +12,11 @@
 //     into slot r % 2 when read[k] >= r - 2.  A link is TWO steps deep -- the minimum the scheme allows: the velocity of the top
 //     node row of element row r is updated by row r + 1 -- a strip takes R + 13 steps (R + 7 rows of stage 0, six steps of lag),
 //     and two slots per link are enough: 96 KB for the three hand-overs.
-//   * the freed LDS holds a RING of the ice strength: the loader (stage 0) reads a row's nine Gauss-point values from memory
-//     once and writes them to the ring, the stages 1-3 take them from there (8 rows x 4.6 KB = 37 KB).  The packed nodal
-//     coefficients (192 B per element) are still re-read by every stage: a ring for them needs another 8 x 12 KB
-//     (profiles/r05_fused4_p2p.md: what fits, what was measured).
+//   * the freed LDS holds two RINGS of seven rows: the loader (stage 0) reads a row's ice strength (nine Gauss-point values) and
+//     packed nodal coefficients from memory once and writes the ice strength and ONE of the three coefficient pairs (u_ocean,
+//     v_ocean of the 4 owned nodes) into the rings, the stages 1-3 take them from there: 136 of the 264 bytes per element each of
+//     them used to re-read.  The other two pairs (128 B) are still re-read from memory -- a ring for them needs another 2 x 28 KB
+//     and the LDS is full: 96 + 31.5 + 28 = 155.5 of 160 KB (profiles/r05_fused4_p2p.md: what fits, what was measured).
 //   * no barrier after the prologue: the waves run as far apart as their dependencies allow, idle steps do not exist.
 //
 // Memory ordering.  All hand-over traffic is LDS traffic of ONE compute unit; the LDS executes the instructions of a wave in order.
@@ -43,10 +44,10 @@ constexpr int P4_OWNED = 57, P4_LEFT = 4; // lanes 4 .. 60 own a column (as in m
 constexpr int P4_HAND = 32; // doubles per lane and hand-over slot: 24 stress coefficients + u, v at the 4 owned nodes
 constexpr int P4_SLOT = P4_HAND * 64; // value k of lane l at (k / 2) * 128 + 2 l + k % 2 (16-byte pairs)
 constexpr int P4_HSLOTS = 2; // slots per link
-constexpr int P4_PRING = 8; // rows of ice strength in the ring
-constexpr int P4_PSLOT = 9 * 64; // pairs k < 4 of lane l at k * 128 + 2 l, the ninth value at 512 + l
-constexpr int P4_LDS = 3 * P4_HSLOTS * P4_SLOT + P4_PRING * P4_PSLOT; // doubles: 96 KB + 36 KB
-constexpr int P4_STEPS_EXTRA = 13; // a strip of R rows takes about R + 13 march steps
+constexpr int P4_PRING = 7; // rows in each of the two rings (a row is in flight for ~5.7 march steps; 7 x (4.6 + 4) KB is what fits)
+constexpr int P4_PSLOT = 9 * 64; // ice strength: pairs k < 4 of lane l at k * 128 + 2 l, the ninth value at 512 + l
+constexpr int P4_CSLOT = 8 * 64; // third pair of the nodal coefficients (u_ocean, v_ocean): node n of lane l at n * 128 + 2 l
+constexpr int P4_LDS = 3 * P4_HSLOTS * P4_SLOT + P4_PRING * (P4_PSLOT + P4_CSLOT); // doubles: 96 + 31.5 + 28 KB of the 160 KB of a CU
 #ifndef NSDG_P2P_SPIN_LIMIT
 #define NSDG_P2P_SPIN_LIMIT (1 << 20) // polls of ~0.2 us: a fifth of a second; a legitimate wait is a few march steps (a few microseconds)
 #endif
@@ -60,9 +61,10 @@ struct FetchP {
 
 struct StageP {
     int s; // pipeline stage of this wave = sub-iteration p + s
+    int nst; // stages of this pass = its sub-iterations (4; 3 or 2 for what is left of a sub-cycle whose length is no multiple of 4)
     int first, last; // element rows this stage works on
     int last_prev; // last row of the previous stage
-    int last3; // last row of stage 3 (the loader's ring wait)
+    int last_final; // last row of the last stage (the loader's ring wait)
     int upd0; // node updates from this row on
 };
 
@@ -87,7 +89,9 @@ __device__ __forceinline__ void flag_wait(volatile lds_int* flags, int which, in
     if (flag_peek(flags + which) >= need)
         return;
     for (int spin = 0; spin < NSDG_P2P_SPIN_LIMIT; ++spin) {
+#ifndef NSDG_P2P_NOSLEEP
         __builtin_amdgcn_s_sleep(1);
+#endif
         if (flag_peek(flags + which) >= need || flag_peek(flags + 6) != 0)
             return;
     }
@@ -121,10 +125,46 @@ __device__ __forceinline__ void request_c_p(const MarchConst3& M, int nrow, doub
     load_nodal(packed, M.nplane, nVn + M.nn, c[2]);
     load_nodal(packed, M.nplane, nVn + M.nn + 1, c[3]);
 }
+__device__ __forceinline__ int ring_slot(int row) { return row % P4_PRING; } // row >= 0
+// the third pair (u_ocean, v_ocean) of the 4 owned nodes of a row from / to its ring
+__device__ __forceinline__ void ring_read_c(const double* __restrict__ cring, int row, int lane, double (&c)[4][6])
+{
+    const double* s = cring + ring_slot(row) * P4_CSLOT + 2 * lane;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const double2 t = *reinterpret_cast<const double2*>(s + n * 128);
+        c[n][4] = t.x, c[n][5] = t.y;
+    }
+}
+__device__ __forceinline__ void ring_write_c(double* __restrict__ cring, int row, int lane, const double (&c)[4][6])
+{
+    double* s = cring + ring_slot(row) * P4_CSLOT + 2 * lane;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+        *reinterpret_cast<double2*>(s + n * 128) = make_double2(c[n][4], c[n][5]);
+}
+// the first two pairs of the nodal coefficients from memory (the third comes from the ring)
+__device__ __forceinline__ void load_nodal2(const double* __restrict__ packed, long plane, long n, double (&c)[6])
+{
+    const double* p = packed + nodal_off(n, plane);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double2 t = *reinterpret_cast<const double2*>(p + k * plane);
+        c[2 * k] = t.x, c[2 * k + 1] = t.y;
+    }
+}
+__device__ __forceinline__ void request_c2_p(const MarchConst3& M, int nrow, double (&c)[4][6], const double* __restrict__ packed)
+{
+    const long nVn = (long)(2 * nrow) * M.nn + 2 * M.ix;
+    load_nodal2(packed, M.nplane, nVn, c[0]);
+    load_nodal2(packed, M.nplane, nVn + 1, c[1]);
+    load_nodal2(packed, M.nplane, nVn + M.nn, c[2]);
+    load_nodal2(packed, M.nplane, nVn + M.nn + 1, c[3]);
+}
 // ice strength of a row from / to the ring
 __device__ __forceinline__ void ring_read_P(const double* __restrict__ ring, int row, int lane, double (&P)[9])
 {
-    const double* s = ring + (row & (P4_PRING - 1)) * P4_PSLOT;
+    const double* s = ring + ring_slot(row) * P4_PSLOT;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const double2 t = *reinterpret_cast<const double2*>(s + k * 128 + 2 * lane);
@@ -134,7 +174,7 @@ __device__ __forceinline__ void ring_read_P(const double* __restrict__ ring, int
 }
 __device__ __forceinline__ void ring_write_P(double* __restrict__ ring, int row, int lane, const double (&P)[9])
 {
-    double* s = ring + (row & (P4_PRING - 1)) * P4_PSLOT;
+    double* s = ring + ring_slot(row) * P4_PSLOT;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         *reinterpret_cast<double2*>(s + k * 128 + 2 * lane) = make_double2(P[2 * k], P[2 * k + 1]);
@@ -151,6 +191,16 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     const int nrow = min(row + 1, G.last); // the row this stage works on next: its inputs are requested during this one
     const int ix = M.ix, nn = M.nn;
     double* const ring = lds + 3 * P4_HSLOTS * P4_SLOT;
+    double* const cring = ring + P4_PRING * P4_PSLOT;
+    // the coefficients of row r: a stage >= 1 takes two pairs from memory and the third from the ring
+    auto request_c = [&](int r) {
+        if (FIRST)
+            request_c_p(M, r, f.c, packed);
+        else {
+            request_c2_p(M, r, f.c, packed);
+            ring_read_c(cring, r, M.lane, f.c);
+        }
+    };
     const long nVn = (long)(2 * nrow) * nn + 2 * ix; // vertex node of the next row
     double s11[8], s12[8], s22[8], uu[4], vv[4], ul[9], vl[9], un[4], vn[4];
     // ------------------------------------------------------------------------------------------ inputs of the row
@@ -167,7 +217,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         flag_wait(flags, stage - 1, min(row + 1, G.last_prev));
         if (row == G.first) { // wave-uniform: the first row of the stage has no predecessor that requested its inputs
             ring_read_P(ring, row, M.lane, f.P);
-            request_c_p(M, row, f.c, packed);
+            request_c(row);
         }
         const double* in = lds + ((stage - 1) * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
         const double* top = lds + ((stage - 1) * P4_HSLOTS + ((row + 1) & 1)) * P4_SLOT + 2 * M.lane;
@@ -189,8 +239,11 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     if (FIRST) {
         // the ice strength of this row goes to the ring for the stages 1-3 (slot of row - 8: stage 3 has passed it), then the
         // register set takes the next row's; u, v of the next row
-        flag_wait(flags, 3 + 2, min(row - P4_PRING, G.last3));
+        flag_wait(flags, 3 + G.nst - 2, min(row - P4_PRING, G.last_final)); // read[] of the LAST link: the last stage has passed that row
         ring_write_P(ring, row, M.lane, f.P);
+#ifndef NSDG_P2P_CLATE
+        ring_write_c(cring, row, M.lane, f.c); // this row's coefficients were requested a step ago; the stages 1-3 take the pair from here
+#endif
         tile_load9(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P);
         if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
 #pragma unroll
@@ -236,9 +289,13 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         carry_top(carry, cx, cy);
     }
     __builtin_amdgcn_sched_barrier(0);
-    request_c_p(M, nrow, f.c, packed); // nodal coefficients of the next row
+#ifdef NSDG_P2P_CLATE
+    if (FIRST)
+        ring_write_c(cring, row, M.lane, f.c);
+#endif
+    request_c(nrow); // nodal coefficients of the next row
     // ------------------------------------------------------------------------------------------ outputs
-    if (FIRST || stage < 3) {
+    if (FIRST || stage < G.nst - 1) {
         flag_wait(flags, 3 + stage, row - P4_HSLOTS); // the consumer has taken the row this slot held
         double* out = lds + (stage * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
 #pragma unroll
@@ -276,7 +333,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     }
 }
 
-__global__ __launch_bounds__(256) void mevp_fused4p_kernel(NodalConsts K, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw,
+__global__ __launch_bounds__(256) void mevp_fused4p_kernel(NodalConsts K, int nst, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw,
     double hx, double hy, double ialpha, double dmin2, StressPtrsP S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
 {
@@ -310,15 +367,18 @@ __global__ __launch_bounds__(256) void mevp_fused4p_kernel(NodalConsts K, int nx
     M.ialpha = ialpha, M.dmin2 = dmin2;
     M.tbeg = M.tendA = M.tendB = 0; // (fields of the other pipelines)
 
+    // a pass of nst sub-iterations (2 <= nst <= 4): stage s works on the rows y0 - nst + s .. y1 + nst - 2 - s, the last one (nst - 1)
+    // on y0 - 1 .. y1 - 1; the waves s >= nst have nothing to do
     StageP G;
     G.s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    auto first_of = [&](int s) { return max(M.y0 - 4 + s, 0); };
-    auto last_of = [&](int s) { return min(M.y1 + 2 - s, ny - 1); };
+    G.nst = nst;
+    auto first_of = [&](int s) { return max(M.y0 - nst + s, 0); };
+    auto last_of = [&](int s) { return min(M.y1 + nst - 2 - s, ny - 1); };
     G.first = first_of(G.s);
     G.last = last_of(G.s);
     G.last_prev = last_of(G.s - 1);
-    G.last3 = last_of(3);
-    G.upd0 = G.s == 0 ? 0 : M.y0 - 3 + G.s;
+    G.last_final = last_of(nst - 1);
+    G.upd0 = G.s == 0 ? 0 : M.y0 - (nst - 1) + G.s;
 
     // counters: done[k] = first row of stage k - 1 (nothing handed over yet), read[k] = first row of stage k + 1 - 1 (every row
     // below the consumer's first one counts as taken: the consumer never looks at it)
@@ -329,6 +389,8 @@ __global__ __launch_bounds__(256) void mevp_fused4p_kernel(NodalConsts K, int nx
     if (threadIdx.x == 6)
         flags[6] = 0;
     __syncthreads(); // the only barrier of the kernel
+    if (G.s >= nst)
+        return; // wave-uniform
 
     FetchP f;
     TopCarry3 carry;
@@ -368,7 +430,7 @@ extern "C" int nsdg_debug_p2p_timeouts(unsigned* out)
     return (int)e;
 }
 
-int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
+int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg)
 {
@@ -376,14 +438,16 @@ int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int 
     const int rowsB = j0b < j1b ? j1b - j0b : 0;
     int R = ctx->strip_rows;
     if (R <= 0) {
-        // a strip of R rows takes about R + 13 march steps; one resident workgroup per CU (LDS)
+        // a strip of R rows takes about R + 4 nst - 3 march steps (R + 2 nst - 1 rows of stage 0, 2 (nst - 1) steps of lag: R + 13 for
+        // four sub-iterations); one resident workgroup per CU (LDS)
+        const double extra = 4. * nst - 3.;
         const long slots = ctx->num_cus;
         double best = 1e30;
         R = 64;
         for (int r = 1; r <= 4096; ++r) {
             const long groups = ((long)nsdg_div_up(j1 - j0, r) + nsdg_div_up(rowsB, r)) * ncw;
             const long rounds = (groups + slots - 1) / slots;
-            const double cost = rounds * (r + (double)P4_STEPS_EXTRA);
+            const double cost = rounds * (r + extra);
             if (cost < best) {
                 best = cost;
                 R = r;
@@ -397,7 +461,7 @@ int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int 
     const StressPtrsP S = { s11i, s12i, s22i, s11, s12, s22 };
     const nsdg_mevp_params& P = ctx->mevp;
     const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
-    hipLaunchKernelGGL(mevp_fused4p_kernel, dim3(ngroups), dim3(256), 0, ctx->stream, K, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
+    hipLaunchKernelGGL(mevp_fused4p_kernel, dim3(ngroups), dim3(256), 0, ctx->stream, K, nst, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
         ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg, u_new, v_new);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;

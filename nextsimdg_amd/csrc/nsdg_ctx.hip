@@ -88,7 +88,7 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     c->strip_rows = 0;
     {
         const char* v = std::getenv("NSDG_F4_P2P");
-        c->f4_p2p = (v && *v) ? std::atoi(v) : 0;
+        c->f4_p2p = (v && *v) ? std::atoi(v) : 1; // default: point to point; NSDG_F4_P2P=0: the round-4 kernel (one barrier per march step), for A/B
     }
     {
         hipDeviceProp_t prop;

@@ -72,8 +72,8 @@ __device__ __forceinline__ double rk_update(double a, double b, double dt, doubl
 
 // Closure of a transport step on ONE element (oracle_transport_limit): cap of the cell mean (ridging, for a
 // field with cap != 0: a mean above hi becomes hi), then the Zhang-Shu scaling limiter -- the higher coefficients are scaled by
-// the largest theta <= 1 that keeps the values at the scheme's own quadrature points, the NQ volume Gauss points and the NG Gauss
-// points of each edge, inside [lo, hi]; the cell mean is never changed by the limiter.  ONE function for the marching kernel's
+// the largest theta <= 1 that keeps the values at the scheme's own quadrature points -- the NQ volume Gauss points and the NG Gauss
+// points of each edge -- and at the four corners inside [lo, hi]; the cell mean is never changed by the limiter.  ONE function for the marching kernel's
 // epilogue and for the stand-alone kernel behind nsdg_transport_limit: the two round identically (fused step == staged step).
 // The division runs only on lanes whose element leaves the range (rare: a handful of elements of a model step).
 template <int ORDER>
@@ -109,6 +109,14 @@ __device__ __forceinline__ void limit_cell(double (&c)[DG<ORDER>::NC], double lo
                 dmin = fmin(dmin, fmin(fmin(dr, dl), fmin(dt, db)));
                 dmax = fmax(dmax, fmax(fmax(dr, dl), fmax(dt, db)));
             }
+            {
+                // the four corners: with the edge mid-points and the centre (Gauss points above) these are the CG2 NODES of the element,
+                // so that the nodal means the momentum equation takes its mass and concentration from stay inside the bounds as well
+                const double Q = 0.25 * c[5];
+                const double d00 = (X[3] + Y[3]) + Q, d10 = (X[4] + Y[3]) - Q, d01 = (X[3] + Y[4]) - Q, d11 = (X[4] + Y[4]) + Q;
+                dmin = fmin(dmin, fmin(fmin(d00, d10), fmin(d01, d11)));
+                dmax = fmax(dmax, fmax(fmax(d00, d10), fmax(d01, d11)));
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -130,6 +138,12 @@ __device__ __forceinline__ void limit_cell(double (&c)[DG<ORDER>::NC], double lo
                 }
                 dmin = fmin(dmin, fmin(fmin(dr, dl), fmin(dt, db)));
                 dmax = fmax(dmax, fmax(fmax(dr, dl), fmax(dt, db)));
+            }
+            { // the four corners (DG1: c1 x + c2 y at x, y = -1/2, 1/2)
+                const double a = 0.5 * c[1], b = 0.5 * c[2];
+                const double d00 = -a - b, d10 = a - b, d01 = b - a, d11 = a + b;
+                dmin = fmin(dmin, fmin(fmin(d00, d10), fmin(d01, d11)));
+                dmax = fmax(dmax, fmax(fmax(d00, d10), fmax(d01, d11)));
             }
         }
         const double mean = c[0];

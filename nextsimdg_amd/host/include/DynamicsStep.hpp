@@ -19,7 +19,11 @@
 // Configuration keys (all optional):
 //     dynamics.domain_size   side of the square box in m        (512e3)
 //     dynamics.nsub          mEVP sub-iterations per step        (120)
-//     dynamics.alpha/.beta   mEVP parameters (0 = stability bound of the mesh, see stableAlpha())
+//     dynamics.alpha/.beta   mEVP parameters (0 = 1500, the BASELINE's value, with the regularisation dynamics.delta_min the mesh needs
+//                            for it -- stableDeltaMin(); with dynamics.delta_min given: the stability bound for it -- stableAlpha())
+//     dynamics.delta_min     regularisation of Delta [1/s] (0 = from the mesh; 2e-9 = the literature's value, the rounds 1-4 runs)
+//     dynamics.closure       ridging cap + scaling limiter in the transport, free drift at ice-free nodes (default true)
+//     dynamics.min_conc/.min_thick   the ice-free-node rule's thresholds (defaults 1e-12, 0.01: the column model's cut-off)
 //     dynamics.thermodynamics  run the column physics first       (false)
 //     dynamics.forcing       thermodynamic forcing: host (the structure's planes, constant in time) | dummy | winter
 //                            (generated on the device at every step's model time, wind speed from the dynamics' wind)
@@ -65,7 +69,8 @@ public:
     double sumH() const { return m_sumH; }
     double sumA() const { return m_sumA; }
     int blocks() const { return (int)m_blocks.size(); }
-    static double stableAlpha(double h, double dt);
+    static double stableAlpha(double h, double dt, double dmin = 2e-9);
+    static double stableDeltaMin(double h, double dt, double alpha = 1500.);
 
     //! rows [r0, r1) of block `rank` of `world` (the same split as nextsimdg_amd/rowblock.py split_rows)
     static void splitRows(int ny, int world, int rank, int& r0, int& r1);
@@ -87,6 +92,7 @@ private:
     int nsub = 120, rowBlocks = 1, passesPerExchange = 3, loopbackWorld = 0;
     bool thermo = false, overlap = true, graph = false, m_inited = false;
     bool closure = true; // ridging cap + scaling limiter in the transport, free drift at ice-free nodes (dynamics.closure)
+    double deltaMin = 0; // dynamics.delta_min; 0: from the mesh, for alpha = beta = 1500
     double minConc = 1e-12, minThick = 0.01; // ice-free-node rule (dynamics.min_conc / min_thick; the column model's cut-off values)
     std::string forcing = "host", devices;
     int m_world = 1, m_rank = 0; // multi-process run (one block per process)

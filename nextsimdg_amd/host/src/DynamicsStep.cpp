@@ -91,19 +91,25 @@ const std::map<int, std::string> Configured<DynamicsStep>::keyMap = { { 0, "dyna
     { 2, "dynamics.alpha" }, { 3, "dynamics.beta" }, { 4, "dynamics.thermodynamics" }, { 5, "dynamics.row_blocks" },
     { 6, "dynamics.passes_per_exchange" }, { 7, "dynamics.overlap" }, { 8, "dynamics.graph" }, { 9, "dynamics.forcing" },
     { 10, "dynamics.devices" }, { 11, "dynamics.loopback_world" }, { 12, "dynamics.closure" }, { 13, "dynamics.min_conc" },
-    { 14, "dynamics.min_thick" } };
+    { 14, "dynamics.min_thick" }, { 15, "dynamics.delta_min" } };
 
 DynamicsStep::DynamicsStep() = default;
 DynamicsStep::~DynamicsStep() { release(); }
 
 void DynamicsStep::release() { m_blocks.clear(); }
 
-double DynamicsStep::stableAlpha(double h, double dt)
+double DynamicsStep::stableAlpha(double h, double dt, double dmin)
 { // alpha*beta >= pi^2 zeta_max dt / (m h^2), zeta_max = P* H / (2 Delta_min); same rule as synthetic.BoxTest.stable_alpha
-    const double pstar = 27.5e3, dmin = 2e-9, rho = 900., hice = 0.3;
+    const double pstar = 27.5e3, rho = 900., hice = 0.3;
     const double zeta = pstar * hice / (2. * dmin);
     const double pi = 3.14159265358979323846;
     return std::max(1500., 2.4 * std::sqrt(pi * pi * zeta * dt / (rho * hice * h * h))); // 2.4: margin a one-day run needs
+}
+
+double DynamicsStep::stableDeltaMin(double h, double dt, double alpha)
+{ // the smallest Delta_min (never below 2e-9) for which alpha = beta = `alpha` meets that bound: synthetic.BoxTest.stable_delta_min
+    const double pstar = 27.5e3, rho = 900., pi = 3.14159265358979323846;
+    return std::max(2e-9, 2.4 * 2.4 * pi * pi * pstar * dt / (2. * rho * h * h * alpha * alpha));
 }
 
 void DynamicsStep::splitRows(int ny, int world, int rank, int& r0, int& r1)
@@ -132,6 +138,10 @@ void DynamicsStep::configure()
     closure = getConfiguration(keyMap.at(12), true);
     minConc = getConfiguration(keyMap.at(13), 1e-12);
     minThick = getConfiguration(keyMap.at(14), 0.01);
+    // sub-cycle parameters (profiles/r05_closure.md): dynamics.alpha / beta given: used as they are; dynamics.delta_min given (and no
+    // alpha): alpha = beta from the stability bound for that regularisation (2e-9: rounds 1-4); neither: alpha = beta = 1500, the
+    // BASELINE's value, with the smallest Delta_min for which it is stable on this mesh
+    deltaMin = getConfiguration(keyMap.at(15), 0.);
     if (rowBlocks < 1 || passesPerExchange < 1 || nsub < 0)
         throw std::invalid_argument("dynamics.row_blocks and dynamics.passes_per_exchange must be >= 1, dynamics.nsub >= 0");
     if (forcing != "host" && forcing != "dummy" && forcing != "winter")
@@ -347,9 +357,11 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
     const double dt = dtSeconds;
     nsdg_mevp_params p;
     nsdg_mevp_default_params(&p);
-    const double a = alpha > 0 ? alpha : stableAlpha(std::min(L / nxf, L / nyf), dt);
+    const double hmesh = std::min(L / nxf, L / nyf);
+    const double a = alpha > 0 ? alpha : (deltaMin > 0 ? stableAlpha(hmesh, dt, deltaMin) : 1500.);
     p.alpha = a;
     p.beta = beta > 0 ? beta : a;
+    p.delta_min = deltaMin > 0 ? deltaMin : stableDeltaMin(hmesh, dt, a);
     p.min_conc = closure ? minConc : 0.;
     p.min_thick = closure ? minThick : 0.;
     const double t = m_time;

@@ -71,6 +71,26 @@ class BoxTest:
         bound = np.sqrt(np.pi ** 2 * zeta_max * dt / (rho_ice * h_ice * h * h))
         return float(max(floor, safety * bound))
 
+    def stable_delta_min(self, dt, alpha=1500.0, pstar=27.5e3, rho_ice=900.0, safety=2.4, floor=2e-9):
+        """The other way round (round 5, profiles/r05_closure.md): the SMALLEST regularisation Delta_min -- never below the
+        literature's 2e-9 1/s -- for which the BASELINE's alpha = beta = 1500 satisfies the stability bound above with its margin:
+        zeta_max / m = P* / (2 Delta_min rho_i) <= alpha^2 h^2 / (safety^2 pi^2 dt).  Why the hosts choose THIS way: with the bound's
+        alpha on a fine mesh (14 438 at 500 m, 57 751 at 125 m) 120 sub-iterations move the stress and the velocity 1 % or less of
+        the way to their viscous-plastic state per model step, and a compressible cover (A0 = 0.9) then leaves the physical range
+        within a model day or two whatever closes the transport; with alpha = 1500 and the viscosity capped accordingly
+        (Delta_min 1.9e-7 at 500 m, 7.4e-7 at 250 m, 3.0e-6 at 125 m: creep below ~1 - 25 % per day) the same runs complete.
+        stable_alpha(dt, delta_min=stable_delta_min(dt, alpha)) == alpha."""
+        h = min(self.hx, self.hy)
+        return float(max(floor, safety ** 2 * np.pi ** 2 * pstar * dt / (2.0 * rho_ice * h * h * alpha * alpha)))
+
+    def subcycle_parameters(self, dt, alpha=1500.0, delta_min=None):
+        """alpha = beta and Delta_min of the mEVP sub-cycle as the hosts set them: the named alpha with the regularisation the mesh
+        needs for it (default), or -- delta_min given -- that regularisation with the alpha its stability bound asks for"""
+        if delta_min is None:
+            return dict(alpha=float(alpha), beta=float(alpha), delta_min=self.stable_delta_min(dt, alpha))
+        a = self.stable_alpha(dt, delta_min=delta_min)
+        return dict(alpha=a, beta=a, delta_min=float(delta_min))
+
     def H0(self, x, y):
         return 0.3 + 0.005 * (np.sin(6e-5 * x) + np.sin(3e-5 * y))
 

@@ -366,6 +366,10 @@ void oracle_transport_limit(int nx, int ny, int j0, int j1, int order, double* p
                 for (int k = 0; k < 4; ++k)
                     mn = fmin(mn, v[k]), mx = fmax(mx, v[k]);
             }
+            for (int k = 0; k < 4; ++k) { /* the four corners: with the edge mid-points and the centre, the CG2 nodes of the element */
+                const double v = dg_eval(phi, N, e, nc, k % 2 ? 0.5 : -0.5, k / 2 ? 0.5 : -0.5);
+                mn = fmin(mn, v), mx = fmax(mx, v);
+            }
             double theta = 1.;
             if (mn < lo)
                 theta = fmin(theta, mean > lo ? (mean - lo) / (mean - mn) : 0.);
@@ -538,7 +542,7 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
             const double h = fmax(cgh[n], p->h_min);
             /* ice-free-node rule (dyn_oracle.h): free drift at full exposure, the neighbours' stress divergence weighted by 2^-100 */
             const int rule = p->min_conc > 0. || p->min_thick > 0.;
-            const int ice_free = rule && (cga[n] < p->min_conc || cgh[n] < p->min_thick * cga[n]);
+            const int ice_free = rule && (cga[n] < p->min_conc || cgh[n] < p->min_thick * cga[n] || cgh[n] <= p->h_min);
             const double a_ = ice_free ? 1. : fmin(fmax(cga[n], 0.), 1.);
             const double wdiv = ice_free ? 0x1p-100 : 1.;
             const double mdt = p->rho_ice * h / dt;

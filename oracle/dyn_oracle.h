@@ -17,8 +17,8 @@ typedef struct {
     double alpha, beta;
     double h_min; /* lower limit applied to the nodal mean thickness in the momentum equation */
     /* ice-free-node rule (round 5; shape of the column model's cut-off, physics/src/modules/NextsimPhysics.cpp:210-219:
-     * c_new < minc || hi < minh): a node whose mean concentration is below min_conc or whose TRUE thickness cgH / cgA is below
-     * min_thick is in free drift -- full exposure (a = 1) to wind and ocean drag, Coriolis, its floor mass -- and the stress
+     * c_new < minc || hi < minh): a node whose mean concentration is below min_conc, whose TRUE thickness cgH / cgA is below
+     * min_thick or whose mean thickness is at the mass floor h_min (its mass would be made up) is in free drift -- full exposure (a = 1) to wind and ocean drag, Coriolis, its floor mass -- and the stress
      * divergence of the neighbouring elements is weighted by 2^-100 there.  Both 0: rule off. */
     double min_conc, min_thick;
 } oracle_mevp_params;
@@ -44,7 +44,7 @@ void oracle_transport_step(int nx, int ny, double hx, double hy, int order, doub
  * to hi (for the concentration with hi = 1: convergence beyond a closed cover turns into thickness -- the mean thickness, the
  * conserved volume, is a field of its own and is not touched).  Then the Zhang-Shu scaling limiter: the higher coefficients are
  * scaled by the largest theta in [0, 1] for which the values at the scheme's quadrature points -- (order+1)^2 volume Gauss
- * points and the order+1 Gauss points of each of the four edges -- lie in [lo, hi]; the cell mean is not changed by it.
+ * points, the order+1 Gauss points of each of the four edges and the four corners -- lie in [lo, hi]; the cell mean is not changed by it.
  * hi = +infinity: no upper bound. */
 void oracle_transport_limit(int nx, int ny, int j0, int j1, int order, double* phi, double lo, double hi, int cap);
 

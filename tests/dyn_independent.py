@@ -208,7 +208,7 @@ def ice_free(par, h_node, a_node):
     over concentration) below min_thick; the shape of the column model's cut-off"""
     if par.get("min_conc", 0.0) <= 0.0 and par.get("min_thick", 0.0) <= 0.0:
         return False
-    if a_node < par["min_conc"]:
+    if a_node < par["min_conc"] or h_node <= par["h_min"]:  # no cover, or a mass that would be the floor's
         return True
     return h_node / a_node < par["min_thick"]  # a_node >= min_conc > 0 here (min_conc = 0: a_node >= 0, 0 / 0 and x / 0 compare False / as inf)
 
@@ -216,10 +216,12 @@ def ice_free(par, h_node, a_node):
 # ------------------------------------------------------------------------------------------------ closure of the transport
 def limit(F, lo, hi, cap):
     """DESIGN.md section 3.3 on a DG2 field [6, ny, nx], returns a new array: cell means above hi are set to hi (cap), then the
-    higher coefficients are scaled by the largest theta <= 1 that keeps the values at the 9 volume and 12 edge Gauss points in [lo, hi]"""
+    higher coefficients are scaled by the largest theta <= 1 that keeps the values at the 9 volume and 12 edge Gauss points and at the
+    4 corners in [lo, hi]"""
     _, ny, nx = F.shape
     g, _ = gauss_unit(3)
     pts = [(x, y) for y in g for x in g] + [(0.5, s) for s in g] + [(-0.5, s) for s in g] + [(s, 0.5) for s in g] + [(s, -0.5) for s in g]
+    pts += [(x, y) for y in (-0.5, 0.5) for x in (-0.5, 0.5)]  # the corners: every CG2 node of the element is then among the points
     out = F.copy()
     for iy in range(ny):
         for ix in range(nx):

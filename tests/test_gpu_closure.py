@@ -53,6 +53,7 @@ def point_values(f):
     nc = f.shape[0]
     g = {3: [-0.5 / np.sqrt(3.0), 0.5 / np.sqrt(3.0)], 6: [-0.5 * np.sqrt(0.6), 0.0, 0.5 * np.sqrt(0.6)]}[nc]
     pts = [(x, y) for y in g for x in g] + [(0.5, s) for s in g] + [(-0.5, s) for s in g] + [(s, 0.5) for s in g] + [(s, -0.5) for s in g]
+    pts += [(x, y) for y in (-0.5, 0.5) for x in (-0.5, 0.5)]  # ... and the corners
     psi = lambda x, y: (1.0, x, y, x * x - 1.0 / 12.0, y * y - 1.0 / 12.0, x * y)[:nc]
     P = np.array([psi(x, y) for (x, y) in pts])  # [npts, nc]
     return np.einsum("pc,cyx->pyx", P, f)
@@ -207,7 +208,7 @@ def test_ice_free_nodes_drift_freely_and_match_the_oracle(ctx, variant):
     cgh, cga = O.dg_to_cg(nx, ny, H), O.dg_to_cg(nx, ny, A)
     uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
     tax, tay = O.wind_stress(po, *[np.ascontiguousarray(a) for a in bt.wind(0.0)])
-    free = (cga < po.min_conc) | (cgh < po.min_thick * cga)
+    free = (cga < po.min_conc) | (cgh < po.min_thick * cga) | (cgh <= po.h_min)
     inner = np.zeros(shape, bool)
     inner[1:-1, 1:-1] = True
     assert 50 < int((free & inner).sum()) < inner.sum() // 2
@@ -308,3 +309,41 @@ def test_closure_is_active_and_decomposition_independent(gpu, world):
         parts = run_world(world, abi.DEFAULT_MEVP_VARIANT, False, nx, ny, nsub, nsteps, group=2, transport="native", native=True, **kw)
         for k in ("H", "A", "u", "v"):
             assert torch.equal(gather(parts, world, k), ref[k]), k
+
+
+def test_compressible_cover_1024_stays_in_range_for_37_hours(gpu):
+    """The run that left the physical range in rounds 3-5 (profiles/r04_soak_divergence_cause.md, profiles/r05_closure.md): a uniform cover
+    A0 = 0.9, H0 = 0.3 on 1024 x 1024, winter forcing, dynamics + column thermodynamics, dt = 120 s, 120 sub-iterations -- with alpha
+    = beta from the stability bound at Delta_min = 2e-9 (14 438) it fails between step 1000 and 1100 with or without the closure.
+    With the hosts' sub-cycle parameters (alpha = beta = 1500 and the regularisation this mesh needs for it) and the closure it
+    must pass that point inside the physical range: 1100 steps = 36.7 model hours (the full 1600 steps: tools/soak_coupled.py)."""
+    nx = ny = 1024
+    L, dt, nsub, steps = 512e3, 120.0, 120, 1100
+    c = abi.Context(gpu)
+    bt = synthetic.BoxTest(nx, ny, L)
+    sub = bt.subcycle_parameters(dt)
+    assert sub["alpha"] == 1500.0 and 1.5e-7 < sub["delta_min"] < 2.5e-7 and abs(bt.stable_alpha(dt, delta_min=sub["delta_min"]) - 1500.0) < 1e-6
+    c.set_mevp_params(c.mevp_default_params(**sub))
+    core = rowblock.CoupledCore(c, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, gpu, native=True, forcing="winter")
+    cs, cf = synthetic.column_fields_smooth(nx, ny, L)
+    cs = {"hsnow": np.full((ny, nx), 0.05), "tice0": np.full((ny, nx), -8.0)}
+    cf["sst"], cf["sss"] = np.full((ny, nx), -1.76), np.full((ny, nx), 32.0)
+    core.load_column({**cs, **cf})
+    H, A = np.zeros((6, ny, nx)), np.zeros((6, ny, nx))
+    H[0], A[0] = 0.3, 0.9
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    core.load_global(H, A, uo, vo, ua, va)
+    for step in range(steps):
+        core.device_wind(L, step * dt)
+        core.step()
+    torch.cuda.synchronize()
+    for f in (core.u, core.v, core.H, core.A):
+        assert bool(torch.isfinite(f).all())
+    assert 0.01 < float(core.u.abs().max()) < 0.2
+    assert 0.2 < float(core.H[0].min()) and float(core.H[0].max()) < 0.45
+    assert 0.7 < float(core.A[0].min()) and float(core.A[0].max()) <= 1.0
+    vA = point_values(host(core.A[:, ::8, ::8]))
+    assert vA.min() >= -1e-15 and vA.max() <= 1.0 + 1e-15
+    core.close()
+    c.close()

@@ -188,8 +188,7 @@ def test_dynamics_step_executable_matches_python_driver(host_build, gpu, tmp_pat
     nx, ny = nfast, nslow  # the dynamics ABI calls the fast dimension nx
     bt = synthetic.BoxTest(nx, ny)
     ctx = abi.Context(gpu)
-    a = bt.stable_alpha(120.0)
-    ctx.set_mevp_params(ctx.mevp_default_params(alpha=a, beta=a))
+    ctx.set_mevp_params(ctx.mevp_default_params(**bt.subcycle_parameters(120.0)))  # the hosts' policy (DynamicsStep: stableDeltaMin)
     core = rowblock.DynamicsCore(ctx, rowblock.RowBlock(nx, ny), bt.hx, bt.hy, 120.0, nsub, torch.device("cuda"))
     H = np.zeros((6, ny, nx)); H[0] = 0.3
     A = np.zeros((6, ny, nx)); A[0] = 0.9

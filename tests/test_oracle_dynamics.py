@@ -401,6 +401,7 @@ def test_oracle_limiter_properties(order):
     f[1:] = 0.2 * rng.standard_normal((nc - 1, ny, nx)) * (rng.random((ny, nx)) < 0.7)
     g = [-0.5 / np.sqrt(3.0), 0.5 / np.sqrt(3.0)] if order == 1 else [-0.5 * np.sqrt(0.6), 0.0, 0.5 * np.sqrt(0.6)]
     pts = [(x, y) for y in g for x in g] + [(0.5, s) for s in g] + [(-0.5, s) for s in g] + [(s, 0.5) for s in g] + [(s, -0.5) for s in g]
+    pts += [(x, y) for y in (-0.5, 0.5) for x in (-0.5, 0.5)]  # ... and the corners
     psi = lambda x, y: (1.0, x, y, x * x - 1.0 / 12.0, y * y - 1.0 / 12.0, x * y)[:nc]
     P = np.array([psi(x, y) for (x, y) in pts])
     vals = lambda a: np.einsum("pc,cyx->pyx", P, a)

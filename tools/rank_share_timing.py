@@ -51,8 +51,7 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
     ctx = abi.Context(dev)
     L, dt = 512e3, 120.0
     bt = synthetic.BoxTest(nx, ny, L)
-    alpha = bt.stable_alpha(dt)
-    ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+    ctx.set_mevp_params(ctx.mevp_default_params(**bt.subcycle_parameters(dt)))  # the hosts' policy: alpha = beta = 1500 + the mesh's Delta_min
     if os.environ.get("NSDG_SHARE_VARIANT"):  # A/B of the mEVP kernel variants
         ctx.set_mevp_variant(int(os.environ["NSDG_SHARE_VARIANT"]))
     rank = world // 2

@@ -21,7 +21,7 @@ ctx = abi.Context(dev)
 if VARIANT is not None:
     ctx.set_mevp_variant(VARIANT)
 bt = synthetic.BoxTest(nx, ny, L)
-alpha = bt.stable_alpha(dt)
+alpha = bt.subcycle_parameters(dt)["alpha"]
 ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
 blk = rowblock.RowBlock(nx, ny, 0, 1)
 core = rowblock.DynamicsCore(ctx, blk, L / nx, L / ny, dt, nsub, dev)

@@ -27,11 +27,15 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 720
 nx = ny = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 forcing = sys.argv[3] if len(sys.argv) > 3 else "winter"
 L, dt, nsub = 512e3, float(os.environ.get("NSDG_SOAK_DT", "120")), int(os.environ.get("NSDG_SOAK_NSUB", "120"))  # NSDG_SOAK_DT: model time step (experiments on the strength / concentration coupling); NSDG_SOAK_NSUB: sub-iterations per step (how far the sub-cycle is from converged)
-delta_min = float(os.environ.get("NSDG_SOAK_DELTA_MIN", "2e-9"))  # NSDG_SOAK_DELTA_MIN: the regularisation of Delta; alpha = beta follows it (the stability bound goes with 1 / sqrt(Delta_min))
+# NSDG_SOAK_DELTA_MIN: the regularisation of Delta, alpha = beta then follow from the stability bound (2e-9: rounds 1-4); default: the
+# hosts' policy -- alpha = beta = 1500 with the Delta_min the mesh needs for it (synthetic.BoxTest.subcycle_parameters)
+delta_min = float(os.environ["NSDG_SOAK_DELTA_MIN"]) if os.environ.get("NSDG_SOAK_DELTA_MIN") else None
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
-alpha = bt.stable_alpha(dt, delta_min=delta_min) * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # NSDG_ALPHA_SCALE: a wider stability margin than the default 2.4 x the bound
+sub = bt.subcycle_parameters(dt, delta_min=delta_min)
+delta_min = sub["delta_min"]
+alpha = sub["alpha"] * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # NSDG_ALPHA_SCALE: a wider stability margin than the default 2.4 x the bound
 # NSDG_SOAK_CLOSURE: 1 (default) the closure of the product -- ridging cap + scaling limiter in the transport, free drift at ice-free
 # nodes; 0 the bare scheme of rounds 1-4; "transport" / "nodes": only one of the two halves (which one a run needs)
 mode = os.environ.get("NSDG_SOAK_CLOSURE", "1")

@@ -13,8 +13,9 @@ L, dt, nsub = 512e3, 120.0, 120
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
-alpha = bt.stable_alpha(dt) * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # experiment: margin over the stability bound
-ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+sub = bt.subcycle_parameters(dt, delta_min=float(os.environ["NSDG_SOAK_DELTA_MIN"]) if os.environ.get("NSDG_SOAK_DELTA_MIN") else None)
+alpha = sub["alpha"] * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # experiment: margin over the stability bound
+ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha, delta_min=sub["delta_min"]))
 core = rowblock.DynamicsCore(ctx, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, dev, native=True)
 H, A = bt.dg_fields()
 uo, vo = bt.ocean()
