@@ -214,7 +214,7 @@ def cpu_baseline(nsub_full, nx, ny, budget_s=12.0):
     return res
 
 
-KERNEL_SOURCES = ("mevp_fused4.hip", "mevp_fused4p.hip", "mevp_pipeline.h", "mevp_fused3.hip", "mevp_fused2.hip", "mevp_fused.hip", "mevp_common.h", "transport.hip")
+KERNEL_SOURCES = ("mevp_fused4.hip", "mevp_pipeline.h", "mevp_fused.hip", "mevp_common.h", "transport.hip")
 
 
 def kernel_source_hash():
@@ -645,7 +645,7 @@ def main():
     full, twos, ones = core.passes_per_step()
     per_launch = core.per_pass if full else (2 if twos else 1)
     launches = full if full else (twos if twos else ones)  # launches of the dominant kernel per sub-cycle
-    fused_kernel = {4: "mevp_fused4_kernel", 3: "mevp_fused3_kernel", 2: "mevp_fused2_kernel", 1: "mevp_fused_kernel"}[per_launch]
+    fused_kernel = "mevp_fused4_kernel" if per_launch >= 2 else "mevp_fused_kernel"  # passes of 2, 3 and 4 sub-iterations are one kernel
     if rank == 0:
         n_elem = nx * ny
         value = n_elem * args.steps / elapsed

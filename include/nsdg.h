@@ -171,15 +171,15 @@ int64_t nsdg_tiled_len(int32_t nx, int32_t ny, int32_t nc);
 /* shape and cell size of the local element array all following calls refer to */
 int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
 
-/* kernel variant of the mEVP sub-cycle: 0 = two kernels per sub-iteration (element-wise stress,
- * node-gather velocity), 1 = fused marching kernel (one launch per sub-iteration), 2 = fused marching
- * kernel that performs two sub-iterations per pass (nsdg_mevp_iterate2 / nsdg_mevp_subcycle on a whole
- * local array; single sub-iterations and row-range calls use the variant-1 kernel), 3 = three
- * sub-iterations per pass (nsdg_mevp_iterate3 / nsdg_mevp_subcycle; remainders of 2 or 1 sub-iterations use
- * the kernels of variants 2 and 1), 4 = four sub-iterations per pass, one pipeline stage per wave of a four-wave
- * workgroup with the hand-over in LDS (nsdg_mevp_iterate4 / nsdg_mevp_subcycle; remainders of 3, 2 or 1 sub-iterations
- * use the kernels of variants 3, 2 and 1); NSDG_MEVP_DEFAULT_VARIANT (4) is the default of a new context.  Variants 1, 2,
- * 3 and 4 agree bit for bit, variant 0 to fp64 round-off. */
+/* kernel variant of the mEVP sub-cycle = the largest number of sub-iterations a kernel pass may perform:
+ * 0 = two kernels per sub-iteration (element-wise stress, node-gather velocity); 1 = fused marching kernel, one launch per
+ * sub-iteration (the bitwise reference of the multi-iteration passes); 2, 3, 4 = up to that many sub-iterations per pass on the
+ * stage-per-wave pipeline (csrc/mevp_fused4.hip: one pipeline stage per wave of a four-wave workgroup, hand-over point to point
+ * through LDS; nsdg_mevp_iterate2 / 3 / 4, nsdg_mevp_subcycle; what is left of a sub-cycle whose length is no multiple of the
+ * variant runs as a shorter pass of the same kernel, a single sub-iteration on the kernel of variant 1).
+ * NSDG_MEVP_DEFAULT_VARIANT (4) is the default of a new context.  Variants 1, 2, 3 and 4 agree bit for bit, variant 0 to fp64
+ * round-off.  (Rounds 1-4 had kernels of their own for 2 and 3 sub-iterations per pass -- two / three stages in ONE wave --
+ * and a four-stage kernel with one workgroup barrier per march step: superseded, see the history of csrc/.) */
 #define NSDG_MEVP_DEFAULT_VARIANT 4
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
 
@@ -307,14 +307,14 @@ int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const d
  * the nodes they own; the intermediate stress and velocity never leave the registers.  j0 == 0 (physical
  * boundary) or j0 >= 2 (two ghost rows below); above, one ghost row or the physical boundary (j1 == ny).
  * A multi-rank driver refreshes the ghost rows of S_out and u_new after every pass (or runs k passes on row ranges
- * shrinking by 2 rows per side and pass on a (2k, 2k-1)-row ghost zone).  Requires variant 2 or 3. */
+ * shrinking by 2 rows per side and pass on a (2k, 2k-1)-row ghost zone).  Requires variant >= 2. */
 int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
     const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
     double* u_new, double* v_new, const double* packed, const double* pg);
 
 /* THREE complete sub-iterations in one pass on the owned element rows [j0, j1): reads S_in, u_old on rows
  * j0-3 .. j1+1 and writes S_out = S^{p+3} on rows [j0, j1) and u_new = u^{p+3} on the nodes they own.  j0 == 0
- * or j0 >= 3 (three ghost rows below); j1 == ny or j1 + 2 <= ny (two ghost rows above).  Requires variant 3. */
+ * or j0 >= 3 (three ghost rows below); j1 == ny or j1 + 2 <= ny (two ghost rows above).  Requires variant >= 3. */
 int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
     const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
     double* u_new, double* v_new, const double* packed, const double* pg);

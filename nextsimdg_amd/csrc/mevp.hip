@@ -346,24 +346,10 @@ static inline bool aligned16(std::initializer_list<const void*> ptrs)
 }
 #define NSDG_CHECK_TILED(...) NSDG_CHECK_ARG(aligned16({ __VA_ARGS__ }), "tiled arrays (stress, ice strength) must be 16-byte aligned")
 
-// defined in mevp_fused3.hip
-int nsdg_launch_mevp_fused3(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
-    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
-int nsdg_launch_mevp_fused3_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
+// defined in mevp_fused4.hip: a pass of nst = 2, 3 or 4 sub-iterations on the rows [j0, j1) and, if j0b < j1b, on a second disjoint range
+int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg);
-// defined in mevp_fused4.hip
-int nsdg_launch_mevp_fused4(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
-    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
-int nsdg_launch_mevp_fused4p_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
-    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
-    const double* pg);
-int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
-    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
-    const double* pg);
-// defined in mevp_fused2.hip
-int nsdg_launch_mevp_fused2(nsdg_ctx* ctx, int j0, int j1, const double* s11i, const double* s12i, const double* s22i, double* s11, double* s12,
-    double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
 
 static NodalConsts nodal_consts(const nsdg_ctx* ctx)
 {
@@ -540,10 +526,8 @@ int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    if (ctx->mevp_variant >= 2 && ctx->f4_p2p) // a pass of the stage-per-wave pipeline with two stages
-        return nsdg_launch_mevp_fused4p_ranges(ctx, 2, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-    if (ctx->mevp_variant >= 2)
-        return nsdg_launch_mevp_fused2(ctx, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
+    if (ctx->mevp_variant >= 2) // a pass of the stage-per-wave pipeline with two stages
+        return nsdg_launch_mevp_fused4_ranges(ctx, 2, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     nsdg_set_error("nsdg_mevp_iterate2: select variant 2, 3 or 4 (nsdg_mevp_variant_set) or call nsdg_mevp_iterate twice");
     return NSDG_ERR_STATE;
 }
@@ -568,10 +552,8 @@ int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    if (ctx->mevp_variant >= 3 && ctx->f4_p2p) // ... with three stages
-        return nsdg_launch_mevp_fused4p_ranges(ctx, 3, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-    if (ctx->mevp_variant >= 3)
-        return nsdg_launch_mevp_fused3(ctx, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
+    if (ctx->mevp_variant >= 3) // ... with three stages
+        return nsdg_launch_mevp_fused4_ranges(ctx, 3, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     nsdg_set_error("nsdg_mevp_iterate3: select variant 3 or 4 (nsdg_mevp_variant_set)");
     return NSDG_ERR_STATE;
 }
@@ -601,9 +583,7 @@ int nsdg_mevp_iterate3_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
         return NSDG_ERR_STATE;
     }
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    if (ctx->f4_p2p)
-        return nsdg_launch_mevp_fused4p_ranges(ctx, 3, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-    return nsdg_launch_mevp_fused3_ranges(ctx, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
+    return nsdg_launch_mevp_fused4_ranges(ctx, 3, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
 }
 
 int nsdg_mevp_iterate4(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i, const double* s12i, const double* s22i,
@@ -627,7 +607,7 @@ int nsdg_mevp_iterate4(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     if (ctx->mevp_variant == 4)
-        return nsdg_launch_mevp_fused4(ctx, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
+        return nsdg_launch_mevp_fused4_ranges(ctx, 4, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     nsdg_set_error("nsdg_mevp_iterate4: select variant 4 (nsdg_mevp_variant_set)");
     return NSDG_ERR_STATE;
 }
@@ -657,7 +637,7 @@ int nsdg_mevp_iterate4_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
         return NSDG_ERR_STATE;
     }
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    return nsdg_launch_mevp_fused4_ranges(ctx, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
+    return nsdg_launch_mevp_fused4_ranges(ctx, 4, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
 }
 
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u, double* v,

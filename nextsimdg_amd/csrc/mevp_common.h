@@ -5,45 +5,6 @@
 #include "dg_tables.h"
 #include "nsdg_internal.h"
 
-#ifdef NSDG_STAMPS
-// Diagnostic build only (tools/ab_build.sh stamps -DNSDG_STAMPS): per-phase shader-cycle totals of one march,
-// s_memtime stamps fenced by scheduling barriers.  Never defined in the product build.
-#define NSDG_STAMP(k)                                            \
-    do {                                                         \
-        __builtin_amdgcn_sched_barrier(0);                       \
-        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
-        stamp_acc[k] += now_ - stamp_last;                       \
-        stamp_last = now_;                                       \
-        __builtin_amdgcn_sched_barrier(0);                       \
-    } while (0)
-#define NSDG_STAMP_ARGS , unsigned (&stamp_acc)[12], unsigned& stamp_last
-#define NSDG_STAMP_PASS , stamp_acc, stamp_last
-#ifdef NSDG_STAMPS_BARRIER
-// only the stamps that bracket the barrier calls of mevp_fused4.hip: how long does each wave wait for the others?
-#undef NSDG_STAMP
-#define NSDG_STAMP(k)                                                                                                  \
-    do {                                                                                                               \
-        if (NSDG_STAMPS_BARRIER == 1 ? ((k) == 1 || (k) == 2 || (k) == 10 || (k) == 4 || (k) == 11 || (k) == 6 || (k) == 7 || (k) == 8) \
-                                     : (k) == 8) { /* 2: one stamp per march step -- the effective shader clock of the unperturbed kernel */ \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
-            const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();                                              \
-            stamp_acc[k] += now_ - stamp_last;                                                                         \
-            stamp_last = now_;                                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
-        }                                                                                                              \
-    } while (0)
-#endif
-#elif defined(NSDG_PHASE_FENCE)
-// scheduling fences at the phase boundaries only (experiment: keeps the compiler from interleaving phases)
-#define NSDG_STAMP(k) __builtin_amdgcn_sched_barrier(0)
-#define NSDG_STAMP_ARGS
-#define NSDG_STAMP_PASS
-#else
-#define NSDG_STAMP(k)
-#define NSDG_STAMP_ARGS
-#define NSDG_STAMP_PASS
-#endif
-
 namespace nsdg_mevp_detail {
 
 using namespace nsdg_tab;

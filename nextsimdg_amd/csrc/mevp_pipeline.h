@@ -1,5 +1,5 @@
-// mevp_pipeline.h -- pieces shared by the pipelined multi-iteration mEVP kernels (mevp_fused3.hip: three stages in one
-// wave; mevp_fused4.hip: four stages on the four waves of a workgroup): the per-lane march constants, the contributions a
+// mevp_pipeline.h -- pieces of the pipelined multi-iteration mEVP kernel (mevp_fused4.hip: the stages of a pass on the waves of a
+// workgroup; rounds 1-4 also had two / three stages in ONE wave, csrc/mevp_fused2.hip / mevp_fused3.hip in the history): the per-lane march constants, the contributions a
 // row carries to the row above it, the update of the four owned nodes of an element row and the gather of an element's
 // nine nodal velocities from the owned nodes of its row, of the row above and of the right neighbour lane.  The same
 // inlined functions in every variant keep their results bit-identical.

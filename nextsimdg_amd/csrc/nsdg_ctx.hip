@@ -87,10 +87,6 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
     c->mevp_variant = NSDG_MEVP_DEFAULT_VARIANT;
     c->strip_rows = 0;
     {
-        const char* v = std::getenv("NSDG_F4_P2P");
-        c->f4_p2p = (v && *v) ? std::atoi(v) : 1; // default: point to point; NSDG_F4_P2P=0: the round-4 kernel (one barrier per march step), for A/B
-    }
-    {
         hipDeviceProp_t prop;
         c->num_cus = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }

@@ -22,7 +22,6 @@ struct nsdg_ctx {
     int num_cus;
     double pack_dt; // time step the packed nodal coefficients were built for (0 = never packed)
     int transport_variant, transport_rows; // transport stage kernel: 0 one element per lane / 2 two elements per lane; rows per workgroup
-    int f4_p2p; // variant 4: hand-over point to point (mevp_fused4p.hip) instead of one barrier per march step (environment NSDG_F4_P2P, A/B)
     int fused_min_waves; // register budget of the fused kernel: 1 or 2 waves per SIMD
     int nbounds; // closure of a transport step: bounds of the advected fields (0 = none), nsdg_transport_bounds_set
     nsdg_field_bounds bounds[4];

@@ -30,7 +30,7 @@ def gpu():
 
 @pytest.fixture(scope="session", autouse=True)
 def _no_pipeline_wait_gave_up():
-    """the point-to-point mEVP pipeline (csrc/mevp_fused4p.hip) bounds every wait and counts the waits that gave up: after a GPU
+    """the point-to-point mEVP pipeline (csrc/mevp_fused4.hip) bounds every wait and counts the waits that gave up: after a GPU
     session the counter must be zero (a non-zero count means a dependency was waited for that never came: wrong results)"""
     yield
     import ctypes

@@ -68,7 +68,7 @@ class OracleOps:
 
     def mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         """two sub-iterations on the owned rows [j0, j1), reading two rows below / one above, exactly the
-        dependency region of the two-iterations-per-pass kernel (csrc/mevp_fused2.hip)"""
+        dependency region of a two-stage pass of the pipelined kernel (csrc/mevp_fused4.hip, nst = 2)"""
         dt, u0v0, tau, ocean, cgh, cga = self.nodal
         ny = self.ny
         a0, a1 = max(j0 - 2, 0), min(j1, ny - 1)  # rows of sub-iteration p
@@ -85,7 +85,7 @@ class OracleOps:
 
     def mevp_iterate3(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         """three sub-iterations on the owned rows [j0, j1), reading three rows below / two above, exactly the
-        dependency region of the three-iterations-per-pass kernel (csrc/mevp_fused3.hip)"""
+        dependency region of a three-stage pass of the pipelined kernel (csrc/mevp_fused4.hip, nst = 3)"""
         dt, u0v0, tau, ocean, cgh, cga = self.nodal
         ny = self.ny
         top = lambda r: min(r, ny - 1) + 1  # exclusive end of a row range clipped to the array
