@@ -37,6 +37,28 @@
 namespace nsdg_mevp_detail {
 
 __device__ unsigned nsdg_p2p_timeouts_dev = 0;
+#ifdef NSDG_P2P_SPINSTAT
+// diagnostic build only (tools/ab_build.sh spin -DNSDG_P2P_SPINSTAT; tools/p2p_spinstat.py): polls per stage and kind of wait -- 0 the
+// previous stage's hand-over, 1 a free hand-over slot, 2 a free ring slot -- and the rows the stage worked on in [3]
+__device__ unsigned long long nsdg_p2p_spin_dev[4][4];
+__device__ unsigned long long nsdg_p2p_phase_dev[4][8]; // shader cycles per stage and phase of a row (s_memtime, fenced)
+#define NSDG_SPIN_ARG , unsigned (&spins)[3], unsigned (&phase)[8], unsigned& stamp_last
+#define NSDG_SPIN_PASS , spins, phase, stamp_last
+#define NSDG_SPIN_COUNT(k, n) spins[k] += (n)
+#define NSDG_PHASE(k)                                                   \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime();   \
+        phase[k] += now_ - stamp_last;                                  \
+        stamp_last = now_;                                              \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#else
+#define NSDG_PHASE(k)
+#define NSDG_SPIN_ARG
+#define NSDG_SPIN_PASS
+#define NSDG_SPIN_COUNT(k, n) (void)(n) /* the wait itself is the argument: it must stay */
+#endif
 
 struct StressPtrsP {
     const double *i11, *i12, *i22;
@@ -87,20 +109,19 @@ __device__ __forceinline__ int flag_peek(const volatile lds_int* p)
     return __builtin_amdgcn_readfirstlane(x);
 }
 // the counter *p has reached `need` (or the workgroup has given up)
-__device__ __forceinline__ void flag_wait(volatile lds_int* flags, int which, int need)
+__device__ __forceinline__ int flag_wait(volatile lds_int* flags, int which, int need) // returns the polls it took beyond the first
 {
     if (flag_peek(flags + which) >= need)
-        return;
+        return 0;
     for (int spin = 0; spin < NSDG_P2P_SPIN_LIMIT; ++spin) {
-#ifndef NSDG_P2P_NOSLEEP
         __builtin_amdgcn_s_sleep(1);
-#endif
         if (flag_peek(flags + which) >= need || flag_peek(flags + 6) != 0)
-            return;
+            return spin + 1;
     }
     flags[6] = 1; // give up: release everybody, count the event
     if ((threadIdx.x & 63) == 0)
         atomicAdd(&nsdg_p2p_timeouts_dev, 1u);
+    return NSDG_P2P_SPIN_LIMIT;
 }
 // everything this wave has written to LDS so far is visible before the counter moves
 __device__ __forceinline__ void flag_publish(volatile lds_int* flags, int which, int value)
@@ -188,7 +209,7 @@ __device__ __forceinline__ void ring_write_P(double* __restrict__ ring, int row,
 template <bool FIRST>
 __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, int row, FetchP& f, TopCarry3& carry, double* __restrict__ lds,
     volatile lds_int* flags, const StressPtrsP& S, const double* __restrict__ u_old, const double* __restrict__ v_old,
-    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
+    const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new NSDG_SPIN_ARG)
 {
     const int stage = FIRST ? 0 : G.s;
     const int nrow = min(row + 1, G.last); // the row this stage works on next: its inputs are requested during this one
@@ -217,7 +238,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         vv[0] = vl[0], vv[1] = vl[1], vv[2] = vl[3], vv[3] = vl[4];
     } else {
         // the previous stage has handed over this row and the row above it (whose bottom nodes are this row's top nodes)
-        flag_wait(flags, stage - 1, min(row + 1, G.last_prev));
+        NSDG_SPIN_COUNT(0, flag_wait(flags, stage - 1, min(row + 1, G.last_prev)));
         if (row == G.first) { // wave-uniform: the first row of the stage has no predecessor that requested its inputs
             ring_read_P(ring, row, M.lane, f.P);
             request_c(row);
@@ -235,18 +256,18 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         gather_nodes(M, uu, tu.x, tu.y, ul);
         gather_nodes(M, vv, tv.x, tv.y, vl);
     }
+    NSDG_PHASE(0); // inputs of the row (stages >= 1: the wait for the previous stage, LDS reads)
     // ------------------------------------------------------------------------------------------ stress update
     double r11[8], r12[8], r22[8];
     stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
     __builtin_amdgcn_sched_barrier(0);
+    NSDG_PHASE(1); // projected stress
     if (FIRST) {
         // the ice strength of this row goes to the ring for the stages 1-3 (slot of row - 8: stage 3 has passed it), then the
         // register set takes the next row's; u, v of the next row
-        flag_wait(flags, 3 + G.nst - 2, min(row - P4_PRING, G.last_final)); // read[] of the LAST link: the last stage has passed that row
+        NSDG_SPIN_COUNT(2, flag_wait(flags, 3 + G.nst - 2, min(row - P4_PRING, G.last_final))); // read[] of the LAST link: the last stage has passed that row
         ring_write_P(ring, row, M.lane, f.P);
-#ifndef NSDG_P2P_CLATE
         ring_write_c(cring, row, M.lane, f.c); // this row's coefficients were requested a step ago; the stages 1-3 take the pair from here
-#endif
         tile_load9(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P);
         if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
 #pragma unroll
@@ -271,6 +292,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         // this row's slot (stress, u, v) and the next row's ice strength have been taken: the producer may write row + 2 into the slot
         flag_publish(flags, 3 + stage - 1, row);
     }
+    NSDG_PHASE(2); // loader: ring wait, ring writes, requests of P, u, v; stages: ring read, stress read, read[] published
     stress_relax(M.ialpha, r11, r12, r22, s11, s12, s22);
     __builtin_amdgcn_sched_barrier(0);
     if (FIRST) { // stress of the next row
@@ -279,6 +301,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         tile_load8(S.i12, ts, f.s12);
         tile_load8(S.i22, ts, f.s22);
     }
+    NSDG_PHASE(3); // relaxation, (loader) stress request
     // ------------------------------------------------------------------------------------------ contributions, node updates
     {
         double cx[9], cy[9];
@@ -292,14 +315,12 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         carry_top(carry, cx, cy);
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifdef NSDG_P2P_CLATE
-    if (FIRST)
-        ring_write_c(cring, row, M.lane, f.c);
-#endif
+    NSDG_PHASE(4); // contributions, node updates (the wait for the nodal coefficients is here)
     request_c(nrow); // nodal coefficients of the next row
+    NSDG_PHASE(5); // request of the coefficients
     // ------------------------------------------------------------------------------------------ outputs
     if (FIRST || stage < G.nst - 1) {
-        flag_wait(flags, 3 + stage, row - P4_HSLOTS); // the consumer has taken the row this slot held
+        NSDG_SPIN_COUNT(1, flag_wait(flags, 3 + stage, row - P4_HSLOTS)); // the consumer has taken the row this slot held
         double* out = lds + (stage * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -334,6 +355,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
                 u_new[nV + 2 * nn + 2] = 0., v_new[nV + 2 * nn + 2] = 0.;
         }
     }
+    NSDG_PHASE(6); // outputs: slot wait, LDS writes, done[] published / global stores
 }
 
 __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw,
@@ -397,6 +419,10 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
 
     FetchP f;
     TopCarry3 carry;
+#ifdef NSDG_P2P_SPINSTAT
+    unsigned spins[3] = { 0, 0, 0 }, phase[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned stamp_last = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
     if (G.s == 0) {
         const int row = G.first;
         const long nV = (long)(2 * row) * M.nn + 2 * M.ix, ts = tile_off(M.ix, row, M.ntx, 8);
@@ -412,11 +438,20 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
         tile_load9(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
         request_c_p(M, row, f.c, packed);
         for (int row = G.first; row <= G.last; ++row)
-            p2p_row<true>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new);
+            p2p_row<true>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
     } else {
         for (int row = G.first; row <= G.last; ++row)
-            p2p_row<false>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new);
+            p2p_row<false>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
     }
+#ifdef NSDG_P2P_SPINSTAT
+    if (lane == 0) {
+        for (int k = 0; k < 3; ++k)
+            atomicAdd(&nsdg_p2p_spin_dev[G.s][k], (unsigned long long)spins[k]);
+        atomicAdd(&nsdg_p2p_spin_dev[G.s][3], (unsigned long long)(G.last - G.first + 1));
+        for (int k = 0; k < 8; ++k)
+            atomicAdd(&nsdg_p2p_phase_dev[G.s][k], (unsigned long long)phase[k]);
+    }
+#endif
 }
 
 } // namespace nsdg_mevp_detail
@@ -432,6 +467,21 @@ extern "C" int nsdg_debug_p2p_timeouts(unsigned* out)
         e = hipMemcpyToSymbol(HIP_SYMBOL(nsdg_p2p_timeouts_dev), &zero, sizeof(unsigned));
     return (int)e;
 }
+
+#ifdef NSDG_P2P_SPINSTAT
+extern "C" int nsdg_debug_p2p_spinstat(unsigned long long* out48) // [16] polls, then [32] phase cycles
+{
+    static const unsigned long long zero[32] = { 0 };
+    hipError_t e = hipMemcpyFromSymbol(out48, HIP_SYMBOL(nsdg_p2p_spin_dev), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemcpyFromSymbol(out48 + 16, HIP_SYMBOL(nsdg_p2p_phase_dev), 32 * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemcpyToSymbol(HIP_SYMBOL(nsdg_p2p_spin_dev), zero, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemcpyToSymbol(HIP_SYMBOL(nsdg_p2p_phase_dev), zero, 32 * sizeof(unsigned long long));
+    return (int)e;
+}
+#endif
 
 int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i,
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,

@@ -51,7 +51,7 @@ def main():
              "mevp_pack_nodal_kernel": (8 * 8 * nn, 6 * 8 * nn)}
     L = ["# HBM traffic, %dx%d, %s\n\n" % (nx, ny, note),
          "Two separate passes (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`) of `rocprofv3 --kernel-trace --output-format csv -- python bench.py "
-         "--steps 1 --warmup 0 --nsub 6 --no-cpu-baseline`; counter unit KB.\n\n"
+         "--steps 1 --warmup 0 --nsub 8 --no-cpu-baseline`; counter unit KB.\n\n"
          "Calibration in this access pattern (8 B/lane unit-stride) on kernels with exactly known traffic:\n\n"
          "| kernel | known read KB | FETCH_SIZE | ratio | known write KB | WRITE_SIZE | ratio |\n|---|---|---|---|---|---|---|\n"]
     for k, (r, w) in known.items():
