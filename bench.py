@@ -622,6 +622,10 @@ def main():
         ok = torch.tensor([float(bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())), float(core.u.abs().max())],
                           dtype=torch.float64, device=device)
         guard = None if args.no_guard else fused_pass_guard(ctx, core)
+        gave_up = ctx.pipeline_waits_given_up()  # bounded waits of the stage-per-wave pipeline that hit their bound: must be none
+        if gave_up:
+            guard = False
+            sys.stderr.write("bench.py rank %d: %d wait(s) of the mEVP pipeline gave up\n" % (rank, gave_up))
         ok = torch.cat([ok, torch.tensor([float(guard is not False)], dtype=torch.float64, device=device)])
         if use_dist:
             lo = ok.clone()
@@ -631,7 +635,8 @@ def main():
         if ok[0] == 0.0 or ok[1] == 0.0:
             raise SystemExit("bench produced non-finite or trivial fields: invalid run")
         if ok[2] == 0.0:
-            raise SystemExit("bench: one pass of the fused kernel differs from single sub-iterations on the live state: invalid run")
+            raise SystemExit("bench: one pass of the fused kernel differs from single sub-iterations on the live state (or a wait of its pipeline "
+                         "gave up): invalid run")
 
     except (abi.NsdgError, RuntimeError) as e:
         # a failed launch, a broken communicator, a device error, a collective of the reduction / validity part that a dead rank

@@ -551,6 +551,16 @@ class Context:
         self._call(self.lib.nsdg_transport_step_oop_rows(self.h, order, j0, j1, float(dt), len(fields_in), _ptr_array(fields_in),
                                                          _ptr_array(fields_out), *[_ptr(t) for t in adv]))
 
+    def pipeline_waits_given_up(self):
+        """waits of the point-to-point mEVP pipeline (csrc/mevp_fused4.hip) that gave up since the last call: 0 in a correct program
+        (a non-zero count means wrong results of the launches in between); synchronises the device"""
+        n = C.c_uint(0)
+        fn = self.lib.nsdg_debug_p2p_timeouts
+        fn.argtypes = [C.POINTER(C.c_uint)]
+        if fn(C.byref(n)) != 0:
+            raise NsdgError("nsdg_debug_p2p_timeouts failed")
+        return int(n.value)
+
     def set_transport_bounds(self, bounds):
         """closure of a transport step: one (lo, hi, cap_mean) per advected field, in the order of the step calls' field lists;
         () or None = none.  abi.H_A_BOUNDS: the dynamics' H and A"""

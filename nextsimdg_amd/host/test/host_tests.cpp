@@ -349,6 +349,17 @@ static void test_physics_config()
     nsphys.configure();
 }
 
+static void test_subcycle_policy()
+{ // alpha = beta = 1500 with the smallest Delta_min for which it is stable on the mesh, and the way back
+    for (double h : { 125., 250., 500. }) {
+        const double dmin = DynamicsStep::stableDeltaMin(h, 120., 1500.);
+        CHECK(dmin > 2e-9 && approx(DynamicsStep::stableAlpha(h, 120., dmin), 1500., 1e-9));
+    }
+    CHECK(approx(DynamicsStep::stableDeltaMin(250., 120.), 7.41e-7, 2e-3) && approx(DynamicsStep::stableDeltaMin(500., 120.), 1.853e-7, 2e-3));
+    CHECK(DynamicsStep::stableDeltaMin(8000., 120.) == 2e-9); // coarse meshes keep the literature's regularisation
+    CHECK(approx(DynamicsStep::stableAlpha(250., 120.), 28875., 1e-3)); // ... which on a fine mesh asks for the alpha of rounds 1-4
+}
+
 static void test_structure()
 { // core/test/DevGrid_test.cpp:24-103, StructureFactory_test.cpp:19-47, ElementData_test.cpp:57-63
     Configurator::clear();
@@ -841,6 +852,7 @@ int main(int argc, char** argv)
             test_iterator();
             test_timer();
             test_physics_config();
+            test_subcycle_policy();
             test_structure();
             test_restart_hdf5();
             test_rendezvous();
