@@ -390,6 +390,10 @@ def transport_bench(args, device):
                      "compulsory_bytes_per_launch": compulsory if fused else alg / stages,
                      "algorithmic_bytes_per_launch": alg if fused else alg / stages,
                      "survey_8d_ratio": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "working_set_bytes": int(2 * phi.size * 8 + sum(a.numel() for a in adv) * 8),
+                     "working_set_note": ("field in + field out + velocities of this grid fit into the 256 MB Infinity Cache: `frac` compares a cache-resident "
+                                          "launch with the HBM peak -- a throughput figure, not a statement about HBM") if (2 * phi.size * 8 + sum(a.numel() for a in adv) * 8) < 256e6
+                     else "larger than the 256 MB Infinity Cache: the bytes come from HBM",
                      "avg_launch_ms": ms if fused else ms / stages, "launches_per_step": 1 if fused else stages,
                      "self_check": "fused-stages step == staged step bitwise on the live field" if fused else None},
         "cpu_baseline": {"value": cpu, "unit": "element-steps/s", "cores": 1, "kind": "port",

@@ -144,7 +144,15 @@ int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hice, double* 
  *      by scaling its higher coefficients; cell means are never changed;
  *   3. ice-free nodes (nsdg_mevp_params.min_conc / min_thick) are in free drift and do not feel their neighbours' stress.
  * 1 and 2 are per-field properties the host states with nsdg_transport_bounds_set (they are OFF until it does: the library does
- * not know which field is a concentration); 3 is ON by default.  The calls still do not check their inputs; both hosts stop
+ * not know which field is a concentration); 3 is ON by default.
+ * What the closure does NOT replace is a sub-cycle that can follow the forcing (profiles/r05_closure.md): alpha = beta must satisfy
+ * alpha beta >= 2.4^2 pi^2 P* dt / (2 delta_min rho_ice h^2) (linear stability, with the margin a one-day run needs), and with the
+ * literature's delta_min = 2e-9 on a mesh finer than ~2 km that is an alpha of 10^4 ... 10^5, under which 120 sub-iterations
+ * move stress and velocity less than 1 % of the way per model step -- a compressible cover (A < 1) then leaves the physical range
+ * within a model day or two with or without the closure.  The hosts of this repository therefore keep alpha = beta = 1500 and
+ * raise delta_min to the smallest value for which that is stable on the mesh (DynamicsStep::stableDeltaMin,
+ * synthetic.BoxTest.subcycle_parameters): 1.9e-7 / 7.4e-7 / 3.0e-6 1/s at 500 / 250 / 125 m.  With that, a uniform cover A = 0.9
+ * completes 53 model hours at 1024 x 1024 and the model day at 4096 x 4096.  The calls do not check any of this; both hosts stop
  * loudly on non-finite fields. */
 typedef struct {
     double rho_ice, rho_atm, rho_ocean;
@@ -345,6 +353,13 @@ int nsdg_mevp_iterate4_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u,
     double* v, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
     const double* vo, const double* cgh, const double* cga, const double* pg, double* scratch);
+
+/* The waits of the stage-per-wave pipeline (csrc/mevp_fused4.hip) are bounded: a wave that waits for a hand-over longer than ~0.2 s
+ * gives up, releases the other waits of its workgroup and counts the event -- the launch then finishes with WRONG results instead
+ * of hanging the GPU.  This call waits for the context's stream and returns the number of such events since the last call (and
+ * resets it): 0 in a correct program; a host checks it where it checks its fields for finiteness (DynamicsStep::stop, bench.py,
+ * the test session). */
+int nsdg_mevp_pipeline_health(nsdg_ctx* ctx, uint32_t* waits_given_up);
 
 /* rows per strip of the fused marching kernel (performance knob; results do not depend on it);
  * 0 (default) = chosen per launch from the row count and the number of resident wave slots */

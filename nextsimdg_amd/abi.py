@@ -120,6 +120,7 @@ SYMBOLS = {
     "nsdg_mevp_iterate3_pair": (C.c_int, [VP, I32, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate4": (C.c_int, [VP, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate4_pair": (C.c_int, [VP, I32, I32, I32, I32] + [VP] * 12),
+    "nsdg_mevp_pipeline_health": (C.c_int, [VP, C.POINTER(C.c_uint32)]),
     "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_occupancy_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_subcycle": (C.c_int, [VP, D, I32] + [VP] * 15),
@@ -553,12 +554,9 @@ class Context:
 
     def pipeline_waits_given_up(self):
         """waits of the point-to-point mEVP pipeline (csrc/mevp_fused4.hip) that gave up since the last call: 0 in a correct program
-        (a non-zero count means wrong results of the launches in between); synchronises the device"""
-        n = C.c_uint(0)
-        fn = self.lib.nsdg_debug_p2p_timeouts
-        fn.argtypes = [C.POINTER(C.c_uint)]
-        if fn(C.byref(n)) != 0:
-            raise NsdgError("nsdg_debug_p2p_timeouts failed")
+        (a non-zero count means wrong results of the launches in between); waits for the context's stream"""
+        n = C.c_uint32(0)
+        self._call(self.lib.nsdg_mevp_pipeline_health(self.h, C.byref(n)))
         return int(n.value)
 
     def set_transport_bounds(self, bounds):

@@ -29,7 +29,7 @@
 // dependency graph of the march (row r of stage k + 1 waits for row r + 1 of stage k; row r of stage k waits for row r - 2 of stage
 // k + 1, which waited for row r - 1 of stage k), so no wave can wait for ever -- and, should that reasoning ever be wrong, a
 // wait gives up after NSDG_P2P_SPIN_LIMIT polls, raises a sticky flag that releases every other wait of the workgroup, and counts
-// the event in a device counter the tests read (nsdg_debug_p2p_timeouts): a wrong result, never a hung GPU.
+// the event in a device counter the hosts read (nsdg_mevp_pipeline_health): a wrong result that is reported, never a hung GPU.
 //
 // The arithmetic is the same sequence of inlined functions as in every other variant: bit-identical to four passes of variant 1.
 #include "mevp_pipeline.h"
@@ -458,14 +458,17 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
 
 using namespace nsdg_mevp_detail;
 
-// events in which a wait of the point-to-point pipeline gave up since the last call (0 in a correct program); resets the counter
-extern "C" int nsdg_debug_p2p_timeouts(unsigned* out)
+// waits of the pipeline that gave up since the last call (0 in a correct program); resets the counter; include/nsdg.h
+extern "C" int nsdg_mevp_pipeline_health(nsdg_ctx* ctx, uint32_t* waits_given_up)
 {
-    unsigned zero = 0;
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(nsdg_p2p_timeouts_dev), sizeof(unsigned));
-    if (e == hipSuccess)
-        e = hipMemcpyToSymbol(HIP_SYMBOL(nsdg_p2p_timeouts_dev), &zero, sizeof(unsigned));
-    return (int)e;
+    NSDG_CHECK_ARG(ctx && waits_given_up, "null argument");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    NSDG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned n = 0, zero = 0;
+    NSDG_CHECK_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(nsdg_p2p_timeouts_dev), sizeof(unsigned)));
+    NSDG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(nsdg_p2p_timeouts_dev), &zero, sizeof(unsigned)));
+    *waits_given_up = n;
+    return NSDG_OK;
 }
 
 #ifdef NSDG_P2P_SPINSTAT

@@ -410,6 +410,10 @@ void DynamicsStep::stop(const Iterator::TimePoint&)
         DynamicsBlock& b = *bp;
         checkHip(hipSetDevice(b.device), "hipSetDevice");
         check(nsdg_ctx_synchronize(b.ctx), "DynamicsStep::stop");
+        uint32_t gaveUp = 0; // bounded waits of the mEVP pipeline that hit their bound: the fields would be wrong
+        check(nsdg_mevp_pipeline_health(b.ctx, &gaveUp), "nsdg_mevp_pipeline_health");
+        if (gaveUp)
+            throw std::runtime_error("DynamicsStep: " + std::to_string(gaveUp) + " wait(s) of the mEVP pipeline gave up: the fields are not to be trusted");
         const std::size_t first = (std::size_t)b.r0 * b.nx, count = (std::size_t)(b.r1 - b.r0) * b.nx, skip = (std::size_t)b.j0 * b.nx;
         checkHip(hipMemcpy(f.hice.data() + first, b.curH() + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download H");
         checkHip(hipMemcpy(f.cice.data() + first, b.curA() + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download A");

@@ -30,17 +30,17 @@ def gpu():
 
 @pytest.fixture(scope="session", autouse=True)
 def _no_pipeline_wait_gave_up():
-    """the point-to-point mEVP pipeline (csrc/mevp_fused4.hip) bounds every wait and counts the waits that gave up: after a GPU
-    session the counter must be zero (a non-zero count means a dependency was waited for that never came: wrong results)"""
+    """the point-to-point mEVP pipeline (csrc/mevp_fused4.hip) bounds every wait and counts the waits that gave up
+    (nsdg_mevp_pipeline_health): after a GPU session the counter must be zero (a non-zero count means a dependency was waited
+    for that never came: wrong results)"""
     yield
-    import ctypes
-
     import torch
 
     from nextsimdg_amd import abi
 
-    if abi._lib is None or not torch.cuda.is_available() or not hasattr(abi._lib, "nsdg_debug_p2p_timeouts"):
+    if abi._lib is None or not torch.cuda.is_available():
         return
-    n = ctypes.c_uint(0)
-    rc = abi._lib.nsdg_debug_p2p_timeouts(ctypes.byref(n))
-    assert rc == 0 and n.value == 0, "the mEVP pipeline gave up %d wait(s)" % n.value
+    ctx = abi.Context(torch.device("cuda:0"))
+    n = ctx.pipeline_waits_given_up()
+    ctx.close()
+    assert n == 0, "the mEVP pipeline gave up %d wait(s)" % n

@@ -56,6 +56,7 @@ def test_abi_version_and_default_params(lib):
     assert (m.h_min, m.min_conc, m.min_thick) == (1e-4, p.min_conc, p.min_thick)
     # closure entry points without a context: argument errors, never a crash
     assert lib.nsdg_transport_bounds_set(None, 0, None) == -1 and lib.nsdg_transport_limit(None, 2, 0, 0, 1, None) == -1
+    assert lib.nsdg_mevp_pipeline_health(None, None) == -1
 
 
 def test_param_struct_layout_matches_oracle():
