@@ -567,6 +567,8 @@ int nsdg_rb_transport_run(nsdg_ctx* ctx, nsdg_rb_transport* p, double dt, int32_
     NSDG_CHECK_ARG(parity == 0 || parity == 1, "parity must be 0 or 1");
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(ctx->nx == p->g.nx && ctx->ny == p->g.ny, "nsdg_grid_set does not match the plan's local array");
+    NSDG_CHECK_ARG(ctx->nbounds == 0 || ctx->nbounds == p->d.nfields,
+        "nsdg_transport_bounds_set was given a different number of fields than this plan advances"); // before anything is advanced
     const Geometry& g = p->g;
     const nsdg_rb_transport_desc& d = p->d;
     double* const* cur = parity == 0 ? d.phi : d.t1; // the state

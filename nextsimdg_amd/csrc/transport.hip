@@ -1017,6 +1017,7 @@ int nsdg_transport_step(nsdg_ctx* ctx, int32_t order, double dt, int32_t nfields
     NSDG_CHECK_ARG(order >= 0 && order <= 2, "order must be 0, 1 or 2");
     NSDG_CHECK_ARG(nfields >= 1 && nfields <= MAXF, "nfields must be 1..4");
     NSDG_CHECK_ARG(phi && scratch && vx_dg && vy_dg && un_x && un_y, "null pointer");
+    NSDG_CHECK_ARG(ctx->nbounds == 0 || ctx->nbounds == nfields, NSDG_BOUNDS_MISMATCH); // before anything is advanced
     const int nc = order == 0 ? 1 : (order == 1 ? 3 : 6);
     const long M = (long)nc * ctx->nx * ctx->ny;
     const double *p0[MAXF], *ps[MAXF];

@@ -165,9 +165,14 @@ def test_step_entry_points_apply_the_closure_identically(ctx, order):
                 ctx.transport_limit(2, 0, ny, out)
                 for k in range(2):
                     assert torch.equal(out[k], full[k])
-        # a call that advances another number of fields than the bounds describe is refused, not silently unlimited
+        # a call that advances another number of fields than the bounds describe is refused, not silently unlimited -- and refused
+        # BEFORE it advances anything (the staged step too, whose closure is a pass of its own at the end)
         with pytest.raises(abi.NsdgError, match="different number of fields"):
             ctx.transport_step_oop(order, dt, [a[0]], [b[0]], adv)
+        keep = a[0].clone()
+        with pytest.raises(abi.NsdgError, match="different number of fields"):
+            ctx.transport_step(order, dt, [a[0]], adv, scratch)
+        assert torch.equal(a[0], keep)
         ctx.set_transport_bounds(())
 
 
