@@ -358,7 +358,7 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
  * gives up, releases the other waits of its workgroup and counts the event -- the launch then finishes with WRONG results instead
  * of hanging the GPU.  This call waits for the context's stream and returns the number of such events since the last call (and
  * resets it): 0 in a correct program; a host checks it where it checks its fields for finiteness (DynamicsStep::stop, bench.py,
- * the test session). */
+ * the test session).  The counter is one per process and device image, shared by all contexts of the process. */
 int nsdg_mevp_pipeline_health(nsdg_ctx* ctx, uint32_t* waits_given_up);
 
 /* rows per strip of the fused marching kernel (performance knob; results do not depend on it);
