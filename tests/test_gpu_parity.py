@@ -656,10 +656,10 @@ def test_mevp_three_iterations_per_pass_equals_three_single_passes_bitwise(ctx):
 
 def test_mevp_four_iterations_per_pass_equals_four_single_passes_bitwise(ctx):
     """variant 4 runs four sub-iterations per pass, one pipeline stage per wave of a four-wave workgroup (hand-over
-    through LDS, one workgroup barrier per march step); it must reproduce four launches of the single-iteration
+    through LDS, point to point: counters in LDS, no barrier in the march); it must reproduce four launches of the single-iteration
     fused kernel bit for bit, for any strip height, for widths around the 57 owned columns of a workgroup, for
     sub-ranges of rows, for two ranges in one launch, and inside nsdg_mevp_subcycle (remainders of 3, 2 and 1
-    sub-iterations through the kernels of variants 3, 2 and 1)"""
+    sub-iterations: passes of 3 / 2 stages of the same kernel, and the single-iteration kernel)"""
     for (nx, ny) in ((130, 45), (57, 9), (58, 13), (200, 3), (56, 1), (7, 5), (115, 22)):
         b = Box(ctx, nx, ny)
         rng = np.random.default_rng(59)
