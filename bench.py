@@ -673,7 +673,7 @@ def main():
         tflops = flops / (launch_ms * 1e-3) / 1e12
         roof = {"bound": "fp64-valu/power",
                 "bound_note": "what the counters and the power probe support (DESIGN.md section 5): vector-ALU issue of fp64 arithmetic at the socket's power "
-                              "cap (in-kernel clock ~1.75 of 2.4 GHz) with the L2 -> fabric traffic at `fabric_traffic_frac_of_copy_peak` of the measured "
+                              "cap (1380 W of 1400, shader clock 2.22 of 2.4 GHz: profiles/r05_power_probe.txt) with the L2 -> fabric traffic at `fabric_traffic_frac_of_copy_peak` of the measured "
                               "copy ceiling; HBM bytes alone (`frac`) are not what limits the pass.  `achieved` / `peak` / `frac` stay the HBM figures "
                               "BASELINE.json's target is stated in; the flop side is `fp64_tflops` / `frac_fp64_valu`",
                 "kernel": fused_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

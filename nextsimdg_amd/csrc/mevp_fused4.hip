@@ -134,6 +134,49 @@ __device__ __forceinline__ void flag_publish(volatile lds_int* flags, int which,
 __device__ __forceinline__ double2 lds_pair_p(const double* slot, int k) { return *reinterpret_cast<const double2*>(slot + k * 128); }
 __device__ __forceinline__ void lds_pair_p(double* slot, int k, double a, double b) { *reinterpret_cast<double2*>(slot + k * 128) = make_double2(a, b); }
 
+// Streaming accesses (NSDG_P2P_NT bits: 1 the loader's stress loads, 2 the last stage's stress stores, 4 the loader's ice-strength
+// loads): data a pass touches exactly once need not displace the coefficient rows the stages 1-3 re-read through the L2.  Measured
+// on one box, three alternations (profiles/r05_fused4_p2p.md section 3): 0 0.8727-0.8741 ms per pass at 2048^2, 2 0.8609-0.8679,
+// 3 0.8619-0.8702, 7 0.8641-0.8708 -- the same bits in memory, about 1 % less time: 3 is the default.
+#ifndef NSDG_P2P_NT
+#define NSDG_P2P_NT 3
+#endif
+typedef double nsdg_pair16p __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ void tile_load8_p(const double* __restrict__ a, long t, double (&c)[8])
+{
+    if (!NT)
+        return tile_load8(a, t, c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const nsdg_pair16p v = __builtin_nontemporal_load(reinterpret_cast<const nsdg_pair16p*>(a + t + 128 * k));
+        c[2 * k] = v.x, c[2 * k + 1] = v.y;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void tile_load9_p(const double* __restrict__ a, long t, int l, double (&c)[9])
+{
+    if (!NT)
+        return tile_load9(a, t, l, c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const nsdg_pair16p v = __builtin_nontemporal_load(reinterpret_cast<const nsdg_pair16p*>(a + t + 128 * k));
+        c[2 * k] = v.x, c[2 * k + 1] = v.y;
+    }
+    c[8] = __builtin_nontemporal_load(a + t + 512 - l);
+}
+template <bool NT>
+__device__ __forceinline__ void tile_store8_p(double* __restrict__ a, long t, const double (&c)[8])
+{
+    if (!NT)
+        return tile_store8(a, t, c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        nsdg_pair16p v;
+        v.x = c[2 * k], v.y = c[2 * k + 1];
+        __builtin_nontemporal_store(v, reinterpret_cast<nsdg_pair16p*>(a + t + 128 * k));
+    }
+}
 typedef double nsdg_pair8p __attribute__((ext_vector_type(2), aligned(8)));
 __device__ __forceinline__ void fetch_nodes_p(const double* __restrict__ w, long n, double (&o)[3])
 {
@@ -268,7 +311,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         NSDG_SPIN_COUNT(2, flag_wait(flags, 3 + G.nst - 2, min(row - P4_PRING, G.last_final))); // read[] of the LAST link: the last stage has passed that row
         ring_write_P(ring, row, M.lane, f.P);
         ring_write_c(cring, row, M.lane, f.c); // this row's coefficients were requested a step ago; the stages 1-3 take the pair from here
-        tile_load9(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P);
+        tile_load9_p<(NSDG_P2P_NT & 4) != 0>(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P);
         if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -297,9 +340,9 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     __builtin_amdgcn_sched_barrier(0);
     if (FIRST) { // stress of the next row
         const long ts = tile_off(ix, nrow, M.ntx, 8);
-        tile_load8(S.i11, ts, f.s11);
-        tile_load8(S.i12, ts, f.s12);
-        tile_load8(S.i22, ts, f.s22);
+        tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i11, ts, f.s11);
+        tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i12, ts, f.s12);
+        tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i22, ts, f.s22);
     }
     NSDG_PHASE(3); // relaxation, (loader) stress request
     // ------------------------------------------------------------------------------------------ contributions, node updates
@@ -337,9 +380,9 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     } else if (M.own && row >= M.y0) { // the last stage runs on rows y0-1 .. y1-1
         const long ts = tile_off(ix, row, M.ntx, 8);
         const long nV = (long)(2 * row) * nn + 2 * ix;
-        tile_store8(S.o11, ts, s11);
-        tile_store8(S.o12, ts, s12);
-        tile_store8(S.o22, ts, s22);
+        tile_store8_p<(NSDG_P2P_NT & 2) != 0>(S.o11, ts, s11);
+        tile_store8_p<(NSDG_P2P_NT & 2) != 0>(S.o12, ts, s12);
+        tile_store8_p<(NSDG_P2P_NT & 2) != 0>(S.o22, ts, s22);
         u_new[nV] = un[0], v_new[nV] = vn[0];
         u_new[nV + 1] = un[1], v_new[nV + 1] = vn[1];
         u_new[nV + nn] = un[2], v_new[nV + nn] = vn[2];
@@ -432,10 +475,10 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
         fetch_nodes_p(v_old, nV + M.nn, f.vm);
         fetch_nodes_p(u_old, nV + 2 * M.nn, f.ut);
         fetch_nodes_p(v_old, nV + 2 * M.nn, f.vt);
-        tile_load8(S.i11, ts, f.s11);
-        tile_load8(S.i12, ts, f.s12);
-        tile_load8(S.i22, ts, f.s22);
-        tile_load9(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
+        tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i11, ts, f.s11);
+        tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i12, ts, f.s12);
+        tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i22, ts, f.s22);
+        tile_load9_p<(NSDG_P2P_NT & 4) != 0>(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
         request_c_p(M, row, f.c, packed);
         for (int row = G.first; row <= G.last; ++row)
             p2p_row<true>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
