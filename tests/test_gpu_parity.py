@@ -319,6 +319,79 @@ def test_mevp_helpers_match_oracle(ctx):
     assert_close(host(tay_d), tay_o, 1e-13, 1e-16, "tay")
 
 
+@pytest.mark.parametrize("strain", [(2e-6, -1e-6, 0.5e-6), (-3e-6, -1e-6, 0.0), (0.0, 0.0, 1.5e-6)])
+def test_device_stress_lies_on_hiblers_elliptic_yield_curve(ctx, strain):
+    """The HIP stress update held to the LITERATURE directly, no oracle in between (the CPU twin of this test,
+    tests/test_oracle_dynamics.py, does the same for the oracle and the independent restatement): a uniform strain rate far above
+    Delta_min on a uniform cover relaxes to a uniform stress whose principal values lie on Hibler's ellipse
+    ((s1 + s2) / P + 1)^2 + e^2 ((s1 - s2) / P)^2 = 1, e = 2, coaxial with the strain rate, strain rate normal to the yield curve."""
+    from nextsimdg_amd import basis
+
+    e11, e22, e12 = strain
+    nx, ny, hx, hy = 70, 5, 500.0, 400.0
+    pk = dict(alpha=2.0, beta=2.0, delta_min=2e-9)
+    ctx.set_mevp_params(ctx.mevp_default_params(**pk))
+    ctx.set_grid(nx, ny, hx, hy)
+    po = O.mevp_params(**pk)
+    H = np.zeros((6, ny, nx)); H[0] = 0.8
+    A = np.zeros((6, ny, nx)); A[0] = 0.93
+    pg = ctx.private_zeros(9, ny, nx, "cuda")
+    ctx.ice_strength(dev(H), dev(A), pg)
+    P = po.pstar * 0.8 * np.exp(-po.compaction * 0.07)
+    assert abs(float(abi.untile(pg, nx)[0, 0, 0]) - P) < 1e-9 * P
+    X, Y = basis.node_coords(nx, ny, nx * hx, ny * hy)
+    u, v = dev(e11 * X + e12 * Y), dev(e12 * X + e22 * Y)
+    s = [tdev(np.zeros((8, ny, nx))) for _ in range(3)]
+    for _ in range(80):  # alpha = 2: the distance to sigma(u, v) halves per sweep
+        ctx.mevp_stress(0, ny, u, v, pg, *s)
+    S = [thost(x, nx) for x in s]
+    for c in range(3):
+        assert np.max(np.abs(S[c][1:])) < 1e-9 * P and np.ptp(S[c][0]) < 1e-9 * P
+    s11, s12, s22 = (float(S[c][0, 2, 33]) for c in range(3))
+    mean, dev_ = 0.5 * (s11 + s22), np.hypot(0.5 * (s11 - s22), s12)
+    s1, s2 = mean + dev_, mean - dev_
+    assert abs(((s1 + s2) / P + 1.0) ** 2 + 4.0 * ((s1 - s2) / P) ** 2 - 1.0) < 1e-5
+    d_eps, d_sig = np.array([0.5 * (e11 - e22), e12]), np.array([0.5 * (s11 - s22), s12])
+    assert abs(d_eps[0] * d_sig[1] - d_eps[1] * d_sig[0]) < 1e-9 * np.linalg.norm(d_eps) * P and d_eps @ d_sig >= 0.0
+    eI, eII = e11 + e22, 2.0 * np.linalg.norm(d_eps)
+    gI, gII = 2.0 * ((s1 + s2) / P + 1.0), 8.0 * (s1 - s2) / P
+    assert abs(eI * gII - eII * gI) < 2e-5 * np.hypot(eI, eII) * np.hypot(gI, gII)
+    ctx.set_mevp_params(ctx.mevp_default_params())
+
+
+@pytest.mark.parametrize("variant", [1, abi.DEFAULT_MEVP_VARIANT])
+def test_device_strengthless_cover_reaches_the_free_drift_of_the_literature(ctx, variant):
+    """P* = 0 on the device, through nsdg_mevp_subcycle (the pipelined kernel and the single-iteration one): after 70 model steps every
+    interior node sits at the steady free drift -- scipy's solution of the published momentum balance (tests/test_oracle_dynamics.py:
+    free_drift_solution), no oracle in between; ~2 % of the wind speed, to the right of the wind (f > 0)."""
+    from test_oracle_dynamics import free_drift_case, free_drift_solution
+
+    nx, ny = 70, 9
+    hx, hy, ua, va, uo, vo, cgh, cga = free_drift_case(nx, ny)
+    pk = dict(pstar=0.0, alpha=5.0, beta=5.0)
+    ctx.set_mevp_variant(variant)
+    ctx.set_mevp_params(ctx.mevp_default_params(**pk))
+    ctx.set_grid(nx, ny, hx, hy)
+    po = O.mevp_params(**pk)
+    tax, tay = torch.zeros_like(dev(ua)), torch.zeros_like(dev(ua))
+    ctx.wind_stress(dev(ua), dev(va), tax, tay)
+    u, v = torch.zeros_like(tax), torch.zeros_like(tax)
+    s = [tdev(np.zeros((8, ny, nx))) for _ in range(3)]
+    pg = ctx.private_zeros(9, ny, nx, "cuda")
+    scratch = torch.zeros(10 * u.numel() + 3 * s[0].numel(), dtype=torch.float64, device="cuda")
+    duo, dvo, dh, da = dev(uo), dev(vo), dev(cgh), dev(cga)
+    for _ in range(70):
+        ctx.mevp_subcycle(600.0, 30, s, u, v, u.clone(), v.clone(), tax, tay, duo, dvo, dh, da, pg, scratch)
+    want = free_drift_solution(po, 9.0, -4.0, 0.05, 0.02, 0.7, 0.85)
+    ui, vi = host(u)[1:-1, 1:-1], host(v)[1:-1, 1:-1]
+    assert np.max(np.abs(ui - want[0])) < 1e-10 and np.max(np.abs(vi - want[1])) < 1e-10
+    assert all(float(x.abs().max()) < 1e-12 for x in s)
+    rel = np.array([want[0] - 0.05, want[1] - 0.02])
+    assert 0.01 < np.linalg.norm(rel) / np.hypot(9.0, -4.0) < 0.03 and 9.0 * rel[1] + 4.0 * rel[0] < 0
+    ctx.set_mevp_variant(abi.DEFAULT_MEVP_VARIANT)
+    ctx.set_mevp_params(ctx.mevp_default_params())
+
+
 def pack(ctx, dt, u0, v0, tax, tay, uo, vo, cgh, cga):
     packed = torch.zeros(8 * u0.size, dtype=torch.float64, device="cuda")
     ctx.mevp_pack_nodal(dt, (dev(u0), dev(v0)), (dev(tax), dev(tay)), (dev(uo), dev(vo)), dev(cgh), dev(cga), packed)

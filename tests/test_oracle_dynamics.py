@@ -220,6 +220,109 @@ def test_mevp_point_symmetry():
     np.testing.assert_allclose(v, -v[::-1, ::-1], rtol=0, atol=1e-12 * np.max(np.abs(v)))
 
 
+@pytest.mark.parametrize("strain", [(2e-6, -1e-6, 0.5e-6), (-3e-6, -1e-6, 0.0), (1e-6, 1e-6, 2e-6), (0.0, 0.0, 1.5e-6)])
+def test_converged_stress_lies_on_hiblers_elliptic_yield_curve(strain):
+    """A uniform strain rate far above Delta_min on a uniform cover: the relaxed stress is uniform and must be the viscous-plastic
+    stress of Hibler (1979) -- checked through what the LITERATURE says about it, not through the formula either restatement uses:
+    the principal stresses lie on the ellipse ((s1 + s2) / P + 1)^2 + e^2 ((s1 - s2) / P)^2 = 1 with e = 2, the stress is coaxial
+    with the strain rate and obeys the normal flow rule (strain rate parallel to the gradient of the yield function).  Oracle and
+    independent restatement both."""
+    import dyn_independent as I
+
+    e11, e22, e12 = strain
+    nx, ny, hx, hy = 4, 3, 500.0, 400.0
+    p = O.mevp_params(alpha=2.0, delta_min=2e-9)
+    H = np.zeros((6, ny, nx)); H[0] = 0.8
+    A = np.zeros((6, ny, nx)); A[0] = 0.93
+    pg = O.ice_strength(nx, ny, p, H, A)
+    P = float(pg[0, 0, 0])
+    assert np.ptp(pg) < 1e-12 * P and abs(P - p.pstar * 0.8 * np.exp(-p.compaction * 0.07)) < 1e-9 * P
+    X, Y = basis.node_coords(nx, ny, nx * hx, ny * hy)
+    u = np.ascontiguousarray(e11 * X + e12 * Y)  # du/dx = e11, (du/dy + dv/dx) / 2 = e12, dv/dy = e22
+    v = np.ascontiguousarray(e12 * X + e22 * Y)
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    for _ in range(80):  # alpha = 2: the relaxation halves the distance to sigma(u, v) per sweep
+        O.mevp_stress(nx, ny, 0, ny, hx, hy, p, u, v, pg, *s)
+    par = dict(alpha=2.0, delta_min=2e-9)
+    si = [np.zeros((8, ny, nx)) for _ in range(3)]
+    for _ in range(60):
+        si = I.mevp_stress(par, hx, hy, u, v, pg, si)
+    for name, S in (("oracle", s), ("independent restatement", si)):
+        for c in range(3):  # uniform: only the cell mean (coefficient 0) is non-zero, the same in every element
+            assert np.max(np.abs(S[c][1:])) < 1e-9 * P, name
+            assert np.ptp(S[c][0]) < 1e-9 * P, name
+        s11, s12, s22 = (float(S[c][0, 1, 1]) for c in range(3))
+        # principal stresses and the ellipse
+        mean, dev = 0.5 * (s11 + s22), np.hypot(0.5 * (s11 - s22), s12)
+        s1, s2 = mean + dev, mean - dev
+        assert abs(((s1 + s2) / P + 1.0) ** 2 + 4.0 * ((s1 - s2) / P) ** 2 - 1.0) < 1e-5, name  # Delta_min / Delta ~ 1e-3: squared
+        # coaxial with the strain rate: the deviators are parallel
+        d_eps = np.array([0.5 * (e11 - e22), e12])
+        d_sig = np.array([0.5 * (s11 - s22), s12])
+        assert abs(d_eps[0] * d_sig[1] - d_eps[1] * d_sig[0]) < 1e-9 * np.linalg.norm(d_eps) * P, name
+        assert d_eps @ d_sig >= 0.0, name
+        # normal flow rule: with F = (sI / P + 1)^2 + e^2 (sII / P)^2 - 1 in the invariants sI = s1 + s2, sII = s1 - s2, the strain
+        # rate invariants (eI, eII) = (e11 + e22, |principal difference|) are parallel to (dF/dsI, dF/dsII)
+        eI, eII = e11 + e22, 2.0 * np.linalg.norm(d_eps)
+        gI, gII = 2.0 * ((s1 + s2) / P + 1.0), 8.0 * (s1 - s2) / P
+        assert abs(eI * gII - eII * gI) < 2e-5 * np.hypot(eI, eII) * np.hypot(gI, gII), name
+
+
+def free_drift_case(nx=6, ny=5):
+    """uniform wind, uniform ocean current, uniform cover WITHOUT strength: every interior node is on its own (shared with the GPU twin)"""
+    hx, hy = 500.0, 400.0
+    shape = (2 * ny + 1, 2 * nx + 1)
+    ua, va = np.full(shape, 9.0), np.full(shape, -4.0)
+    uo, vo = np.full(shape, 0.05), np.full(shape, 0.02)
+    cgh, cga = np.full(shape, 0.7), np.full(shape, 0.85)
+    return hx, hy, ua, va, uo, vo, cgh, cga
+
+
+def free_drift_solution(p, ua, va, uo, vo, h, a):
+    """the steady momentum balance of the literature (Hibler 1979; Mehlmann & Richter 2017, eq. 1, with the sea-surface tilt written
+    through the geostrophic current), solved by scipy -- no code of either restatement:
+        0 = A tau_a + A C_w rho_w |u_o - u| (u_o - u) - rho_i h f k x (u - u_o)"""
+    from scipy.optimize import fsolve
+
+    wind = np.hypot(ua, va)
+    tax, tay = p.c_atm * p.rho_atm * wind * ua, p.c_atm * p.rho_atm * wind * va
+
+    def balance(w):
+        du, dv = uo - w[0], vo - w[1]
+        drag = a * p.c_ocean * p.rho_ocean * np.hypot(du, dv)
+        m = p.rho_ice * h
+        return [a * tax + drag * du + m * p.fc * (w[1] - vo), a * tay + drag * dv - m * p.fc * (w[0] - uo)]
+
+    sol = fsolve(balance, [uo, vo], xtol=1e-14)
+    assert np.max(np.abs(balance(sol))) < 1e-12
+    return sol
+
+
+def test_strengthless_cover_reaches_the_free_drift_of_the_literature():
+    """P* = 0: no stress, every interior node integrates its own momentum balance; after enough model steps (implicit Euler in u0, time
+    scale rho h / drag ~ 16 min) the velocity must be the STEADY free drift: ~2 % of the wind speed, turned to the right of the wind
+    on the northern hemisphere (Nansen's rule), and equal to scipy's solution of the published balance.  (The steady state does not
+    depend on how far the sub-cycle converges inside a step: u = u0 = fixed point of the sweep is the balance itself.)"""
+    nx, ny = 6, 5
+    hx, hy, ua, va, uo, vo, cgh, cga = free_drift_case(nx, ny)
+    p = O.mevp_params(pstar=0.0, alpha=5.0, beta=5.0)
+    tax, tay = O.wind_stress(p, ua, va)
+    pg = np.zeros((9, ny, nx))
+    u, v = np.zeros_like(ua), np.zeros_like(ua)
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    for _ in range(70):
+        O.mevp_subcycle(nx, ny, hx, hy, 600.0, 30, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg)
+    assert all(np.max(np.abs(x)) < 1e-12 for x in s)  # -P/2 = 0: no stress at all
+    want = free_drift_solution(p, 9.0, -4.0, 0.05, 0.02, 0.7, 0.85)
+    ui, vi = u[1:-1, 1:-1], v[1:-1, 1:-1]
+    assert np.max(np.abs(ui - want[0])) < 1e-10 and np.max(np.abs(vi - want[1])) < 1e-10
+    rel = np.array([want[0] - 0.05, want[1] - 0.02])  # drift relative to the current
+    ratio = np.linalg.norm(rel) / np.hypot(9.0, -4.0)
+    assert 0.01 < ratio < 0.03
+    cross = 9.0 * rel[1] - (-4.0) * rel[0]  # z component of wind x drift: negative = drift to the RIGHT of the wind (f > 0)
+    assert p.fc > 0 and cross < 0
+
+
 # ------------------------------------------------------------------------------------ frozen outputs (self-fixture)
 def test_oracle_reproduces_its_frozen_outputs():
     """SELF-FIXTURE -- NOT reference parity (the reference has no DG / mEVP code).  The oracle is the
