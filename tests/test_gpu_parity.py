@@ -392,6 +392,25 @@ def test_device_strengthless_cover_reaches_the_free_drift_of_the_literature(ctx,
     ctx.set_mevp_params(ctx.mevp_default_params())
 
 
+def test_device_converged_subcycle_solves_the_implicit_vp_step(ctx):
+    """the defining property of mEVP on the device: 2500 sub-iterations of the default (pipelined) kernel through nsdg_mevp_subcycle,
+    then ONE Picard sweep of the implicit viscous-plastic step by the independent restatement (tests/test_oracle_dynamics.py:
+    check_implicit_vp_fixed_point) returns the same stress and velocity -- no oracle in between"""
+    from test_oracle_dynamics import check_implicit_vp_fixed_point, implicit_vp_case
+
+    c = implicit_vp_case()
+    nx, ny = c["nx"], c["ny"]
+    ctx.set_mevp_params(ctx.mevp_default_params(**c["pk"]))
+    ctx.set_grid(nx, ny, c["hx"], c["hy"])
+    u, v = dev(c["u0"]), dev(c["v0"])
+    s = [tdev(np.zeros((8, ny, nx))) for _ in range(3)]
+    scratch = torch.zeros(10 * u.numel() + 3 * s[0].numel(), dtype=torch.float64, device="cuda")
+    ctx.mevp_subcycle(c["dt"], 2500, s, u, v, dev(c["u0"]), dev(c["v0"]), dev(c["tax"]), dev(c["tay"]), dev(c["uo"]), dev(c["vo"]),
+                      dev(c["cgh"]), dev(c["cga"]), tdev(c["pg"]), scratch)
+    check_implicit_vp_fixed_point(c, host(u), host(v), [thost(x, nx) for x in s])
+    ctx.set_mevp_params(ctx.mevp_default_params())
+
+
 def pack(ctx, dt, u0, v0, tax, tay, uo, vo, cgh, cga):
     packed = torch.zeros(8 * u0.size, dtype=torch.float64, device="cuda")
     ctx.mevp_pack_nodal(dt, (dev(u0), dev(v0)), (dev(tax), dev(tay)), (dev(uo), dev(vo)), dev(cgh), dev(cga), packed)

@@ -323,6 +323,65 @@ def test_strengthless_cover_reaches_the_free_drift_of_the_literature():
     assert p.fc > 0 and cross < 0
 
 
+def implicit_vp_case():
+    """a small box whose cover deforms under the wind: inputs of the fixed-point test (shared with the GPU twin)"""
+    nx = ny = 8
+    bt = synthetic.BoxTest(nx, ny, 40e3)  # 5 km elements: the stress divergence matters
+    pk = dict(alpha=80.0, beta=80.0, delta_min=2e-7)
+    p = O.mevp_params(**pk)
+    H, A = bt.dg_fields()
+    A[0] -= 0.15  # a cover that deforms under this wind
+    c = dict(nx=nx, ny=ny, hx=bt.hx, hy=bt.hy, dt=120.0, pk=pk, p=p, H=H, A=A)
+    c["pg"] = O.ice_strength(nx, ny, p, H, A)
+    c["cgh"], c["cga"] = O.dg_to_cg(nx, ny, H), O.dg_to_cg(nx, ny, A)
+    c["uo"], c["vo"] = [np.ascontiguousarray(a) for a in bt.ocean()]
+    ua, va = [np.ascontiguousarray(a) for a in bt.wind(0.0)]
+    c["tax"], c["tay"] = O.wind_stress(p, ua, va)
+    rng = np.random.default_rng(3)
+    c["u0"], c["v0"] = 0.02 * rng.standard_normal(c["uo"].shape), 0.02 * rng.standard_normal(c["uo"].shape)
+    for a in (c["u0"], c["v0"]):
+        a[0] = a[-1] = 0
+        a[:, 0] = a[:, -1] = 0
+    return c
+
+
+def check_implicit_vp_fixed_point(c, u, v, s):
+    """(u, v, s) -- a converged sub-cycle -- against ONE Picard sweep of the implicit equation written by the independent restatement"""
+    import dyn_independent as I
+
+    scale = np.max(np.hypot(u, v))
+    smax = max(np.max(np.abs(x)) for x in s)
+    assert scale > 1e-4 and smax > 1.0
+    par = {k: getattr(c["p"], k) for k in I.PARAMS}
+    par.update(alpha=1.0, beta=0.0)  # alpha = 1: S = Proj sigma(u); beta = 0: no pseudo-time term
+    S = I.mevp_stress(par, c["hx"], c["hy"], u, v, c["pg"], [np.zeros_like(x) for x in s])
+    for a, b in zip(S, s):
+        assert np.max(np.abs(a - b)) < 1e-7 * smax
+    args = (c["u0"], c["v0"], c["tax"], c["tay"], c["uo"], c["vo"], c["cgh"], c["cga"])
+    un, vn = I.mevp_velocity(par, c["hx"], c["hy"], c["dt"], S, u, v, *args)
+    assert np.max(np.abs(un - u)) < 1e-7 * scale and np.max(np.abs(vn - v)) < 1e-7 * scale
+    # and the step is not trivial: the stress divergence is a leading term of the balance
+    uf, vf = I.mevp_velocity(par, c["hx"], c["hy"], c["dt"], [np.zeros_like(x) for x in s], u, v, *args)
+    assert np.max(np.hypot(uf - u, vf - v)) > 1e-2 * scale
+
+
+def test_converged_subcycle_solves_the_implicit_vp_step():
+    """What defines mEVP (Bouillon et al. 2013, Kimmritz et al. 2015): the pseudo-time iteration's fixed point is the solution of the
+    implicit viscous-plastic step  m (u - u0) / dt = F(u, sigma(u)),  whatever alpha and beta are.  The oracle iterates to convergence;
+    the INDEPENDENT restatement then evaluates one Picard sweep of the implicit equation itself (alpha = 1, beta = 0) at that state --
+    it must return the same stress and the same velocity."""
+    c = implicit_vp_case()
+    nx, ny = c["nx"], c["ny"]
+    u, v = c["u0"].copy(), c["v0"].copy()
+    s = [np.zeros((8, ny, nx)) for _ in range(3)]
+    args = (c["u0"], c["v0"], c["tax"], c["tay"], c["uo"], c["vo"], c["cgh"], c["cga"], c["pg"])
+    O.mevp_subcycle(nx, ny, c["hx"], c["hy"], c["dt"], 2500, c["p"], s, u, v, *args)
+    up, vp = u.copy(), v.copy()
+    O.mevp_subcycle(nx, ny, c["hx"], c["hy"], c["dt"], 1, c["p"], [x.copy() for x in s], up, vp, *args)
+    assert np.max(np.abs(up - u)) < 1e-10 * np.max(np.hypot(u, v))  # converged
+    check_implicit_vp_fixed_point(c, u, v, s)
+
+
 # ------------------------------------------------------------------------------------ frozen outputs (self-fixture)
 def test_oracle_reproduces_its_frozen_outputs():
     """SELF-FIXTURE -- NOT reference parity (the reference has no DG / mEVP code).  The oracle is the
