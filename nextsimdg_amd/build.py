@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnsdg.so")
-SOURCES = ["nsdg_ctx.hip", "column_step.hip", "transport.hip", "mevp.hip", "mevp_fused.hip", "mevp_fused4.hip", "halo.hip", "rowblock.hip", "forcing.hip"]
-HEADERS = ["nsdg_internal.h", "dg_tables.h", "mevp_common.h", "mevp_pipeline.h", os.path.join("..", "..", "include", "nsdg.h")]
+SOURCES = ["nsdg_ctx.hip", "column_step.hip", "transport.hip", "mevp.hip", "mevp_fused.hip", "mevp_fused4.hip", "mevp_fused8.hip", "halo.hip", "rowblock.hip", "forcing.hip"]
+HEADERS = ["nsdg_internal.h", "dg_tables.h", "mevp_common.h", "mevp_pipeline.h", "mevp_p2p.h", os.path.join("..", "..", "include", "nsdg.h")]
 # -ffp-contract=on: fuse a*b+c only where it is written as one expression (decided in the front end), so
 # that the same inlined device function rounds identically in every kernel it is inlined into -- the
 # mEVP kernel variants agree bit for bit; the default (fast) let the back end fuse differently per kernel

@@ -22,21 +22,15 @@
 //     and the LDS is full: 96 + 31.5 + 28 = 155.5 of 160 KB (profiles/r05_fused4_p2p.md: what fits, what was measured).
 //   * no barrier after the prologue: the waves run as far apart as their dependencies allow, idle steps do not exist.
 //
-// Memory ordering.  All hand-over traffic is LDS traffic of ONE compute unit; the LDS executes the instructions of a wave in order.
-// A producer waits for its own LDS writes (s_waitcnt lgkmcnt(0)) before it raises its counter; a consumer reads the counter,
-// waits for that read, and only then issues its reads of the slot -- the pattern of an LDS-scope release / acquire, written out
-// with compiler barriers around it.  Counters only ever increase.  Every wait is on an event that is strictly earlier in the
-// dependency graph of the march (row r of stage k + 1 waits for row r + 1 of stage k; row r of stage k waits for row r - 2 of stage
-// k + 1, which waited for row r - 1 of stage k), so no wave can wait for ever -- and, should that reasoning ever be wrong, a
-// wait gives up after NSDG_P2P_SPIN_LIMIT polls, raises a sticky flag that releases every other wait of the workgroup, and counts
-// the event in a device counter the hosts read (nsdg_mevp_pipeline_health): a wrong result that is reported, never a hung GPU.
+// Memory ordering of the hand-over, the bounded wait and how a wait that gave up becomes an error status: mevp_p2p.h.  Every wait is
+// on an event that is strictly earlier in the dependency graph of the march (row r of stage k + 1 waits for row r + 1 of stage k; row r
+// of stage k waits for row r - 2 of stage k + 1, which waited for row r - 1 of stage k), so no wave can wait for ever.
 //
 // The arithmetic is the same sequence of inlined functions as in every other variant: bit-identical to four passes of variant 1.
-#include "mevp_pipeline.h"
+#include "mevp_p2p.h"
 
 namespace nsdg_mevp_detail {
 
-__device__ unsigned nsdg_p2p_timeouts_dev = 0;
 #ifdef NSDG_P2P_SPINSTAT
 // diagnostic build only (tools/ab_build.sh spin -DNSDG_P2P_SPINSTAT; tools/p2p_spinstat.py): polls per stage and kind of wait -- 0 the
 // previous stage's hand-over, 1 a free hand-over slot, 2 a free ring slot -- and the rows the stage worked on in [3]
@@ -60,22 +54,14 @@ __device__ unsigned long long nsdg_p2p_phase_dev[4][8]; // shader cycles per sta
 #define NSDG_SPIN_COUNT(k, n) (void)(n) /* the wait itself is the argument: it must stay */
 #endif
 
-struct StressPtrsP {
-    const double *i11, *i12, *i22;
-    double *o11, *o12, *o22;
-};
-
 constexpr int P4_OWNED = 57, P4_LEFT = 4; // lanes 4 .. 60 own a column (four sub-iterations reach four columns / rows)
 constexpr int P4_HAND = 32; // doubles per lane and hand-over slot: 24 stress coefficients + u, v at the 4 owned nodes
 constexpr int P4_SLOT = P4_HAND * 64; // value k of lane l at (k / 2) * 128 + 2 l + k % 2 (16-byte pairs)
 constexpr int P4_HSLOTS = 2; // slots per link
 constexpr int P4_PRING = 7; // rows in each of the two rings (a row is in flight for ~5.7 march steps; 7 x (4.6 + 4) KB is what fits)
-constexpr int P4_PSLOT = 9 * 64; // ice strength: pairs k < 4 of lane l at k * 128 + 2 l, the ninth value at 512 + l
+constexpr int P4_PSLOT = P2P_PSLOT; // ice strength (mevp_p2p.h)
 constexpr int P4_CSLOT = 8 * 64; // third pair of the nodal coefficients (u_ocean, v_ocean): node n of lane l at n * 128 + 2 l
 constexpr int P4_LDS = 3 * P4_HSLOTS * P4_SLOT + P4_PRING * (P4_PSLOT + P4_CSLOT); // doubles: 96 + 31.5 + 28 KB of the 160 KB of a CU
-#ifndef NSDG_P2P_SPIN_LIMIT
-#define NSDG_P2P_SPIN_LIMIT (1 << 20) // polls of ~0.2 us: a fifth of a second; a legitimate wait is a few march steps (a few microseconds)
-#endif
 
 struct FetchP {
     double P[9]; // ice strength at the Gauss points of the row the stage works on next
@@ -98,100 +84,6 @@ struct FlagsP {
     int v[8];
 };
 
-// the counters are accessed through LDS-typed pointers: a volatile access through a generic pointer would be a FLAT instruction, which
-// counts on vmcnt as well and so waits for every global load in flight
-typedef __attribute__((address_space(3))) int lds_int;
-__device__ __forceinline__ int flag_peek(const volatile lds_int* p)
-{
-    asm volatile("" ::: "memory");
-    const int x = *p;
-    asm volatile("" ::: "memory");
-    return __builtin_amdgcn_readfirstlane(x);
-}
-// the counter *p has reached `need` (or the workgroup has given up)
-__device__ __forceinline__ int flag_wait(volatile lds_int* flags, int which, int need) // returns the polls it took beyond the first
-{
-    if (flag_peek(flags + which) >= need)
-        return 0;
-    for (int spin = 0; spin < NSDG_P2P_SPIN_LIMIT; ++spin) {
-        __builtin_amdgcn_s_sleep(1);
-        if (flag_peek(flags + which) >= need || flag_peek(flags + 6) != 0)
-            return spin + 1;
-    }
-    flags[6] = 1; // give up: release everybody, count the event
-    if ((threadIdx.x & 63) == 0)
-        atomicAdd(&nsdg_p2p_timeouts_dev, 1u);
-    return NSDG_P2P_SPIN_LIMIT;
-}
-// everything this wave has written to LDS so far is visible before the counter moves
-__device__ __forceinline__ void flag_publish(volatile lds_int* flags, int which, int value)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    flags[which] = value;
-    asm volatile("" ::: "memory");
-}
-
-__device__ __forceinline__ double2 lds_pair_p(const double* slot, int k) { return *reinterpret_cast<const double2*>(slot + k * 128); }
-__device__ __forceinline__ void lds_pair_p(double* slot, int k, double a, double b) { *reinterpret_cast<double2*>(slot + k * 128) = make_double2(a, b); }
-
-// Streaming accesses (NSDG_P2P_NT bits: 1 the loader's stress loads, 2 the last stage's stress stores, 4 the loader's ice-strength
-// loads): data a pass touches exactly once need not displace the coefficient rows the stages 1-3 re-read through the L2.  Measured
-// on one box, three alternations (profiles/r05_fused4_p2p.md section 3): 0 0.8727-0.8741 ms per pass at 2048^2, 2 0.8609-0.8679,
-// 3 0.8619-0.8702, 7 0.8641-0.8708 -- the same bits in memory, about 1 % less time: 3 is the default.
-#ifndef NSDG_P2P_NT
-#define NSDG_P2P_NT 3
-#endif
-typedef double nsdg_pair16p __attribute__((ext_vector_type(2)));
-template <bool NT>
-__device__ __forceinline__ void tile_load8_p(const double* __restrict__ a, long t, double (&c)[8])
-{
-    if (!NT)
-        return tile_load8(a, t, c);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const nsdg_pair16p v = __builtin_nontemporal_load(reinterpret_cast<const nsdg_pair16p*>(a + t + 128 * k));
-        c[2 * k] = v.x, c[2 * k + 1] = v.y;
-    }
-}
-template <bool NT>
-__device__ __forceinline__ void tile_load9_p(const double* __restrict__ a, long t, int l, double (&c)[9])
-{
-    if (!NT)
-        return tile_load9(a, t, l, c);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const nsdg_pair16p v = __builtin_nontemporal_load(reinterpret_cast<const nsdg_pair16p*>(a + t + 128 * k));
-        c[2 * k] = v.x, c[2 * k + 1] = v.y;
-    }
-    c[8] = __builtin_nontemporal_load(a + t + 512 - l);
-}
-template <bool NT>
-__device__ __forceinline__ void tile_store8_p(double* __restrict__ a, long t, const double (&c)[8])
-{
-    if (!NT)
-        return tile_store8(a, t, c);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        nsdg_pair16p v;
-        v.x = c[2 * k], v.y = c[2 * k + 1];
-        __builtin_nontemporal_store(v, reinterpret_cast<nsdg_pair16p*>(a + t + 128 * k));
-    }
-}
-typedef double nsdg_pair8p __attribute__((ext_vector_type(2), aligned(8)));
-__device__ __forceinline__ void fetch_nodes_p(const double* __restrict__ w, long n, double (&o)[3])
-{
-    const nsdg_pair8p a = *reinterpret_cast<const nsdg_pair8p*>(w + n);
-    o[0] = a.x, o[1] = a.y, o[2] = w[n + 2];
-}
-
-__device__ __forceinline__ void request_c_p(const MarchConst3& M, int nrow, double (&c)[4][6], const double* __restrict__ packed)
-{
-    const long nVn = (long)(2 * nrow) * M.nn + 2 * M.ix;
-    load_nodal(packed, M.nplane, nVn, c[0]);
-    load_nodal(packed, M.nplane, nVn + 1, c[1]);
-    load_nodal(packed, M.nplane, nVn + M.nn, c[2]);
-    load_nodal(packed, M.nplane, nVn + M.nn + 1, c[3]);
-}
 __device__ __forceinline__ int ring_slot(int row) { return row % P4_PRING; } // row >= 0
 // the third pair (u_ocean, v_ocean) of the 4 owned nodes of a row from / to its ring
 __device__ __forceinline__ void ring_read_c(const double* __restrict__ cring, int row, int lane, double (&c)[4][6])
@@ -228,30 +120,10 @@ __device__ __forceinline__ void request_c2_p(const MarchConst3& M, int nrow, dou
     load_nodal2(packed, M.nplane, nVn + M.nn, c[2]);
     load_nodal2(packed, M.nplane, nVn + M.nn + 1, c[3]);
 }
-// ice strength of a row from / to the ring
-__device__ __forceinline__ void ring_read_P(const double* __restrict__ ring, int row, int lane, double (&P)[9])
-{
-    const double* s = ring + ring_slot(row) * P4_PSLOT;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double2 t = *reinterpret_cast<const double2*>(s + k * 128 + 2 * lane);
-        P[2 * k] = t.x, P[2 * k + 1] = t.y;
-    }
-    P[8] = s[512 + lane];
-}
-__device__ __forceinline__ void ring_write_P(double* __restrict__ ring, int row, int lane, const double (&P)[9])
-{
-    double* s = ring + ring_slot(row) * P4_PSLOT;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<double2*>(s + k * 128 + 2 * lane) = make_double2(P[2 * k], P[2 * k + 1]);
-    s[512 + lane] = P[8];
-}
-
 // One row of one stage.  FIRST: the loader (stage 0): inputs from memory, ice strength into the ring.
 template <bool FIRST>
 __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, int row, FetchP& f, TopCarry3& carry, double* __restrict__ lds,
-    volatile lds_int* flags, const StressPtrsP& S, const double* __restrict__ u_old, const double* __restrict__ v_old,
+    volatile lds_int* flags, const P2PReport& rep, const StressPtrsP& S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new NSDG_SPIN_ARG)
 {
     const int stage = FIRST ? 0 : G.s;
@@ -281,9 +153,9 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         vv[0] = vl[0], vv[1] = vl[1], vv[2] = vl[3], vv[3] = vl[4];
     } else {
         // the previous stage has handed over this row and the row above it (whose bottom nodes are this row's top nodes)
-        NSDG_SPIN_COUNT(0, flag_wait(flags, stage - 1, min(row + 1, G.last_prev)));
+        NSDG_SPIN_COUNT(0, flag_wait(flags, stage - 1, min(row + 1, G.last_prev), rep));
         if (row == G.first) { // wave-uniform: the first row of the stage has no predecessor that requested its inputs
-            ring_read_P(ring, row, M.lane, f.P);
+            ring_read_P<P4_PRING>(ring, row, M.lane, f.P);
             request_c(row);
         }
         const double* in = lds + ((stage - 1) * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
@@ -308,8 +180,8 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     if (FIRST) {
         // the ice strength of this row goes to the ring for the stages 1-3 (slot of row - 8: stage 3 has passed it), then the
         // register set takes the next row's; u, v of the next row
-        NSDG_SPIN_COUNT(2, flag_wait(flags, 3 + G.nst - 2, min(row - P4_PRING, G.last_final))); // read[] of the LAST link: the last stage has passed that row
-        ring_write_P(ring, row, M.lane, f.P);
+        NSDG_SPIN_COUNT(2, flag_wait(flags, 3 + G.nst - 2, min(row - P4_PRING, G.last_final), rep)); // read[] of the LAST link: the last stage has passed that row
+        ring_write_P<P4_PRING>(ring, row, M.lane, f.P);
         ring_write_c(cring, row, M.lane, f.c); // this row's coefficients were requested a step ago; the stages 1-3 take the pair from here
         tile_load9_p<(NSDG_P2P_NT & 4) != 0>(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P);
         if (nrow > row) { // wave-uniform: the top node row of this element row is the bottom one of the next
@@ -325,7 +197,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         for (int i = 0; i < 8; ++i)
             s11[i] = f.s11[i], s12[i] = f.s12[i], s22[i] = f.s22[i];
     } else {
-        ring_read_P(ring, nrow, M.lane, f.P); // written by the loader before it handed row nrow over: done[stage - 1] >= row + 1 implies done[0] >= nrow
+        ring_read_P<P4_PRING>(ring, nrow, M.lane, f.P); // written by the loader before it handed row nrow over: done[stage - 1] >= row + 1 implies done[0] >= nrow
         const double* in = lds + ((stage - 1) * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -363,7 +235,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     NSDG_PHASE(5); // request of the coefficients
     // ------------------------------------------------------------------------------------------ outputs
     if (FIRST || stage < G.nst - 1) {
-        NSDG_SPIN_COUNT(1, flag_wait(flags, 3 + stage, row - P4_HSLOTS)); // the consumer has taken the row this slot held
+        NSDG_SPIN_COUNT(1, flag_wait(flags, 3 + stage, row - P4_HSLOTS, rep)); // the consumer has taken the row this slot held
         double* out = lds + (stage * P4_HSLOTS + (row & 1)) * P4_SLOT + 2 * M.lane;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -402,10 +274,10 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
 }
 
 __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw,
-    double hx, double hy, double ialpha, double dmin2, StressPtrsP S, const double* __restrict__ u_old, const double* __restrict__ v_old,
+    double hx, double hy, double ialpha, double dmin2, P2PReport rep, StressPtrsP S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
 {
-    __shared__ __attribute__((aligned(16))) double lds[P4_LDS]; // 96 KB of hand-over slots + 36 KB of ice-strength ring
+    __shared__ __attribute__((aligned(16))) double lds[P4_LDS]; // 96 KB of hand-over slots + 31.5 + 28 KB of rings (ice strength, one coefficient pair)
     __shared__ FlagsP flagmem;
     volatile lds_int* flags = (volatile lds_int*)flagmem.v;
     const int lane = threadIdx.x & 63;
@@ -454,14 +326,14 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
         flags[threadIdx.x] = first_of(threadIdx.x) - 1;
         flags[3 + threadIdx.x] = first_of(threadIdx.x + 1) - 1;
     }
-    if (threadIdx.x == 6)
-        flags[6] = 0;
+    if (threadIdx.x == P2P_GIVEUP)
+        flags[P2P_GIVEUP] = 0;
     __syncthreads(); // the only barrier of the kernel
     if (G.s >= nst)
         return; // wave-uniform
 
     FetchP f;
-    TopCarry3 carry;
+    TopCarry3 carry; // zero by its member initialisers: the first row of a stage adds nothing from a row below
 #ifdef NSDG_P2P_SPINSTAT
     unsigned spins[3] = { 0, 0, 0 }, phase[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned stamp_last = (unsigned)__builtin_amdgcn_s_memtime();
@@ -481,10 +353,10 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
         tile_load9_p<(NSDG_P2P_NT & 4) != 0>(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
         request_c_p(M, row, f.c, packed);
         for (int row = G.first; row <= G.last; ++row)
-            p2p_row<true>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
+            p2p_row<true>(M, G, row, f, carry, lds, flags, rep, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
     } else {
         for (int row = G.first; row <= G.last; ++row)
-            p2p_row<false>(M, G, row, f, carry, lds, flags, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
+            p2p_row<false>(M, G, row, f, carry, lds, flags, rep, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
     }
 #ifdef NSDG_P2P_SPINSTAT
     if (lane == 0) {
@@ -500,19 +372,6 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
 } // namespace nsdg_mevp_detail
 
 using namespace nsdg_mevp_detail;
-
-// waits of the pipeline that gave up since the last call (0 in a correct program); resets the counter; include/nsdg.h
-extern "C" int nsdg_mevp_pipeline_health(nsdg_ctx* ctx, uint32_t* waits_given_up)
-{
-    NSDG_CHECK_ARG(ctx && waits_given_up, "null argument");
-    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    NSDG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    unsigned n = 0, zero = 0;
-    NSDG_CHECK_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(nsdg_p2p_timeouts_dev), sizeof(unsigned)));
-    NSDG_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(nsdg_p2p_timeouts_dev), &zero, sizeof(unsigned)));
-    *waits_given_up = n;
-    return NSDG_OK;
-}
 
 #ifdef NSDG_P2P_SPINSTAT
 extern "C" int nsdg_debug_p2p_spinstat(unsigned long long* out48) // [16] polls, then [32] phase cycles
@@ -561,7 +420,8 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j
     const nsdg_mevp_params& P = ctx->mevp;
     const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
     hipLaunchKernelGGL(mevp_fused4_kernel, dim3(ngroups), dim3(256), 0, ctx->stream, K, nst, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
-        ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg, u_new, v_new);
+        ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, P2PReport { ctx->p2p_count_dev, ctx->p2p_flag_dev }, S, u_old, v_old, packed, pg,
+        u_new, v_new);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }

@@ -16,6 +16,17 @@ void nsdg_set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+int nsdg_p2p_check(nsdg_ctx* ctx, const char* where)
+{
+    if (*(volatile unsigned*)ctx->p2p_flag_host)
+        ctx->p2p_given_up = 1;
+    if (!ctx->p2p_given_up)
+        return NSDG_OK;
+    nsdg_set_error("%s: a bounded wait of the mEVP pipeline gave up in an earlier launch on this context: its fields are wrong "
+                   "(nsdg_mevp_pipeline_health returns the count and clears this status)", where);
+    return NSDG_ERR_HIP;
+}
+
 extern "C" {
 
 int nsdg_abi_version(void) { return NSDG_ABI_VERSION; }
@@ -106,6 +117,22 @@ int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
         if (!(c->comm_deadline_s >= 0.))
             c->comm_deadline_s = 300.;
     }
+    // the report channel of the pipelines' bounded waits: a wait that gives up must reach the host without anybody asking
+    c->p2p_count_dev = nullptr, c->p2p_flag_host = nullptr, c->p2p_flag_dev = nullptr, c->p2p_given_up = 0;
+    hipError_t e = hipMalloc((void**)&c->p2p_count_dev, sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipMemset(c->p2p_count_dev, 0, sizeof(unsigned));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void**)&c->p2p_flag_host, sizeof(unsigned), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->p2p_flag_host = 0;
+        e = hipHostGetDevicePointer((void**)&c->p2p_flag_dev, c->p2p_flag_host, 0);
+    }
+    if (e != hipSuccess) {
+        nsdg_set_error("nsdg_ctx_create: allocating the pipeline report channel failed: %s", hipGetErrorString(e));
+        nsdg_ctx_destroy(c);
+        return NSDG_ERR_HIP;
+    }
     *out = c;
     return NSDG_OK;
 }
@@ -115,6 +142,14 @@ int nsdg_ctx_destroy(nsdg_ctx* ctx)
     if (!ctx)
         return NSDG_OK;
     nsdg_comm_finalize(ctx);
+    if (ctx->p2p_count_dev || ctx->p2p_flag_host) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream); // no launch may still hold the addresses
+        if (ctx->p2p_count_dev)
+            (void)hipFree(ctx->p2p_count_dev);
+        if (ctx->p2p_flag_host)
+            (void)hipHostFree(ctx->p2p_flag_host);
+    }
     delete ctx;
     return NSDG_OK;
 }
@@ -122,9 +157,26 @@ int nsdg_ctx_destroy(nsdg_ctx* ctx)
 int nsdg_ctx_synchronize(nsdg_ctx* ctx)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
-    if (ctx->comm) // a dead neighbour must not block this rank for ever
-        return nsdg_comm_bounded_drain(ctx);
+    if (ctx->comm) { // a dead neighbour must not block this rank for ever
+        const int rc = nsdg_comm_bounded_drain(ctx);
+        return rc ? rc : nsdg_p2p_check(ctx, __func__);
+    }
     NSDG_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return nsdg_p2p_check(ctx, __func__);
+}
+
+// waits of the pipelines that gave up since the last call (0 in a correct program); takes the events: the context's status is OK again
+int nsdg_mevp_pipeline_health(nsdg_ctx* ctx, uint32_t* waits_given_up)
+{
+    NSDG_CHECK_ARG(ctx && waits_given_up, "null argument");
+    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
+    NSDG_CHECK_HIP(hipStreamSynchronize(ctx->stream)); // no launch of this context is running: read and reset cannot lose an event
+    unsigned n = 0;
+    NSDG_CHECK_HIP(hipMemcpy(&n, ctx->p2p_count_dev, sizeof(unsigned), hipMemcpyDeviceToHost));
+    NSDG_CHECK_HIP(hipMemset(ctx->p2p_count_dev, 0, sizeof(unsigned)));
+    *(volatile unsigned*)ctx->p2p_flag_host = 0;
+    ctx->p2p_given_up = 0;
+    *waits_given_up = n;
     return NSDG_OK;
 }
 
@@ -210,7 +262,7 @@ int nsdg_mevp_occupancy_set(nsdg_ctx* ctx, int32_t waves_per_simd)
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
-    NSDG_CHECK_ARG(variant >= 0 && variant <= 4, "variant must be 0, 1, 2, 3 or 4");
+    NSDG_CHECK_ARG((variant >= 0 && variant <= 4) || variant == 8, "variant must be 0, 1, 2, 3, 4 or 8");
     ctx->mevp_variant = variant;
     return NSDG_OK;
 }

@@ -30,9 +30,17 @@ struct nsdg_ctx {
     nsdg_comm* comm; // row-block communicator (halo.hip), null until nsdg_comm_init*
     int64_t comm_group; // id of the local group the communicator belongs to
     double comm_deadline_s; // upper bound on any wait for a neighbour (0 = for ever)
+    // report channel of the mEVP pipelines' bounded waits (mevp_p2p.h): a device counter and a flag in mapped host memory
+    unsigned* p2p_count_dev;
+    unsigned* p2p_flag_host; // hipHostMalloc'ed; p2p_flag_dev is its device address
+    unsigned* p2p_flag_dev;
+    unsigned p2p_given_up; // sticky: events seen so far and not yet taken by nsdg_mevp_pipeline_health
 };
 
 void nsdg_set_error(const char* fmt, ...);
+// NSDG_ERR_HIP (sticky until nsdg_mevp_pipeline_health) if a bounded wait of an mEVP pipeline launched on this context has given up
+// in a launch that has completed; does not synchronise
+int nsdg_p2p_check(nsdg_ctx* ctx, const char* where);
 int nsdg_comm_bounded_drain(nsdg_ctx* ctx); // halo.hip: drain the context's streams within the communicator's deadline
 
 #define NSDG_CHECK_ARG(cond, msg)                                        \
