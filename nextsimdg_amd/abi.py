@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+GIVEN_UP_UNSEEN = 0  # waits of the mEVP pipeline that gave up on contexts that were closed without anybody asking (Context.close)
 LIB_PATH = os.environ.get("NSDG_LIB", os.path.join(HERE, "lib", "libnsdg.so"))  # NSDG_LIB: A/B builds of the same ABI
 
 c_double_p = C.POINTER(C.c_double)
@@ -317,7 +318,14 @@ class Context:
             raise NsdgError("nsdg error %d: %s" % (rc, self.lib.nsdg_last_error().decode()))
 
     def close(self):
+        """destroys the context; a wait of the mEVP pipeline that gave up on it and was never taken (pipeline_waits_given_up) is
+        added to the process-wide tally abi.GIVEN_UP_UNSEEN first: a session that ignored wrong results can still be told"""
+        global GIVEN_UP_UNSEEN
         if getattr(self, "h", None):
+            try:
+                GIVEN_UP_UNSEEN += self.pipeline_waits_given_up()
+            except Exception:
+                pass
             self.lib.nsdg_ctx_destroy(self.h)
             self.h = None
 
@@ -555,8 +563,9 @@ class Context:
                                                          _ptr_array(fields_out), *[_ptr(t) for t in adv]))
 
     def pipeline_waits_given_up(self):
-        """waits of the point-to-point mEVP pipeline (csrc/mevp_fused4.hip) that gave up since the last call: 0 in a correct program
-        (a non-zero count means wrong results of the launches in between); waits for the context's stream"""
+        """waits of the point-to-point mEVP pipelines (csrc/mevp_p2p.h) on THIS context that gave up since the last call: 0 in a correct
+        program (a non-zero count means wrong results of the launches in between, and synchronize / mevp_subcycle / the row-block
+        run raise NsdgError until this call has taken the events); waits for the context's stream"""
         n = C.c_uint32(0)
         self._call(self.lib.nsdg_mevp_pipeline_health(self.h, C.byref(n)))
         return int(n.value)

@@ -63,6 +63,40 @@ def build_lib(force=False, verbose=True, extra_flags=()):
     return LIB
 
 
+# Diagnostic builds of the same ABI: the sources named in `only` are recompiled with extra flags, everything else is the product's
+# objects.  "giveup": every wait of the mEVP pipelines gives up after ONE poll (csrc/mevp_p2p.h) -- the build that lets a test see the
+# report channel of a wait that gave up (tests/test_gpu_giveup.py); never loaded by the product.
+DIAG = {"giveup": (["-DNSDG_P2P_SPIN_LIMIT=1"], ["mevp_fused4.hip", "mevp_fused8.hip"])}
+
+
+def diag_lib_path(name):
+    return os.path.join(LIBDIR, "diag", name, "libnsdg.so")
+
+
+def build_diag(name, force=False, verbose=True):
+    flags, only = DIAG[name]
+    build_lib(verbose=verbose)
+    out = diag_lib_path(name)
+    deps = [os.path.join(CSRC, s) for s in only + HEADERS] + [os.path.abspath(__file__), LIB]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        if s in only:
+            o = os.path.join(os.path.dirname(out), s.replace(".hip", ".o"))
+            cmd = [hipcc()] + FLAGS + flags + ["-c", os.path.join(CSRC, s), "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lpthread"])
+    return out
+
+
 if __name__ == "__main__":
     build_lib(force="--force" in sys.argv)
     print("built", LIB)
+    for name in DIAG:
+        print("built", build_diag(name, force="--force" in sys.argv))

@@ -32,10 +32,19 @@ constexpr int P8_HAND = 32; // doubles per lane and hand-over slot: 24 stress co
 constexpr int P8_SLOT = P8_HAND * 64; // value k of lane l at (k / 2) * 128 + 2 l + k % 2 (16-byte pairs)
 constexpr int P8_HSLOTS = 2; // slots per link
 #ifndef NSDG_P8_PRING
+#ifdef NSDG_P8_TIMING
+#define NSDG_P8_PRING 10
+#else
 #define NSDG_P8_PRING 12
 #endif
+#endif
 constexpr int P8_PRING = NSDG_P8_PRING; // rows of the ice-strength ring: a row is in flight for ~8 march steps (loader's A .. last wave's B)
-constexpr int P8_LDS = 3 * P8_HSLOTS * P8_SLOT + P8_PRING * P2P_PSLOT; // doubles
+#ifdef NSDG_P8_TIMING
+constexpr int P8_STAGE = 24 * 64 + (NSDG_P8_TIMING == 2 ? 8 * 64 : 0); // the loader's next row of stress (and of u, v), filled by LDS-DMA
+#else
+constexpr int P8_STAGE = 0;
+#endif
+constexpr int P8_LDS = 3 * P8_HSLOTS * P8_SLOT + P8_PRING * P2P_PSLOT + P8_STAGE; // doubles
 constexpr int P8_RINGFLAG = 7; // counter index: last row whose ice strength the last wave's B has read
 static_assert(P8_LDS * 8 + 64 <= 160 * 1024, "LDS of a compute unit");
 
@@ -61,6 +70,21 @@ struct Wave8 {
     int lastB_final; // last row of the last wave's B (the loader's ring wait)
 };
 
+#ifdef NSDG_P8_TIMING
+// 16 bytes per lane from a per-lane address straight into LDS at lds_dst + 16 * lane; hidden from the compiler's s_waitcnt bookkeeping
+__device__ __forceinline__ void glds16(const double* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_stress(const double* __restrict__ a, long t, double* lds_stage, int comp)
+{
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) double*)lds_stage + comp * 4 * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        glds16(a + t + 128 * k, __builtin_amdgcn_readfirstlane(base + k * 1024));
+}
+#endif
 // One march step of one wave.  FIRST: the loader (wave 0): A's inputs from memory, ice strength into the ring.
 template <bool FIRST>
 __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, int t, RowSet8& cur, RowSet8& prev, Fetch8& f, TopCarry3& ca, TopCarry3& cb,
@@ -71,10 +95,17 @@ __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, in
     const int ix = M.ix, nn = M.nn;
     double* const ring = lds + 3 * P8_HSLOTS * P8_SLOT;
     const int nrow = min(t + 1, G.lastA); // the row A works on next
+#if defined(NSDG_P8_TIMING) && NSDG_P8_TIMING == 2
+    constexpr bool LOADS = false; // TIMING ONLY: the loader computes on what it finds in LDS (garbage), like a stage wave; its memory traffic is LDS-DMA
+    const int sp = FIRST ? 2 : s - 1;
+#else
+    constexpr bool LOADS = FIRST;
+    const int sp = s - 1;
+#endif
     // ================================================================================== A(t): sub-iteration 2 s on row t -> cur
     if (t <= G.lastA) { // wave-uniform (the last step of a strip that ends at the top boundary only drains B)
         double ul[9], vl[9], uu[4], vv[4], P[9];
-        if (FIRST) {
+        if (LOADS) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 ul[a] = f.ub[a], ul[3 + a] = f.um[a], ul[6 + a] = f.ut[a];
@@ -87,10 +118,11 @@ __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, in
             vv[0] = vl[0], vv[1] = vl[1], vv[2] = vl[3], vv[3] = vl[4];
         } else {
             // the previous wave has handed over this row and the row above it (whose bottom nodes are this row's top nodes)
-            (void)flag_wait(flags, s - 1, min(t + 1, G.lastB_prev), rep);
+            if (!FIRST)
+                (void)flag_wait(flags, s - 1, min(t + 1, G.lastB_prev), rep);
             ring_read_P<P8_PRING>(ring, t, M.lane, P); // written by the loader before it handed row t over: done[s - 1] >= t + 1 implies its A(t)
-            const double* in = lds + ((s - 1) * P8_HSLOTS + (t & 1)) * P8_SLOT + 2 * M.lane;
-            const double* top = lds + ((s - 1) * P8_HSLOTS + ((t + 1) & 1)) * P8_SLOT + 2 * M.lane;
+            const double* in = lds + (sp * P8_HSLOTS + (t & 1)) * P8_SLOT + 2 * M.lane;
+            const double* top = lds + (sp * P8_HSLOTS + ((t + 1) & 1)) * P8_SLOT + 2 * M.lane;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const double2 a = lds_pair_p(in, 12 + k), b = lds_pair_p(in, 14 + k);
@@ -105,13 +137,24 @@ __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, in
         double r11[8], r12[8], r22[8];
         stress_projected(ul, vl, P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
         __builtin_amdgcn_sched_barrier(0);
-        if (FIRST) {
+        if (LOADS) {
             // the ice strength of this row goes to the ring (slot of row t - 12: the last wave's B has passed it)
             (void)flag_wait(flags, P8_RINGFLAG, min(t - P8_PRING, G.lastB_final), rep);
             ring_write_P<P8_PRING>(ring, t, M.lane, P);
+#ifdef NSDG_P8_TIMING
+            {
+                const double* st = ring + P8_PRING * P2P_PSLOT + 2 * M.lane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double2 a = lds_pair_p(st, k), b = lds_pair_p(st, 4 + k), c = lds_pair_p(st, 8 + k);
+                    cur.s11[2 * k] = a.x, cur.s11[2 * k + 1] = a.y, cur.s12[2 * k] = b.x, cur.s12[2 * k + 1] = b.y, cur.s22[2 * k] = c.x, cur.s22[2 * k + 1] = c.y;
+                }
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 cur.s11[i] = f.s11[i], cur.s12[i] = f.s12[i], cur.s22[i] = f.s22[i];
+#endif
             // requests for the next row: ice strength, u, v (its bottom node row is this row's top one)
             tile_load9_p<(NSDG_P2P_NT & 4) != 0>(pg, tile_off(ix, nrow, M.ntx, 9), ix & 63, f.P);
             if (nrow > t) {
@@ -125,21 +168,43 @@ __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, in
             fetch_nodes_p(u_old, nVn + 2 * nn, f.ut);
             fetch_nodes_p(v_old, nVn + 2 * nn, f.vt);
         } else {
-            const double* in = lds + ((s - 1) * P8_HSLOTS + (t & 1)) * P8_SLOT + 2 * M.lane;
+            const double* in = lds + (sp * P8_HSLOTS + (t & 1)) * P8_SLOT + 2 * M.lane;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const double2 a = lds_pair_p(in, k), b = lds_pair_p(in, 4 + k), c = lds_pair_p(in, 8 + k);
                 cur.s11[2 * k] = a.x, cur.s11[2 * k + 1] = a.y, cur.s12[2 * k] = b.x, cur.s12[2 * k + 1] = b.y, cur.s22[2 * k] = c.x, cur.s22[2 * k + 1] = c.y;
             }
-            flag_publish(flags, 3 + s - 1, t); // this row's slot has been taken: the producer may write row t + 2 into it
+            if (!FIRST)
+                flag_publish(flags, 3 + s - 1, t); // this row's slot has been taken: the producer may write row t + 2 into it
         }
         stress_relax(M.ialpha, r11, r12, r22, cur.s11, cur.s12, cur.s22);
         __builtin_amdgcn_sched_barrier(0);
         if (FIRST) { // stress of the next row
             const long ts = tile_off(ix, nrow, M.ntx, 8);
+#ifdef NSDG_P8_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staging buffer has been read
+            double* st = ring + P8_PRING * P2P_PSLOT;
+            glds_stress(S.i11, ts, st, 0);
+            glds_stress(S.i12, ts, st, 1);
+            glds_stress(S.i22, ts, st, 2);
+#if NSDG_P8_TIMING == 2
+            {
+                // ice strength of the next row straight into its ring slot (the ninth value is skipped), u, v of its two new node rows
+                (void)flag_wait(flags, P8_RINGFLAG, min(nrow - P8_PRING, G.lastB_final), rep);
+                glds_stress(pg, tile_off(ix, nrow, M.ntx, 9), ring + (nrow % P8_PRING) * P2P_PSLOT, 0);
+                const unsigned ub = (unsigned)(size_t)(__attribute__((address_space(3))) double*)(st + 24 * 64);
+                const long nVn = (long)(2 * nrow) * nn + 2 * ix;
+                glds16(u_old + nVn + nn, __builtin_amdgcn_readfirstlane(ub));
+                glds16(v_old + nVn + nn, __builtin_amdgcn_readfirstlane(ub + 1024));
+                glds16(u_old + nVn + 2 * nn, __builtin_amdgcn_readfirstlane(ub + 2048));
+                glds16(v_old + nVn + 2 * nn, __builtin_amdgcn_readfirstlane(ub + 3072));
+            }
+#endif
+#else
             tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i11, ts, f.s11);
             tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i12, ts, f.s12);
             tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i22, ts, f.s22);
+#endif
         }
         {
             double cx[9], cy[9];
@@ -177,7 +242,12 @@ __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, in
         {
             double cx[9], cy[9];
             node_contrib_all(prev.s11, prev.s12, prev.s22, M.hx, M.hy, cx, cy);
+#ifdef NSDG_P8_TIMING
+            // TIMING ONLY (wrong values): the loader's B uses A's coefficients, so that the loader carries one set of them, not two
+            owned_node_updates(M, r > 0, FIRST ? cur.c : prev.c, prev.u, prev.v, cb, cx, cy, un, vn);
+#else
             owned_node_updates(M, r > 0, prev.c, prev.u, prev.v, cb, cx, cy, un, vn);
+#endif
             if (r < G.updB0) { // wave-uniform
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -304,9 +374,19 @@ __global__ __launch_bounds__(256) void mevp_fused8_kernel(NodalConsts K, int nx,
         fetch_nodes_p(v_old, nV + M.nn, f.vm);
         fetch_nodes_p(u_old, nV + 2 * M.nn, f.ut);
         fetch_nodes_p(v_old, nV + 2 * M.nn, f.vt);
+#ifdef NSDG_P8_TIMING
+        {
+            double* st = lds + 3 * P8_HSLOTS * P8_SLOT + P8_PRING * P2P_PSLOT;
+            glds_stress(S.i11, ts, st, 0);
+            glds_stress(S.i12, ts, st, 1);
+            glds_stress(S.i22, ts, st, 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#else
         tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i11, ts, f.s11);
         tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i12, ts, f.s12);
         tile_load8_p<(NSDG_P2P_NT & 1) != 0>(S.i22, ts, f.s22);
+#endif
         tile_load9_p<(NSDG_P2P_NT & 4) != 0>(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
         request_c_p(M, row, X.c, packed);
         for (int t = G.firstA; t <= tend; t += 2) {

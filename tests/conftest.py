@@ -30,17 +30,14 @@ def gpu():
 
 @pytest.fixture(scope="session", autouse=True)
 def _no_pipeline_wait_gave_up():
-    """the point-to-point mEVP pipeline (csrc/mevp_fused4.hip) bounds every wait and counts the waits that gave up
-    (nsdg_mevp_pipeline_health): after a GPU session the counter must be zero (a non-zero count means a dependency was waited
-    for that never came: wrong results)"""
+    """the point-to-point mEVP pipelines (csrc/mevp_p2p.h) bound every wait and report the waits that gave up per context: an error
+    status from nsdg_ctx_synchronize / nsdg_mevp_subcycle / nsdg_rb_mevp_run, a count from nsdg_mevp_pipeline_health.  Tests that
+    synchronise through torch never see the status, so every Context adds what nobody took to abi.GIVEN_UP_UNSEEN when it is closed:
+    after a GPU session the tally must be zero (a non-zero count means a dependency was waited for that never came: wrong results)"""
     yield
-    import torch
-
     from nextsimdg_amd import abi
 
-    if abi._lib is None or not torch.cuda.is_available():
-        return
-    ctx = abi.Context(torch.device("cuda:0"))
-    n = ctx.pipeline_waits_given_up()
-    ctx.close()
-    assert n == 0, "the mEVP pipeline gave up %d wait(s)" % n
+    import gc
+
+    gc.collect()  # contexts that were dropped without close()
+    assert abi.GIVEN_UP_UNSEEN == 0, "the mEVP pipeline gave up %d wait(s)" % abi.GIVEN_UP_UNSEEN
