@@ -415,9 +415,10 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=None, help="rows per strip of the fused mEVP kernel")
     ap.add_argument("--transport-variant", type=int, default=None, help="transport stage kernel: 0 one element per lane, 2 two elements per lane (default: library default = 2)")
     ap.add_argument("--occupancy", type=int, default=None, help="waves/SIMD budget of the fused mEVP kernel (1 or 2)")
-    ap.add_argument("--passes-per-exchange", type=int, default=3,
+    ap.add_argument("--passes-per-exchange", type=int, default=2,
                     help="N > 1: mEVP kernel passes (v = 4 sub-iterations each with the default kernel) between two ghost-row exchanges "
-                         "(ghost depth v k / v k - 1 rows); default 3")
+                         "(ghost depth v k / v k - 1 rows); default 2: the best of the rehearsed 8-block runs at both modelled link rates "
+                         "(DESIGN.md section 8; rounds 4-5 used 3)")
     ap.add_argument("--tune-passes", type=str, default="",
                     help="N > 1, explicit opt-in: comma-separated candidates for --passes-per-exchange, e.g. 2,3,6: each is run for two un-timed "
                          "steps in the warm-up (a context and a communicator of its own) and the fastest is kept.  Off by default: a plain "
@@ -462,9 +463,17 @@ def main():
         with stdout_to_stderr():
             import datetime
 
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=TORCH_TIMEOUT_S))
+            # ONE RCCL communicator per rank -- the library's, which moves the ghost rows.  What torch.distributed does here is control
+            # plane only (the 128 bytes of the RCCL id, the barriers around the timed region, MAX / MIN over the ranks of a few doubles,
+            # the per-rank reports): the gloo backend on CPU tensors.  Two communicators on one device were ordered against each other
+            # by convention only (round-5 review); --halo torch (ghost rows as torch P2P ops on device tensors) still needs nccl.
+            if args.halo == "torch":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=datetime.timedelta(seconds=TORCH_TIMEOUT_S))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=TORCH_TIMEOUT_S))
             dist.barrier()  # the first collective creates torch's communicator (and waits for rank 0's build)
             torch.cuda.synchronize()
+    red_device = device if (use_dist and args.halo == "torch") else torch.device("cpu")  # where the tensors of torch's reductions live
 
     if args.workload in ("column", "transport"):
         if world != 1:
@@ -528,8 +537,8 @@ def main():
         return c, b, d, ex, nat, co
 
     def drain(c, ex):
-        # drain this rank's own work first: the ghost exchanges run on the library's RCCL communicator, the barrier on
-        # torch's -- two communicators are never given work at the same time.  With neighbours the drain is BOUNDED
+        # drain this rank's own work first, then meet the others on the host (torch's barrier is gloo: no device work, the library's RCCL
+        # communicator is the only one this rank owns).  With neighbours the drain is BOUNDED
         # (nsdg_ctx_synchronize polls the streams against the communicator's deadline): a rank whose neighbour has died
         # leaves with a non-zero status instead of waiting in ncclRecv for ever; the launcher then ends the others.
         if ex is not None:
@@ -544,8 +553,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Passes per exchange: a fixed 3 by default (with a transfer time proportional to the bytes few passes
-    # per exchange win, and the first runs on real links should be boring: ONE context, ONE library communicator).  What a
+    # Passes per exchange: a fixed 2 by default (with a transfer time proportional to the bytes few passes
+    # per exchange win -- 2 was the best of the rehearsed 8-block runs at both modelled link rates -- and the first runs on real links
+    # should be boring: ONE context, ONE library communicator).  What a
     # transfer costs on the machine -- mostly latency or mostly bandwidth -- is only known there, so --tune-passes K1,K2,...
     # tries the candidates during the warm-up, two un-timed steps each, and keeps the fastest (max over ranks).
     tune = None
@@ -566,7 +576,7 @@ def main():
             for _ in range(2):
                 co_.step()
             drain(c_, ex_)
-            tt = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device=device)
+            tt = torch.tensor([(time.perf_counter() - t0) / 2], dtype=torch.float64, device=red_device)
             if use_dist:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tune[cand] = {"ms_per_step": 1e3 * float(tt[0]), "ghost_depth": d_}
@@ -606,7 +616,7 @@ def main():
         elapsed = time.perf_counter() - t0
         where = "reduction over the ranks"
         own_elapsed = elapsed
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -624,13 +634,13 @@ def main():
         where = "validity checks"
         # ---- validity of the run: finite, non-trivial, and the fused pass still equals single sub-iterations bit for bit
         ok = torch.tensor([float(bool(torch.isfinite(core.u).all() and torch.isfinite(core.H).all())), float(core.u.abs().max())],
-                          dtype=torch.float64, device=device)
+                          dtype=torch.float64, device=red_device)
         guard = None if args.no_guard else fused_pass_guard(ctx, core)
         gave_up = ctx.pipeline_waits_given_up()  # bounded waits of the stage-per-wave pipeline that hit their bound: must be none
         if gave_up:
             guard = False
             sys.stderr.write("bench.py rank %d: %d wait(s) of the mEVP pipeline gave up\n" % (rank, gave_up))
-        ok = torch.cat([ok, torch.tensor([float(guard is not False)], dtype=torch.float64, device=device)])
+        ok = torch.cat([ok, torch.tensor([float(guard is not False)], dtype=torch.float64, device=red_device)])
         if use_dist:
             lo = ok.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)

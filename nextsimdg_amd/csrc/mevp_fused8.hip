@@ -40,7 +40,7 @@ constexpr int P8_HSLOTS = 2; // slots per link
 #endif
 constexpr int P8_PRING = NSDG_P8_PRING; // rows of the ice-strength ring: a row is in flight for ~8 march steps (loader's A .. last wave's B)
 #ifdef NSDG_P8_TIMING
-constexpr int P8_STAGE = 24 * 64 + (NSDG_P8_TIMING == 2 ? 8 * 64 : 0); // the loader's next row of stress (and of u, v), filled by LDS-DMA
+constexpr int P8_STAGE = 24 * 64 + (NSDG_P8_TIMING >= 2 ? 8 * 64 : 0); // the loader's next row of stress (and of u, v), filled by LDS-DMA
 #else
 constexpr int P8_STAGE = 0;
 #endif
@@ -95,7 +95,7 @@ __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, in
     const int ix = M.ix, nn = M.nn;
     double* const ring = lds + 3 * P8_HSLOTS * P8_SLOT;
     const int nrow = min(t + 1, G.lastA); // the row A works on next
-#if defined(NSDG_P8_TIMING) && NSDG_P8_TIMING == 2
+#if defined(NSDG_P8_TIMING) && NSDG_P8_TIMING >= 2
     constexpr bool LOADS = false; // TIMING ONLY: the loader computes on what it finds in LDS (garbage), like a stage wave; its memory traffic is LDS-DMA
     const int sp = FIRST ? 2 : s - 1;
 #else
@@ -181,7 +181,9 @@ __device__ __forceinline__ void p8_step(const MarchConst3& M, const Wave8& G, in
         __builtin_amdgcn_sched_barrier(0);
         if (FIRST) { // stress of the next row
             const long ts = tile_off(ix, nrow, M.ntx, 8);
-#ifdef NSDG_P8_TIMING
+#if defined(NSDG_P8_TIMING) && NSDG_P8_TIMING == 3
+            (void)ts; // mode 3: no memory traffic at all in the loader (the speed of the stage arithmetic and hand-over alone)
+#elif defined(NSDG_P8_TIMING)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staging buffer has been read
             double* st = ring + P8_PRING * P2P_PSLOT;
             glds_stress(S.i11, ts, st, 0);

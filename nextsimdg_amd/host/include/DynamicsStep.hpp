@@ -27,7 +27,7 @@
 //     dynamics.thermodynamics  run the column physics first       (false)
 //     dynamics.forcing       thermodynamic forcing: host (the structure's planes, constant in time) | dummy | winter
 //                            (generated on the device at every step's model time, wind speed from the dynamics' wind)
-//     dynamics.row_blocks, dynamics.devices, dynamics.passes_per_exchange (3), dynamics.overlap (true),
+//     dynamics.row_blocks, dynamics.devices, dynamics.passes_per_exchange (2), dynamics.overlap (true),
 //     dynamics.graph (false), dynamics.loopback_world (0: off; N: rehearse an interior block of N on one GPU with
 //     real RCCL send/recv to the rank itself -- values wrap around, for timing and call-path checks only)
 // The structure's cell means initialise the DG fields: H <- hice, A <- cice (coefficient 0; higher coefficients

@@ -126,7 +126,7 @@ void DynamicsStep::configure()
     beta = getConfiguration(keyMap.at(3), 0.);
     thermo = getConfiguration(keyMap.at(4), false);
     rowBlocks = getConfiguration(keyMap.at(5), 1);
-    passesPerExchange = getConfiguration(keyMap.at(6), 3);
+    passesPerExchange = getConfiguration(keyMap.at(6), 2); // the best of the rehearsed 8-block runs at both modelled link rates
     overlap = getConfiguration(keyMap.at(7), true);
     graph = getConfiguration(keyMap.at(8), false);
     forcing = getConfiguration(keyMap.at(9), std::string("host"));

@@ -41,7 +41,7 @@ def test_eight_ranks_plan_the_real_2048_blocks():
     assert len(lines) == 1, p.stdout.decode()
     L = lines[0]
     assert L["n_gpus"] == 8 and L["rows_total"] == 2048 and L["max_rank_seen"] == 7 and L["value"] is None
-    assert L["ghost_depth"] == [12, 11] and L["passes_per_exchange"] == 3 and L["subiterations_per_pass"] == 4
+    assert L["ghost_depth"] == [8, 7] and L["passes_per_exchange"] == 2 and L["subiterations_per_pass"] == 4
     ranks = L["ranks"]
     assert [r["rank"] for r in ranks] == list(range(8))
     first = 0
