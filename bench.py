@@ -664,7 +664,7 @@ def main():
     full, twos, ones = core.passes_per_step()
     per_launch = core.per_pass if full else (2 if twos else 1)
     launches = full if full else (twos if twos else ones)  # launches of the dominant kernel per sub-cycle
-    fused_kernel = "mevp_fused8_kernel" if per_launch == 8 else ("mevp_fused4_kernel" if per_launch >= 2 else "mevp_fused_kernel")  # passes of 2, 3 and 4 sub-iterations are one kernel
+    fused_kernel = "mevp_fused4_kernel" if per_launch >= 2 else "mevp_fused_kernel"  # passes of 2, 3 and 4 sub-iterations are one kernel
     if rank == 0:
         n_elem = nx * ny
         value = n_elem * args.steps / elapsed
@@ -742,7 +742,7 @@ def main():
                                depth[0], depth[1], core.group_passes,
                                " (--tune-passes, chosen in the warm-up: %s)" % ", ".join("%d passes %.3f ms/step" % (k_, t_["ms_per_step"]) for k_, t_ in sorted(tune.items())) if tune else "",
                                args.halo) if eff_world > 1 else ""),
-                       "mevp_passes": "%s sub-iteration%s per kernel pass" % ({8: "eight", 4: "four", 3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
+                       "mevp_passes": "%s sub-iteration%s per kernel pass" % ({4: "four", 3: "three", 2: "two", 1: "one"}[per_launch], "s" if per_launch > 1 else ""),
                        "mevp_variant": args.variant if args.variant is not None else "default",
                        "closure": "off (--no-closure: the bare scheme)" if args.no_closure else
                                   "on: ridging cap + scaling limiter in the transport epilogue, free drift at ice-free nodes (include/nsdg.h)",
@@ -806,7 +806,7 @@ def plan_blocks(variant, passes_per_exchange, nx, ny, rank, world):
     """row block of `rank`: ghost element rows below / above are (v k, v k - 1) for k passes of v sub-iterations
     between two exchanges"""
     kpass = max(1, min(passes_per_exchange, (ny // world) // 16)) if world > 1 else 1
-    vpass = 8 if variant == 8 else min(variant, 4)
+    vpass = min(variant, 4)
     depth = (vpass * kpass, vpass * kpass - 1) if vpass >= 2 else (1, 1)
     return rowblock.RowBlock(nx, ny, rank, world, *depth), depth
 

@@ -185,10 +185,8 @@ int nsdg_grid_set(nsdg_ctx* ctx, int32_t nx, int32_t ny, double hx, double hy);
  * stage-per-wave pipeline (csrc/mevp_fused4.hip: one pipeline stage per wave of a four-wave workgroup, hand-over point to point
  * through LDS; nsdg_mevp_iterate2 / 3 / 4, nsdg_mevp_subcycle; what is left of a sub-cycle whose length is no multiple of the
  * variant runs as a shorter pass of the same kernel, a single sub-iteration on the kernel of variant 1).
- * 8 = passes of eight on the same pipeline with TWO sub-iterations per stage wave (csrc/mevp_fused8.hip; nsdg_mevp_iterate8), what is
- * left of a sub-cycle through the passes of 4, 3, 2 and 1.
- * NSDG_MEVP_DEFAULT_VARIANT (4) is the default of a new context.  Variants 1, 2, 3, 4 and 8 agree bit for bit, variant 0 to fp64
- * round-off.  (Rounds 1-4 had kernels of their own for 2 and 3 sub-iterations per pass -- two / three stages in ONE wave --
+ * NSDG_MEVP_DEFAULT_VARIANT (4) is the default of a new context.  Variants 1, 2, 3 and 4 agree bit for bit, variant 0 to fp64
+ * round-off.  (Round 6 built passes of EIGHT -- two sub-iterations per stage wave -- bit-exact and slower: profiles/r06_fused8.md.)  (Rounds 1-4 had kernels of their own for 2 and 3 sub-iterations per pass -- two / three stages in ONE wave --
  * and a four-stage kernel with one workgroup barrier per march step: superseded, see the history of csrc/.) */
 #define NSDG_MEVP_DEFAULT_VARIANT 4
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant);
@@ -349,20 +347,6 @@ int nsdg_mevp_iterate4_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
     const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old, double* u_new,
     double* v_new, const double* packed, const double* pg);
 
-/* EIGHT complete sub-iterations in one pass on the owned element rows [j0, j1) (csrc/mevp_fused8.hip: the stage-per-wave pipeline with
- * two sub-iterations per stage wave): reads S_in, u_old on rows j0-8 .. j1+6 and writes S_out = S^{p+8} on rows [j0, j1) and
- * u_new = u^{p+8} on the nodes they own.  j0 == 0 or j0 >= 8 (eight ghost rows below); j1 == ny or j1 + 7 <= ny (seven ghost rows
- * above).  Requires variant 8.  Bit-identical to eight calls of nsdg_mevp_iterate. */
-int nsdg_mevp_iterate8(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11_in, const double* s12_in,
-    const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old,
-    double* u_new, double* v_new, const double* packed, const double* pg);
-
-/* The same on TWO disjoint row ranges in ONE launch (see nsdg_mevp_iterate3_pair); each range obeys the ghost-row
- * conditions of nsdg_mevp_iterate8; bit-identical to two calls. */
-int nsdg_mevp_iterate8_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b, int32_t j1b, const double* s11_in, const double* s12_in,
-    const double* s22_in, double* s11_out, double* s12_out, double* s22_out, const double* u_old, const double* v_old, double* u_new,
-    double* v_new, const double* packed, const double* pg);
-
 /* nsub sub-iterations over the whole local array (packs the nodal coefficients, then iterates);
  * result in s11/s12/s22 and u, v (u0/v0 may be the same arrays as u/v).  scratch: 10*(2nx+1)*(2ny+1) + 24*nx*ny doubles, 16-byte aligned
  * (packed coefficients + ping-pong copies of the velocity and the stress). */
@@ -370,7 +354,7 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
     double* v, const double* u0, const double* v0, const double* tax, const double* tay, const double* uo,
     const double* vo, const double* cgh, const double* cga, const double* pg, double* scratch);
 
-/* The waits of the stage-per-wave pipelines (csrc/mevp_fused4.hip, mevp_fused8.hip; csrc/mevp_p2p.h) are bounded: a wave that waits for
+/* The waits of the stage-per-wave pipeline (csrc/mevp_fused4.hip, csrc/mevp_p2p.h) are bounded: a wave that waits for
  * a hand-over longer than ~0.2 s gives up, releases the other waits of its workgroup and reports the event -- the launch then finishes
  * with WRONG results instead of hanging the GPU.  The report reaches the host without being asked for: the kernel sets a flag in host
  * memory that belongs to the context, and from then on nsdg_ctx_synchronize (after the launch has completed), nsdg_mevp_subcycle and

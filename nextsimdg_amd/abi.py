@@ -121,8 +121,6 @@ SYMBOLS = {
     "nsdg_mevp_iterate3_pair": (C.c_int, [VP, I32, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate4": (C.c_int, [VP, I32, I32] + [VP] * 12),
     "nsdg_mevp_iterate4_pair": (C.c_int, [VP, I32, I32, I32, I32] + [VP] * 12),
-    "nsdg_mevp_iterate8": (C.c_int, [VP, I32, I32] + [VP] * 12),
-    "nsdg_mevp_iterate8_pair": (C.c_int, [VP, I32, I32, I32, I32] + [VP] * 12),
     "nsdg_mevp_pipeline_health": (C.c_int, [VP, C.POINTER(C.c_uint32)]),
     "nsdg_mevp_strip_rows_set": (C.c_int, [VP, I32]),
     "nsdg_mevp_occupancy_set": (C.c_int, [VP, I32]),
@@ -675,23 +673,10 @@ class Context:
     def bind_mevp_iterate4(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         return self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=4)
 
-    def mevp_iterate8(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
-        """eight sub-iterations in one pass on the owned rows [j0, j1) (variant 8: two sub-iterations per stage wave)"""
-        self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=8)()
-
-    def mevp_iterate8_pair(self, ra, rb, s_in, s_out, uv_old, uv_new, packed, pg):
-        """eight sub-iterations on two disjoint row ranges ra = (j0, j1), rb = (j0, j1) in one launch"""
-        ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
-        _check_f64(*ts)
-        self._call(self.lib.nsdg_mevp_iterate8_pair(self.h, ra[0], ra[1], rb[0], rb[1], *[_ptr(t) for t in ts]))
-
-    def bind_mevp_iterate8(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
-        return self.bind_mevp_iterate2(j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=8)
-
     def bind_mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg, passes=2):
         ts = [s_in[0], s_in[1], s_in[2], s_out[0], s_out[1], s_out[2], uv_old[0], uv_old[1], uv_new[0], uv_new[1], packed, pg]
         _check_f64(*ts)
-        fn = {2: self.lib.nsdg_mevp_iterate2, 3: self.lib.nsdg_mevp_iterate3, 4: self.lib.nsdg_mevp_iterate4, 8: self.lib.nsdg_mevp_iterate8}[passes]
+        fn = {2: self.lib.nsdg_mevp_iterate2, 3: self.lib.nsdg_mevp_iterate3, 4: self.lib.nsdg_mevp_iterate4}[passes]
         args = (self.h, I32(j0), I32(j1)) + tuple(_ptr(t) for t in ts)
         keep = ts
 

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnsdg.so")
-SOURCES = ["nsdg_ctx.hip", "column_step.hip", "transport.hip", "mevp.hip", "mevp_fused.hip", "mevp_fused4.hip", "mevp_fused8.hip", "halo.hip", "rowblock.hip", "forcing.hip"]
+SOURCES = ["nsdg_ctx.hip", "column_step.hip", "transport.hip", "mevp.hip", "mevp_fused.hip", "mevp_fused4.hip", "halo.hip", "rowblock.hip", "forcing.hip"]
 HEADERS = ["nsdg_internal.h", "dg_tables.h", "mevp_common.h", "mevp_pipeline.h", "mevp_p2p.h", os.path.join("..", "..", "include", "nsdg.h")]
 # -ffp-contract=on: fuse a*b+c only where it is written as one expression (decided in the front end), so
 # that the same inlined device function rounds identically in every kernel it is inlined into -- the
@@ -66,7 +66,7 @@ def build_lib(force=False, verbose=True, extra_flags=()):
 # Diagnostic builds of the same ABI: the sources named in `only` are recompiled with extra flags, everything else is the product's
 # objects.  "giveup": every wait of the mEVP pipelines gives up after ONE poll (csrc/mevp_p2p.h) -- the build that lets a test see the
 # report channel of a wait that gave up (tests/test_gpu_giveup.py); never loaded by the product.
-DIAG = {"giveup": (["-DNSDG_P2P_SPIN_LIMIT=1"], ["mevp_fused4.hip", "mevp_fused8.hip"])}
+DIAG = {"giveup": (["-DNSDG_P2P_SPIN_LIMIT=1"], ["mevp_fused4.hip"])}
 
 
 def diag_lib_path(name):

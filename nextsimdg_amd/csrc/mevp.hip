@@ -351,10 +351,6 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg);
 
-// defined in mevp_fused8.hip: a pass of eight sub-iterations (two per stage wave)
-int nsdg_launch_mevp_fused8_ranges(nsdg_ctx* ctx, int j0, int j1, int j0b, int j1b, const double* s11i, const double* s12i, const double* s22i, double* s11,
-    double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed, const double* pg);
-
 static NodalConsts nodal_consts(const nsdg_ctx* ctx)
 {
     const nsdg_mevp_params& P = ctx->mevp;
@@ -532,7 +528,7 @@ int nsdg_mevp_iterate2(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     if (ctx->mevp_variant >= 2) // a pass of the stage-per-wave pipeline with two stages
         return nsdg_launch_mevp_fused4_ranges(ctx, 2, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-    nsdg_set_error("nsdg_mevp_iterate2: select variant 2, 3, 4 or 8 (nsdg_mevp_variant_set) or call nsdg_mevp_iterate twice");
+    nsdg_set_error("nsdg_mevp_iterate2: select variant 2, 3 or 4 (nsdg_mevp_variant_set) or call nsdg_mevp_iterate twice");
     return NSDG_ERR_STATE;
 }
 
@@ -558,7 +554,7 @@ int nsdg_mevp_iterate3(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     if (ctx->mevp_variant >= 3) // ... with three stages
         return nsdg_launch_mevp_fused4_ranges(ctx, 3, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-    nsdg_set_error("nsdg_mevp_iterate3: select variant 3, 4 or 8 (nsdg_mevp_variant_set)");
+    nsdg_set_error("nsdg_mevp_iterate3: select variant 3 or 4 (nsdg_mevp_variant_set)");
     return NSDG_ERR_STATE;
 }
 
@@ -583,7 +579,7 @@ int nsdg_mevp_iterate3_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
         return NSDG_ERR_STATE;
     }
     if (ctx->mevp_variant < 3) {
-        nsdg_set_error("nsdg_mevp_iterate3_pair: select variant 3, 4 or 8 (nsdg_mevp_variant_set)");
+        nsdg_set_error("nsdg_mevp_iterate3_pair: select variant 3 or 4 (nsdg_mevp_variant_set)");
         return NSDG_ERR_STATE;
     }
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
@@ -612,7 +608,7 @@ int nsdg_mevp_iterate4(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     if (ctx->mevp_variant >= 4)
         return nsdg_launch_mevp_fused4_ranges(ctx, 4, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-    nsdg_set_error("nsdg_mevp_iterate4: select variant 4 or 8 (nsdg_mevp_variant_set)");
+    nsdg_set_error("nsdg_mevp_iterate4: select variant 4 (nsdg_mevp_variant_set)");
     return NSDG_ERR_STATE;
 }
 
@@ -637,65 +633,11 @@ int nsdg_mevp_iterate4_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b
         return NSDG_ERR_STATE;
     }
     if (ctx->mevp_variant < 4) {
-        nsdg_set_error("nsdg_mevp_iterate4_pair: select variant 4 or 8 (nsdg_mevp_variant_set)");
+        nsdg_set_error("nsdg_mevp_iterate4_pair: select variant 4 (nsdg_mevp_variant_set)");
         return NSDG_ERR_STATE;
     }
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
     return nsdg_launch_mevp_fused4_ranges(ctx, 4, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-}
-
-int nsdg_mevp_iterate8(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11i, const double* s12i, const double* s22i,
-    double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
-    const double* packed, const double* pg)
-{
-    NSDG_NEED_GRID(ctx);
-    NSDG_CHECK_ARG(0 <= j0 && j0 <= j1 && j1 <= ctx->ny, "row range outside the local array");
-    NSDG_CHECK_ARG(j0 == 0 || j0 >= 8, "need eight ghost rows below the owned rows (or j0 == 0 at the physical boundary)");
-    NSDG_CHECK_ARG(j1 == ctx->ny || j1 + 7 <= ctx->ny, "need seven ghost rows above the owned rows (or j1 == ny at the physical boundary)");
-    NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed && pg,
-        "null field pointer");
-    NSDG_CHECK_TILED(s11i, s12i, s22i, s11, s12, s22, pg);
-    NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
-    NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
-    if (!(ctx->pack_dt > 0)) {
-        nsdg_set_error("nsdg_mevp_iterate8: nsdg_mevp_pack_nodal was not called on this context");
-        return NSDG_ERR_STATE;
-    }
-    if (j0 == j1)
-        return NSDG_OK;
-    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    if (ctx->mevp_variant == 8)
-        return nsdg_launch_mevp_fused8_ranges(ctx, j0, j1, 0, 0, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
-    nsdg_set_error("nsdg_mevp_iterate8: select variant 8 (nsdg_mevp_variant_set)");
-    return NSDG_ERR_STATE;
-}
-
-int nsdg_mevp_iterate8_pair(nsdg_ctx* ctx, int32_t j0a, int32_t j1a, int32_t j0b, int32_t j1b, const double* s11i, const double* s12i,
-    const double* s22i, double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new,
-    const double* packed, const double* pg)
-{
-    NSDG_NEED_GRID(ctx);
-    for (int k = 0; k < 2; ++k) {
-        const int j0 = k ? j0b : j0a, j1 = k ? j1b : j1a;
-        NSDG_CHECK_ARG(0 <= j0 && j0 < j1 && j1 <= ctx->ny, "row range outside the local array (or empty)");
-        NSDG_CHECK_ARG(j0 == 0 || j0 >= 8, "need eight ghost rows below the rows of a range (or j0 == 0 at the physical boundary)");
-        NSDG_CHECK_ARG(j1 == ctx->ny || j1 + 7 <= ctx->ny, "need seven ghost rows above the rows of a range (or j1 == ny at the physical boundary)");
-    }
-    NSDG_CHECK_ARG(j1a <= j0b || j1b <= j0a, "the two row ranges must be disjoint");
-    NSDG_CHECK_ARG(s11i && s12i && s22i && s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed && pg, "null field pointer");
-    NSDG_CHECK_TILED(s11i, s12i, s22i, s11, s12, s22, pg);
-    NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
-    NSDG_CHECK_ARG(s11 != s11i && s12 != s12i && s22 != s22i, "the output stress must not alias the input stress");
-    if (!(ctx->pack_dt > 0)) {
-        nsdg_set_error("nsdg_mevp_iterate8_pair: nsdg_mevp_pack_nodal was not called on this context");
-        return NSDG_ERR_STATE;
-    }
-    if (ctx->mevp_variant != 8) {
-        nsdg_set_error("nsdg_mevp_iterate8_pair: select variant 8 (nsdg_mevp_variant_set)");
-        return NSDG_ERR_STATE;
-    }
-    NSDG_CHECK_HIP(hipSetDevice(ctx->device));
-    return nsdg_launch_mevp_fused8_ranges(ctx, j0a, j1a, j0b, j1b, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
 }
 
 int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, double* s12, double* s22, double* u, double* v,
@@ -722,10 +664,7 @@ int nsdg_mevp_subcycle(nsdg_ctx* ctx, double dt, int32_t nsub, double* s11, doub
     if (rc)
         return rc;
     for (int it = 0; it < nsub; ++it) {
-        if (ctx->mevp_variant == 8 && it + 7 < nsub) { // eight sub-iterations per pass
-            rc = nsdg_mevp_iterate8(ctx, 0, ctx->ny, sa[0], sa[1], sa[2], sb[0], sb[1], sb[2], ua, va, ub, vb, packed, pg);
-            it += 7;
-        } else if (ctx->mevp_variant >= 4 && it + 3 < nsub) { // four sub-iterations per pass
+        if (ctx->mevp_variant >= 4 && it + 3 < nsub) { // four sub-iterations per pass
             rc = nsdg_mevp_iterate4(ctx, 0, ctx->ny, sa[0], sa[1], sa[2], sb[0], sb[1], sb[2], ua, va, ub, vb, packed, pg);
             it += 3;
         } else if (ctx->mevp_variant >= 3 && it + 2 < nsub) { // three sub-iterations per pass

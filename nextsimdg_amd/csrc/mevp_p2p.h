@@ -1,5 +1,5 @@
-// mevp_p2p.h -- what the two stage-per-wave pipelines of the mEVP sub-cycle share (mevp_fused4.hip: one sub-iteration per stage wave,
-// passes of 2-4; mevp_fused8.hip: two per stage wave, passes of 8): the point-to-point hand-over between the waves of a workgroup --
+// mevp_p2p.h -- the point-to-point primitives of the stage-per-wave pipeline of the mEVP sub-cycle (mevp_fused4.hip; round 6 built a second
+// pipeline on them, two sub-iterations per stage wave, and withdrew it: profiles/r06_fused8.md): the hand-over between the waves of a workgroup --
 // counters in LDS, a bounded wait, the report of a wait that gave up --, the streaming 16-byte accesses, the rings of a row's ice
 // strength / nodal coefficients in LDS.
 //

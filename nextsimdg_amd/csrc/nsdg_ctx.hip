@@ -262,7 +262,7 @@ int nsdg_mevp_occupancy_set(nsdg_ctx* ctx, int32_t waves_per_simd)
 int nsdg_mevp_variant_set(nsdg_ctx* ctx, int32_t variant)
 {
     NSDG_CHECK_ARG(ctx != nullptr, "null context");
-    NSDG_CHECK_ARG((variant >= 0 && variant <= 4) || variant == 8, "variant must be 0, 1, 2, 3, 4 or 8");
+    NSDG_CHECK_ARG(variant >= 0 && variant <= 4, "variant must be 0, 1, 2, 3 or 4");
     ctx->mevp_variant = variant;
     return NSDG_OK;
 }

@@ -186,9 +186,6 @@ int pass_launch(nsdg_rb_mevp* p, int v, Range r, int par)
     const int q = 1 - par;
     if (r.j0 >= r.j1)
         return NSDG_OK;
-    if (v == 8)
-        return nsdg_mevp_iterate8(p->ctx, r.j0, r.j1, d.s11[par], d.s12[par], d.s22[par], d.s11[q], d.s12[q], d.s22[q], d.u[par], d.v[par], d.u[q],
-            d.v[q], d.packed, d.pg);
     if (v == 4)
         return nsdg_mevp_iterate4(p->ctx, r.j0, r.j1, d.s11[par], d.s12[par], d.s22[par], d.s11[q], d.s12[q], d.s22[q], d.u[par], d.v[par], d.u[q],
             d.v[q], d.packed, d.pg);
@@ -308,7 +305,7 @@ int nsdg_rb_mevp_create(nsdg_ctx* ctx, const nsdg_rb_mevp_desc* desc, nsdg_rb_me
     p->d = d;
     // v sub-iterations per kernel pass need a (v k, v k - 1) ghost depth; a block without neighbours needs none
     p->per_pass = 1;
-    for (int v : { 8, 4, 3, 2 }) {
+    for (int v : { 4, 3, 2 }) {
         const bool deep = g.depth_below >= v && g.depth_below % v == 0 && g.depth_above == g.depth_below - 1;
         if (ctx->mevp_variant >= v && (!g.multi() || deep)) {
             p->per_pass = v;
@@ -404,8 +401,6 @@ int nsdg_rb_mevp_run(nsdg_ctx* ctx, nsdg_rb_mevp* p, int32_t parity, int32_t* pa
         const bool split_ok = d.overlap && g.multi() && (g.j1 - g.j0) >= g.depth_below + g.depth_above + 5;
         // passes of per_pass sub-iterations, then what is left of nsub through the kernels with fewer sub-iterations per pass
         for (int v = p->per_pass; v >= 2; --v) {
-            if (v > 4 && v != 8)
-                continue; // kernels exist for passes of 8, 4, 3 and 2
             while (d.nsub - it >= v) {
                 const int m = std::min(k, (d.nsub - it) / v);
                 // everything of the group before its exchange is posted: passes 1 .. m-1 and the travelling rows of
@@ -421,7 +416,7 @@ int nsdg_rb_mevp_run(nsdg_ctx* ctx, nsdg_rb_mevp* p, int32_t parity, int32_t* pa
                         if (split_ok && last && n == 2 && v >= 3) {
                             // the rows that travel up and the rows that travel down: ONE launch (bit-identical to two)
                             const nsdg_rb_mevp_desc& d = p->d;
-                            const int e = (v == 8 ? nsdg_mevp_iterate8_pair : v == 4 ? nsdg_mevp_iterate4_pair : nsdg_mevp_iterate3_pair)(p->ctx, r[0].j0, r[0].j1, r[1].j0, r[1].j1, d.s11[q],
+                            const int e = (v == 4 ? nsdg_mevp_iterate4_pair : nsdg_mevp_iterate3_pair)(p->ctx, r[0].j0, r[0].j1, r[1].j0, r[1].j1, d.s11[q],
                                 d.s12[q], d.s22[q], d.s11[1 - q], d.s12[1 - q], d.s22[1 - q], d.u[q], d.v[q], d.u[1 - q], d.v[1 - q], d.packed, d.pg);
                             if (e != NSDG_OK)
                                 return e;

@@ -279,12 +279,12 @@ class DynamicsCore:
         # two exchanges as one hipGraph.
         self.native, self.use_graph = native, use_graph
         self._calls = {}
-        # v sub-iterations per kernel pass (v = 8: variant 8, 4: variant 4, 3: variant 3, 2: variant 2) need a (v k, v k - 1) ghost depth
+        # v sub-iterations per kernel pass (v = 4: variant 4, v = 3: variant 3, v = 2: variant 2) need a (v k, v k - 1) ghost depth
         # for k passes between two exchanges; a single domain has no ghosts at all.  All variants produce
         # bit-identical results, so a variant-3 context on a (2k, 2k-1) block simply uses the two-iteration kernel.
         variant = getattr(ops, "mevp_variant", None)
         self.per_pass = 1
-        for v in (8, 4, 3, 2):
+        for v in (4, 3, 2):
             deep = blk.depth_below >= v and blk.depth_below % v == 0 and blk.depth_above == blk.depth_below - 1
             if variant is not None and variant >= v and (blk.world == 1 or deep):
                 self.per_pass = v
@@ -375,9 +375,6 @@ class DynamicsCore:
         if v == 1:
             return 0, 0, n
         full, rest = n // v, n % v  # the remainder runs through the kernels with fewer sub-iterations per pass: 3 -> one
-        if rest >= 4:  # (passes of 8) one pass of four, counted with the minority launches
-            four, rest = 1, rest - 4
-            return full, four + (1 if rest == 3 else rest // 2), (0 if rest == 3 else rest % 2)
         if rest == 3:  # three-iteration pass (counted with the "twos": a minority launch), 2 -> one two-iteration pass, 1 -> a single
             return full, 1, 0
         return full, rest // 2, rest % 2
@@ -399,7 +396,7 @@ class DynamicsCore:
             # of nsub after the v-passes is done by a two-iteration pass and / or single sub-iterations.
             k = self.group_passes
             split_ok = self.overlap and b.world > 1 and (b.j1 - b.j0) >= b.depth_below + b.depth_above + 5
-            for v in [w for w in (8, 4, 3, 2) if w <= self.per_pass]:  # kernels exist for passes of 8, 4, 3 and 2
+            for v in range(self.per_pass, 1, -1):
                 while self.nsub - it >= v:
                     m = min(k, (self.nsub - it) // v)
                     for i in range(1, m + 1):
@@ -453,7 +450,7 @@ class DynamicsCore:
             self.halo.rows_exchange_finish(*pending)
 
     def _pass_calls(self, v, split, ext=0):
-        """launches of one pass of v (2, 3, 4 or 8) sub-iterations for the current ping-pong parity (bound once, cached).
+        """launches of one pass of v (2, 3 or 4) sub-iterations for the current ping-pong parity (bound once, cached).
         ext > 0: a pass inside a group, one launch over the owned rows extended by v*ext ghost rows on each
         side.  ext == 0 and split: the rows whose results travel to the neighbours first, the interior last"""
         key = (self.u.data_ptr(), self.s[0].data_ptr(), split, v, ext)

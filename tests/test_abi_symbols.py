@@ -42,7 +42,7 @@ def test_header_is_plain_c():
 
 
 def test_abi_version_and_default_params(lib):
-    assert lib.nsdg_abi_version() == 6  # 6: nsdg_mevp_iterate8*, a pipeline give-up is an error status; 5: nsdg_transport_bounds_set / nsdg_transport_limit, nsdg_mevp_params.min_conc / min_thick; 2: nsdg_comm_* / nsdg_halo_* (row-block ghost exchange); 3: bounded waits, exchange statistics, nsdg_copy_f64; 4: nsdg_mevp_iterate4*, nsdg_comm_simulate_wire
+    assert lib.nsdg_abi_version() == 6  # 6: a pipeline wait that gives up is an error status (nsdg_ctx_synchronize, nsdg_mevp_subcycle, nsdg_rb_mevp_run), per-context count; 5: nsdg_transport_bounds_set / nsdg_transport_limit, nsdg_mevp_params.min_conc / min_thick; 2: nsdg_comm_* / nsdg_halo_* (row-block ghost exchange); 3: bounded waits, exchange statistics, nsdg_copy_f64; 4: nsdg_mevp_iterate4*, nsdg_comm_simulate_wire
     p = abi.ColumnParams()
     lib.nsdg_column_default_params(C.byref(p))
     # defaults of the reference: NextsimPhysics.cpp:76-82, ThermoIce0.cpp:30-31, HiblerConcentration.cpp:28-29

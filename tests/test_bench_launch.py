@@ -28,12 +28,12 @@ def test_plain_command_with_two_ranks_self_launches():
     assert len(lines) == 1, p.stdout.decode()
     assert lines[0]["dry_run"] is True and lines[0]["value"] is None  # a dry run reports no metric
     assert lines[0]["n_gpus"] == 2 and lines[0]["rows_total"] == 2048 and lines[0]["max_rank_seen"] == 1
-    assert lines[0]["ghost_depth"] == [12, 11]  # 3 passes of the four-iteration kernel between two exchanges
+    assert lines[0]["ghost_depth"] == [8, 7]  # 2 passes of the four-iteration kernel between two exchanges
 
 
 def test_eight_ranks_plan_the_real_2048_blocks():
     """the N = 8 run of the scaling record, as far as it goes without GPUs: eight processes through the launcher path, the real
-    2048 x 2048 row blocks with the default passes per exchange (a FIXED 3: ghost depth 12 / 11 with the four-iteration
+    2048 x 2048 row blocks with the default passes per exchange (a FIXED 2: ghost depth 8 / 7 with the four-iteration
     kernel), every rank's entry in the line, the rows tile the grid, and the bytes of an exchange are what the geometry says"""
     p = run_bench("--gpus", "8", "--dry-run", "--steps", "1", "--warmup", "0")
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -49,15 +49,15 @@ def test_eight_ranks_plan_the_real_2048_blocks():
         assert r["row_first"] == first and r["rows_owned"] == 256
         first += r["rows_owned"]
         inner_below, inner_above = r["rank"] > 0, r["rank"] < 7
-        assert r["ghost_rows_below"] == (12 if inner_below else 0) and r["ghost_rows_above"] == (11 if inner_above else 0)
+        assert r["ghost_rows_below"] == (8 if inner_below else 0) and r["ghost_rows_above"] == (7 if inner_above else 0)
         assert r["rows_local"] == 256 + r["ghost_rows_below"] + r["ghost_rows_above"]
         assert r["neighbour_below"] == (r["rank"] - 1 if inner_below else None) and r["neighbour_above"] == (r["rank"] + 1 if inner_above else None)
-        # 12 stress rows of 3 components (32 tiles x 8 coefficients x 64 elements x 8 B) + 24 node rows of u and v (4097 nodes) upwards,
-        # 11 stress rows + 23 node rows downwards; 120 sub-iterations = 30 passes of 4 = 10 groups of 3
-        assert r["mevp_exchange_bytes_up"] == (12 * 3 * 131072 + 24 * 2 * 4097 * 8 if inner_above else 0)
-        assert r["mevp_exchange_bytes_down"] == (11 * 3 * 131072 + 23 * 2 * 4097 * 8 if inner_below else 0)
-        assert r["mevp_exchanges_per_step"] == 10
-        assert r["transport_exchange_bytes_up"] == (12 * 2048 * 96 if inner_above else 0)
+        # 8 stress rows of 3 components (32 tiles x 8 coefficients x 64 elements x 8 B) + 16 node rows of u and v (4097 nodes) upwards,
+        # 7 stress rows + 15 node rows downwards; 120 sub-iterations = 30 passes of 4 = 15 groups of 2
+        assert r["mevp_exchange_bytes_up"] == (8 * 3 * 131072 + 16 * 2 * 4097 * 8 if inner_above else 0)
+        assert r["mevp_exchange_bytes_down"] == (7 * 3 * 131072 + 15 * 2 * 4097 * 8 if inner_below else 0)
+        assert r["mevp_exchanges_per_step"] == 15
+        assert r["transport_exchange_bytes_up"] == (8 * 2048 * 96 if inner_above else 0)
     assert first == 2048
 
 
