@@ -434,8 +434,12 @@ def main():
                     "deliberately wrong diagnostic builds only; the line then says 'finite fields' as its self-check)")
     ap.add_argument("--no-closure", action="store_true", help="the bare scheme of rounds 1-4: no ridging cap / scaling limiter in the transport, no "
                     "ice-free-node rule (A/B of what the closure costs; the default run has it ON, as the hosts do)")
-    ap.add_argument("--delta-min", type=float, default=None, help="regularisation of Delta [1/s]; alpha = beta then follow from the stability bound "
-                    "of the sub-cycle (2e-9: the configuration of rounds 1-4).  Default: alpha = beta = 1500 with the Delta_min the mesh needs for it")
+    ap.add_argument("--subcycle", choices=["adaptive", "keep_alpha", "keep_delta_min"], default="adaptive",
+                    help="how the sub-cycle satisfies its stability bound (nsdg_mevp_stable_params): adaptive (default since round 6) = local, "
+                         "solution-adaptive alpha and beta (Kimmritz et al. 2016) at the literature's Delta_min = 2e-9; keep_alpha (round 5) = uniform "
+                         "alpha = beta = 1500 with the Delta_min the mesh needs for it; keep_delta_min (rounds 1-4) = uniform alpha = beta from the "
+                         "bound for Delta_min = 2e-9")
+    ap.add_argument("--delta-min", type=float, default=None, help="regularisation of Delta [1/s] instead of 2e-9 (adaptive, keep_delta_min) / as a floor (keep_alpha)")
     ap.add_argument("--dry-run", action="store_true", help="plumbing check without a GPU (gloo): launch, rendezvous, planning; no metric")
     args = ap.parse_args()
 
@@ -484,10 +488,10 @@ def main():
     L = 512e3
     dt = 120.0
     bt = synthetic.BoxTest(nx, ny, L)
-    # alpha = beta = 1500 as BASELINE / SURVEY 8(d) name it, with the regularisation Delta_min this mesh needs for that alpha to be stable
-    # (synthetic.BoxTest.stable_delta_min); --delta-min X: that regularisation instead, with the alpha its stability bound asks for
-    # (2e-9: the rounds 1-4 configuration, alpha = 28 875 at 2048^2)
-    sub = bt.subcycle_parameters(dt, delta_min=args.delta_min)
+    # The sub-cycle's parameters (nsdg_mevp_stable_params through synthetic.BoxTest.subcycle_parameters).  Default: local, solution-adaptive
+    # alpha and beta at the standard Delta_min = 2e-9 that SURVEY 8(d) names; --subcycle keep_alpha: the uniform alpha = beta = 1500 of
+    # SURVEY 8(d) with the regularisation this mesh needs for it (round 5); keep_delta_min: uniform alpha from the bound (28 875 at 2048^2)
+    sub = bt.subcycle_parameters(dt, mode=args.subcycle, delta_min=args.delta_min)
     alpha = sub["alpha"]
     coupled = args.workload == "coupled"
     # One-GPU rehearsal of the WHOLE N-rank code path (NSDG_BENCH_LOOPBACK_WORLD=W): this process plays the interior block W/2
@@ -731,12 +735,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("column thermodynamics + " if coupled else "") + "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
-                                   "512 km box test, dt=120 s, alpha=beta=%.0f, Delta_min=%.2e 1/s (%s; the %d sub-iterations move the sub-cycle "
-                                   "%.1f %% of the way per model step; flops and bytes do not depend on either)" % (
-                                       nx, ny, nsub, alpha, sub["delta_min"],
-                                       "SURVEY 8(d)'s alpha with the smallest regularisation for which it satisfies the sub-cycle's stability bound on this mesh"
-                                       if args.delta_min is None else "--delta-min: alpha from the stability bound of the sub-cycle on this mesh",
-                                       nsub, 100.0 * min(1.0, nsub / alpha)),
+                                   "512 km box test, dt=120 s, %s, Delta_min=%.2e 1/s (creep below %.3g %% per day)" % (
+                                       nx, ny, nsub,
+                                       ("local, solution-adaptive alpha and beta (Kimmritz et al. 2016: alpha_e^2 = max(%.0f^2, %.2f zeta_e dt / (m_e |K|)), beta_n = max over "
+                                        "the adjacent elements) at the standard parameters of SURVEY 8(d)" % (sub["aevp_alpha_min"], sub["aevp_c"])) if sub["aevp_c"] > 0 else
+                                       ("uniform alpha=beta=%.0f (%s; the %d sub-iterations move the sub-cycle %.1f %% of the way per model step)" % (
+                                           alpha, "SURVEY 8(d)'s alpha with the smallest regularisation for which it satisfies the sub-cycle's stability bound on this mesh"
+                                           if args.subcycle == "keep_alpha" else "alpha from the stability bound of the sub-cycle on this mesh", nsub, 100.0 * min(1.0, nsub / alpha))),
+                                       sub["delta_min"], sub["delta_min"] * 8.64e6),
+                       "subcycle": args.subcycle,
                        "decomposition": "%d row block(s), ghost-row send/recv" % eff_world + (
                            ", ghost depth %d/%d rows, one exchange per %d mEVP passes%s, halo=%s" % (
                                depth[0], depth[1], core.group_passes,

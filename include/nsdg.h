@@ -168,10 +168,38 @@ typedef struct {
      * 2^-100 there.  Defaults: the column model's cut-off values 1e-12 and 0.01 m (nextsim_thermo.min_conc / min_thick,
      * physics/src/modules/NextsimPhysics.cpp:81-82).  Both 0: rule off. */
     double min_conc, min_thick;
+    /* LOCAL, SOLUTION-ADAPTIVE alpha and beta (round 6; after Kimmritz, Danilov & Losch 2016, "The adaptive EVP method for solving
+     * the sea ice momentum equation", Ocean Modelling 101 -- parity unpinned like the rest of the dynamics).  aevp_c > 0 replaces the
+     * uniform alpha, beta above: in every sub-iteration every element takes the alpha its own viscosity asks for,
+     *     zeta_e = max over its 9 Gauss points of P / (2 Delta),
+     *     alpha_e = sqrt(max(aevp_alpha_min^2, aevp_c zeta_e dt / (rho_ice h'_c hx hy))),
+     * h'_c = max(nodal mean thickness at the element's centre node, h_min) (alpha_e = aevp_alpha_min where that node is ice-free), the
+     * stress relaxes with 1 / alpha_e, and every node takes beta_n = the largest alpha_e of its adjacent elements.  aevp_c is the
+     * stability bound's constant: (2.4 pi)^2 = 56.85 is the bound DESIGN.md section 3.4 states with its margin.  Where the ice
+     * deforms alpha is small and the stress follows the strain rate within a few sub-iterations, where it is rigid alpha is what the
+     * uniform form needs everywhere; the converged sub-cycle solves the same implicit step.  aevp_c = 0 (the default of
+     * nsdg_mevp_default_params): uniform alpha, beta -- bit-identical to ABI 5.  The adaptive form exists in the marching kernels
+     * (nsdg_mevp_iterate*, nsdg_mevp_subcycle, nsdg_rb_mevp_run); nsdg_mevp_stress / nsdg_mevp_velocity return NSDG_ERR_STATE. */
+    double aevp_c, aevp_alpha_min;
 } nsdg_mevp_params;
 
 void nsdg_mevp_default_params(nsdg_mevp_params* p);
 int nsdg_mevp_params_set(nsdg_ctx* ctx, const nsdg_mevp_params* p);
+
+/* The stability rule of the explicit sub-cycle, stated ONCE (round 5 had a copy in each host): on cells of size h = min(hx, hy) and
+ * for a model time step dt the sub-cycle is linearly stable where  alpha beta >= (2.4 pi)^2 zeta dt / (m h^2)  (2.4: the margin a
+ * one-day run needs, profiles/r02_alpha_margin.txt), zeta / m <= pstar / (2 delta_min rho_ice).  Three ways to satisfy it, chosen by
+ * `mode`; the other members of *p are read (pstar, rho_ice, and what the mode keeps) and left alone:
+ *   NSDG_SUBCYCLE_ADAPTIVE       aevp_c = (2.4 pi)^2, aevp_alpha_min = 50: alpha_e, beta_n follow the local viscosity of every
+ *                                sub-iteration; delta_min stays (the literature's 2e-9 by default).  The hosts' default since round 6.
+ *   NSDG_SUBCYCLE_KEEP_ALPHA     uniform alpha = beta = p->alpha; delta_min is raised to the smallest value for which that is stable
+ *                                (never lowered): the viscosity is capped -- below a strain rate of delta_min the ice creeps
+ *                                (nsdg_mevp_creep_percent_per_day).  The hosts' default of round 5.
+ *   NSDG_SUBCYCLE_KEEP_DELTA_MIN uniform alpha = beta = the bound's value for p->delta_min (at least 1500): rounds 1-4. */
+enum { NSDG_SUBCYCLE_ADAPTIVE = 0, NSDG_SUBCYCLE_KEEP_ALPHA = 1, NSDG_SUBCYCLE_KEEP_DELTA_MIN = 2 };
+int nsdg_mevp_stable_params(nsdg_mevp_params* p, int32_t mode, double h, double dt);
+/* strain rate below which the ice creeps instead of staying rigid (= delta_min), in percent per day */
+double nsdg_mevp_creep_percent_per_day(const nsdg_mevp_params* p);
 
 /* number of doubles of a tiled array (see "Data layout") */
 int64_t nsdg_tiled_len(int32_t nx, int32_t ny, int32_t nc);

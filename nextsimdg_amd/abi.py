@@ -31,7 +31,10 @@ class ColumnParams(C.Structure):
 class MevpParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "rho_ice", "rho_atm", "rho_ocean", "c_atm", "c_ocean", "pstar", "compaction", "delta_min", "fc",
-        "alpha", "beta", "h_min", "min_conc", "min_thick")]
+        "alpha", "beta", "h_min", "min_conc", "min_thick", "aevp_c", "aevp_alpha_min")]
+
+
+SUBCYCLE_ADAPTIVE, SUBCYCLE_KEEP_ALPHA, SUBCYCLE_KEEP_DELTA_MIN = 0, 1, 2  # modes of nsdg_mevp_stable_params
 
 
 class FieldBounds(C.Structure):
@@ -93,6 +96,8 @@ SYMBOLS = {
     "nsdg_column_step": (C.c_int, [VP, I64, D] + [VP] * 16),
     "nsdg_mevp_default_params": (None, [C.POINTER(MevpParams)]),
     "nsdg_mevp_params_set": (C.c_int, [VP, C.POINTER(MevpParams)]),
+    "nsdg_mevp_stable_params": (C.c_int, [C.POINTER(MevpParams), I32, D, D]),
+    "nsdg_mevp_creep_percent_per_day": (C.c_double, [C.POINTER(MevpParams)]),
     "nsdg_tiled_len": (C.c_int64, [I32, I32, I32]),
     "nsdg_grid_set": (C.c_int, [VP, I32, I32, D, D]),
     "nsdg_mevp_variant_set": (C.c_int, [VP, I32]),
@@ -176,6 +181,20 @@ def load_library(path=LIB_PATH):
 
 
 TILE = 64
+
+
+def stable_mevp_params(p, mode, h, dt):
+    """nsdg_mevp_stable_params: the sub-cycle's stability rule (one copy, in the library) applied to the MevpParams `p` in place for cells
+    of size h and a model time step dt; mode = SUBCYCLE_ADAPTIVE / SUBCYCLE_KEEP_ALPHA / SUBCYCLE_KEEP_DELTA_MIN"""
+    rc = load_library().nsdg_mevp_stable_params(C.byref(p), int(mode), float(h), float(dt))
+    if rc != 0:
+        raise NsdgError("nsdg error %d: %s" % (rc, load_library().nsdg_last_error().decode()))
+    return p
+
+
+def creep_percent_per_day(p):
+    """strain rate below which the ice creeps instead of staying rigid (= delta_min), in percent per day"""
+    return float(load_library().nsdg_mevp_creep_percent_per_day(C.byref(p)))
 
 
 def tile(a):

@@ -351,11 +351,16 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j
     double* s11, double* s12, double* s22, const double* u_old, const double* v_old, double* u_new, double* v_new, const double* packed,
     const double* pg);
 
-static NodalConsts nodal_consts(const nsdg_ctx* ctx)
-{
-    const nsdg_mevp_params& P = ctx->mevp;
-    return NodalConsts { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
-}
+static NodalConsts nodal_consts(const nsdg_ctx* ctx) { return nsdg_nodal_consts(ctx); }
+
+// the adaptive form of alpha, beta (mevp_common.h) exists in the marching kernels only
+#define NSDG_NOT_ADAPTIVE(ctx)                                                                                                  \
+    do {                                                                                                                        \
+        if (nsdg_adaptive(ctx)) {                                                                                               \
+            nsdg_set_error("%s: the two-kernel form has no adaptive alpha / beta (nsdg_mevp_params.aevp_c > 0): use nsdg_mevp_iterate*", __func__); \
+            return NSDG_ERR_STATE;                                                                                              \
+        }                                                                                                                       \
+    } while (0)
 
 extern "C" {
 
@@ -420,6 +425,7 @@ int nsdg_mevp_stress(nsdg_ctx* ctx, int32_t k0, int32_t k1, const double* u, con
     NSDG_CHECK_ARG(0 <= k0 && k0 <= k1 && k1 <= ctx->ny, "row range outside the local array");
     NSDG_CHECK_ARG(u && v && pg && s11 && s12 && s22, "null field pointer");
     NSDG_CHECK_TILED(pg, s11, s12, s22);
+    NSDG_NOT_ADAPTIVE(ctx);
     if (k0 == k1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
@@ -466,6 +472,7 @@ int nsdg_mevp_velocity(nsdg_ctx* ctx, int32_t j0, int32_t j1, const double* s11,
     NSDG_CHECK_ARG(s11 && s12 && s22 && u_old && v_old && u_new && v_new && packed, "null field pointer");
     NSDG_CHECK_TILED(s11, s12, s22);
     NSDG_CHECK_ARG(u_new != u_old && v_new != v_old, "u_new/v_new must not alias u_old/v_old");
+    NSDG_NOT_ADAPTIVE(ctx);
     if (j0 == j1)
         return NSDG_OK;
     NSDG_CHECK_HIP(hipSetDevice(ctx->device));
@@ -499,7 +506,7 @@ int nsdg_mevp_iterate(nsdg_ctx* ctx, int32_t k0, int32_t j0, int32_t j1, const d
         nsdg_set_error("nsdg_mevp_iterate: nsdg_mevp_pack_nodal was not called on this context");
         return NSDG_ERR_STATE;
     }
-    if (ctx->mevp_variant >= 1) // variants 2 and 3 use the single-iteration fused kernel for one sub-iteration
+    if (ctx->mevp_variant >= 1 || nsdg_adaptive(ctx)) // variants 2-4 use the single-iteration fused kernel for one sub-iteration; so does variant 0 in the adaptive form
         return nsdg_launch_mevp_fused(ctx, k0, j0, j1, s11i, s12i, s22i, s11, s12, s22, u_old, v_old, u_new, v_new, packed, pg);
     int rc = launch_stress(ctx, k0, j1, u_old, v_old, pg, s11i, s12i, s22i, s11, s12, s22);
     if (rc)

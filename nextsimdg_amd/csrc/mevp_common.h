@@ -382,6 +382,78 @@ __device__ __forceinline__ void stress_update(const double (&ul)[9], const doubl
     stress_relax(ialpha, r11, r12, r22, s11, s12, s22);
 }
 
+// ---------------------------------------------------------------------------------------------
+// LOCAL, SOLUTION-ADAPTIVE alpha and beta (round 6; Kimmritz, Danilov & Losch 2016, "The adaptive EVP method for solving the sea ice
+// momentum equation", Ocean Modelling 101; parity unpinned like the rest of the dynamics).  The explicit sub-cycle is stable where
+// alpha beta >= c zeta dt / (m |K|); with ONE alpha for the domain that is the rigid limit zeta_max = P / (2 Delta_min) of the
+// thickest ice -- tens of thousands on a sub-kilometre mesh, and 120 sub-iterations then move the sub-cycle a fraction of a percent
+// of the way.  Adaptive: every element takes the alpha its OWN viscosity of THIS sub-iteration asks for,
+//     zeta_e = max_q P_q / (2 Delta_q),   alpha_e = sqrt(max(alpha_min^2, c zeta_e dt / (rho_i h'_c |K|))),
+// h'_c = the mass-floor-limited nodal mean thickness at the element's centre node (the packed coefficient [0] of that node: an
+// ice-free centre node stores it scaled by 2^100, which gives alpha_min exactly as the oracle's rule states it), and every node takes
+// beta_n = the largest alpha of its adjacent elements.  Where the ice deforms alpha is small and the stress follows the strain rate
+// within a few sub-iterations; where it is rigid alpha is the old global value and the ice stays rigid.  Same limit as the uniform form.
+struct AdaptConsts {
+    double G; // c dt / (rho_i |K|)
+    double amin2; // alpha_min^2
+};
+
+// Proj sigma(v) of one element (NOT scaled by 1 / alpha) and the element's alpha and 1 / alpha
+__device__ __forceinline__ void stress_projected_adaptive(const double (&ul)[9], const double (&vl)[9], const double (&P)[9], double ihx,
+    double ihy, double dmin2, double hc, const AdaptConsts& AC, double (&r11)[8], double (&r12)[8], double (&r22)[8], double& alpha, double& ialpha)
+{
+    double E11[8], E12[8], E22[8];
+    {
+        double uxi[8], ueta[8], vxi[8], veta[8];
+        sf_grad(ul, uxi, ueta);
+        sf_grad(vl, vxi, veta);
+        const double hihx = 0.5 * ihx, hihy = 0.5 * ihy;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool zx = i == 3 || i == 6, zy = i == 4 || i == 7;
+            E11[i] = zx ? 0. : uxi[i] * ihx;
+            E22[i] = zy ? 0. : veta[i] * ihy;
+            E12[i] = zx ? ueta[i] * hihy : (zy ? vxi[i] * hihx : ueta[i] * hihy + vxi[i] * hihx);
+        }
+    }
+    double e11[9], e12[9], e22[9];
+    sf_eval<1>(E11, e11);
+    sf_eval<0>(E12, e12);
+    sf_eval<2>(E22, e22);
+    double t11[9], t12[9], t22[9];
+    double zmax = 0.;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const double hp = 0.5 * P[q]; // P / 2
+        const double a = e11[q] + e22[q], hb = 0.5 * (e11[q] - e22[q]);
+        const double d2 = __builtin_fma(hb, hb, __builtin_fma(a, a, __builtin_fma(e12[q], e12[q], dmin2)));
+        const double z = hp * fast_rsqrt(d2); // zeta = P / (2 Delta)
+        zmax = __builtin_fmax(zmax, z);
+        t11[q] = __builtin_fma(z, __builtin_fma(0.5, hb, a), -hp);
+        t22[q] = __builtin_fma(z, __builtin_fma(-0.5, hb, a), -hp);
+        t12[q] = (0.5 * z) * e12[q];
+    }
+    sf_project(t11, r11);
+    sf_project(t12, r12);
+    sf_project(t22, r22);
+    const double a2 = __builtin_fmax(AC.amin2, (AC.G * zmax) * fast_rcp(hc));
+    ialpha = fast_rsqrt(a2);
+    alpha = a2 * ialpha;
+}
+
+// S <- (1 - 1/alpha_e) S + (1/alpha_e) r, r = Proj sigma(v) from stress_projected_adaptive
+__device__ __forceinline__ void stress_relax_adaptive(double ialpha, const double (&r11)[8], const double (&r12)[8], const double (&r22)[8],
+    double (&s11)[8], double (&s12)[8], double (&s22)[8])
+{
+    const double keep = 1. - ialpha;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s11[i] = __builtin_fma(keep, s11[i], ialpha * r11[i]);
+        s12[i] = __builtin_fma(keep, s12[i], ialpha * r12[i]);
+        s22[i] = __builtin_fma(keep, s22[i], ialpha * r22[i]);
+    }
+}
+
 // all 18 nodal contributions -(sigma, grad phi_n)_K of one element
 __device__ __forceinline__ void node_contrib_all(const double (&s11)[8], const double (&s12)[8], const double (&s22)[8],
     double hx, double hy, double (&cx)[9], double (&cy)[9])
@@ -462,6 +534,7 @@ __host__ __device__ __forceinline__ long nodal_off(long n, long plane)
 
 struct NodalConsts {
     double k1, k2, k3;
+    double rdt; // rho_ice / dt (the adaptive form: K1 = rdt beta_n, K2 = rdt (1 + beta_n) per node)
 };
 
 __device__ __forceinline__ void node_update_packed(const NodalConsts& K, const double (&c)[6], double uu, double vv, double divx,
@@ -473,6 +546,32 @@ __device__ __forceinline__ void node_update_packed(const NodalConsts& K, const d
     const double c1 = K.k1 * c[0], cor = K.k3 * c[0];
     un = denom * (c1 * uu + c[2] + drag * c[4] + cor * vv + divx * ilumped);
     vn = denom * (c1 * vv + c[3] + drag * c[5] - cor * uu + divy * ilumped);
+}
+
+// the same with the node's own beta (adaptive form)
+__device__ __forceinline__ void node_update_packed_adaptive(const NodalConsts& K, const double (&c)[6], double uu, double vv, double divx,
+    double divy, double ilumped, double beta, double& un, double& vn)
+{
+    const double du = c[4] - uu, dv = c[5] - vv;
+    const double drag = c[1] * fast_sqrt(du * du + dv * dv);
+    const double rb = K.rdt * beta;
+    const double denom = fast_rcp((rb + K.rdt) * c[0] + drag);
+    const double c1 = rb * c[0], cor = K.k3 * c[0];
+    un = denom * (c1 * uu + c[2] + drag * c[4] + cor * vv + divx * ilumped);
+    vn = denom * (c1 * vv + c[3] + drag * c[5] - cor * uu + divy * ilumped);
+}
+
+// launch constants of the velocity update / of the adaptive alpha from the context's parameters and the packing's time step
+static inline NodalConsts nsdg_nodal_consts(const nsdg_ctx* ctx)
+{
+    const nsdg_mevp_params& P = ctx->mevp;
+    return NodalConsts { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc, P.rho_ice / ctx->pack_dt };
+}
+static inline bool nsdg_adaptive(const nsdg_ctx* ctx) { return ctx->mevp.aevp_c > 0.; }
+static inline AdaptConsts nsdg_adapt_consts(const nsdg_ctx* ctx)
+{
+    const nsdg_mevp_params& P = ctx->mevp;
+    return AdaptConsts { P.aevp_c * ctx->pack_dt / (P.rho_ice * ctx->hx * ctx->hy), P.aevp_alpha_min * P.aevp_alpha_min };
 }
 
 // plane = nodal_plane(number of nodes of the local array)

@@ -38,8 +38,8 @@ __device__ __forceinline__ double shift_up(double x)
     return lane_from_left(x);
 }
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, int nx, int ny, int k0, int j0, int j1, int R, int ncw, double hx,
+template <int MINW, bool AD>
+__global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, AdaptConsts AC, int nx, int ny, int k0, int j0, int j1, int R, int ncw, double hx,
     double hy, double ialpha, double dmin2, StressPtrs S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
 {
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
     // contributions of the row below to its top-row nodes: b6 (top-left), b7 (top-mid) of my column and
     // bl8 = top-right of the column to my left
     double b6x = 0., b6y = 0., b7x = 0., b7y = 0., bl8x = 0., bl8y = 0.;
+    double ba = 0., bal = 0.; // adaptive form: alpha of the element below and below-left
 
     for (int iy = (y0 > k0 ? y0 - 1 : y0); iy < y1; ++iy) {
         const bool prologue = iy < y0; // recomputed row owned by the strip below: nothing is stored
@@ -76,7 +77,17 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
             vl[a] = v_old[n];
         }
         tile_load9(pg, tp, ix & 63, Pq);
-        if constexpr (MINW >= 2) {
+        double alpha = 0.; // adaptive form: this element's alpha of this sub-iteration
+        if constexpr (AD) {
+            // local, solution-adaptive alpha (mevp_common.h); h' of the element's centre node is its packed coefficient [0]
+            const double hc = packed[nodal_off(nV + nn + 1, nplane)];
+            double r11[8], r12[8], r22[8], ialpha;
+            stress_projected_adaptive(ul, vl, Pq, ihx, ihy, dmin2, hc, AC, r11, r12, r22, alpha, ialpha);
+            tile_load8(S.i11, ts, s11);
+            tile_load8(S.i12, ts, s12);
+            tile_load8(S.i22, ts, s22);
+            stress_relax_adaptive(ialpha, r11, r12, r22, s11, s12, s22);
+        } else if constexpr (MINW >= 2) {
             // 2 waves/SIMD build: stage the loads so that the live set stays under 256 registers -- the old
             // stress is fetched only after the projected stress is formed, the partner wave covers the latency
             double r11[8], r12[8], r22[8];
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
         // wavefront-level edge exchange: right-column contributions of the element to my left
         const double l2x = shift_up(cx[2]), l2y = shift_up(cy[2]);
         const double l5x = shift_up(cx[5]), l5y = shift_up(cy[5]);
+        const double al = AD ? shift_up(alpha) : 0.;
 
         if (!prologue && iy >= j0) { // wave-uniform
             const bool hasB = iy > 0;
@@ -111,7 +123,11 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
             // vertex: below-left + below + left + own (the oracle's summation order)
             if (hasL && hasB) {
                 load_nodal(packed, nplane, nV, c);
-                node_update_packed(K, c, ul[0], vl[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea, un, vn);
+                if constexpr (AD)
+                    node_update_packed_adaptive(K, c, ul[0], vl[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea,
+                        __builtin_fmax(__builtin_fmax(bal, ba), __builtin_fmax(al, alpha)), un, vn);
+                else
+                    node_update_packed(K, c, ul[0], vl[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea, un, vn);
             } else
                 un = vn = 0.;
             if (own)
@@ -119,7 +135,10 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
             // bottom edge-mid: below + own
             if (hasB) {
                 load_nodal(packed, nplane, nV + 1, c);
-                node_update_packed(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, un, vn);
+                if constexpr (AD)
+                    node_update_packed_adaptive(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, __builtin_fmax(ba, alpha), un, vn);
+                else
+                    node_update_packed(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, un, vn);
             } else
                 un = vn = 0.;
             if (own)
@@ -127,14 +146,20 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
             // left edge-mid: left + own
             if (hasL) {
                 load_nodal(packed, nplane, nV + nn, c);
-                node_update_packed(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, un, vn);
+                if constexpr (AD)
+                    node_update_packed_adaptive(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, __builtin_fmax(al, alpha), un, vn);
+                else
+                    node_update_packed(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, un, vn);
             } else
                 un = vn = 0.;
             if (own)
                 u_new[nV + nn] = un, v_new[nV + nn] = vn;
             // centre: own
             load_nodal(packed, nplane, nV + nn + 1, c);
-            node_update_packed(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, un, vn);
+            if constexpr (AD)
+                node_update_packed_adaptive(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, alpha, un, vn);
+            else
+                node_update_packed(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, un, vn);
             if (own) {
                 u_new[nV + nn + 1] = un, v_new[nV + nn + 1] = vn;
                 // right column / top row of the local lattice are boundary nodes (v = 0)
@@ -153,6 +178,8 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, in
         // carry the top-row contributions to the next row of the march
         b6x = cx[6], b6y = cy[6], b7x = cx[7], b7y = cy[7];
         bl8x = shift_up(cx[8]), bl8y = shift_up(cy[8]);
+        if constexpr (AD)
+            ba = alpha, bal = al;
     }
 }
 
@@ -189,17 +216,21 @@ int nsdg_launch_mevp_fused(nsdg_ctx* ctx, int k0, int j0, int j1, const double* 
     const int nstrips = nsdg_div_up(j1 - k0, R);
     const long nwaves = (long)ncw * nstrips;
     const StressPtrs S = { s11i, s12i, s22i, s11, s12, s22 };
-    const nsdg_mevp_params& P = ctx->mevp;
-    const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
-    // two register budgets of the same kernel: 1 wave/SIMD (no spills) or 2 waves/SIMD (a few scratch spills)
-    if (ctx->fused_min_waves >= 2)
-        hipLaunchKernelGGL(mevp_fused_kernel<2>, dim3(nsdg_div_up(nwaves, 4)), dim3(256), 0, ctx->stream, K, ctx->nx, ctx->ny, k0, j0, j1,
-            R, ncw, ctx->hx, ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg,
-            u_new, v_new);
+    const NodalConsts K = nsdg_nodal_consts(ctx);
+    const AdaptConsts AC = nsdg_adapt_consts(ctx);
+    const double ialpha = 1. / ctx->mevp.alpha, dmin2 = ctx->mevp.delta_min * ctx->mevp.delta_min;
+    const dim3 grid(nsdg_div_up(nwaves, 4)), block(256);
+    // two register budgets of the same kernel: 1 wave/SIMD (no spills) or 2 waves/SIMD (a few scratch spills); the adaptive form (local
+    // alpha, beta: mevp_common.h) runs at 1 wave/SIMD
+    if (nsdg_adaptive(ctx))
+        hipLaunchKernelGGL((mevp_fused_kernel<1, true>), grid, block, 0, ctx->stream, K, AC, ctx->nx, ctx->ny, k0, j0, j1, R, ncw, ctx->hx, ctx->hy, ialpha, dmin2, S,
+            u_old, v_old, packed, pg, u_new, v_new);
+    else if (ctx->fused_min_waves >= 2)
+        hipLaunchKernelGGL((mevp_fused_kernel<2, false>), grid, block, 0, ctx->stream, K, AC, ctx->nx, ctx->ny, k0, j0, j1, R, ncw, ctx->hx, ctx->hy, ialpha, dmin2, S,
+            u_old, v_old, packed, pg, u_new, v_new);
     else
-        hipLaunchKernelGGL(mevp_fused_kernel<1>, dim3(nsdg_div_up(nwaves, 4)), dim3(256), 0, ctx->stream, K, ctx->nx, ctx->ny, k0, j0, j1,
-            R, ncw, ctx->hx, ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, S, u_old, v_old, packed, pg,
-            u_new, v_new);
+        hipLaunchKernelGGL((mevp_fused_kernel<1, false>), grid, block, 0, ctx->stream, K, AC, ctx->nx, ctx->ny, k0, j0, j1, R, ncw, ctx->hx, ctx->hy, ialpha, dmin2, S,
+            u_old, v_old, packed, pg, u_new, v_new);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }

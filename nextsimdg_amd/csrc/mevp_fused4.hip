@@ -121,7 +121,7 @@ __device__ __forceinline__ void request_c2_p(const MarchConst3& M, int nrow, dou
     load_nodal2(packed, M.nplane, nVn + M.nn + 1, c[3]);
 }
 // One row of one stage.  FIRST: the loader (stage 0): inputs from memory, ice strength into the ring.
-template <bool FIRST>
+template <bool FIRST, bool AD>
 __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, int row, FetchP& f, TopCarry3& carry, double* __restrict__ lds,
     volatile lds_int* flags, const P2PReport& rep, const StressPtrsP& S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new NSDG_SPIN_ARG)
@@ -174,7 +174,11 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     NSDG_PHASE(0); // inputs of the row (stages >= 1: the wait for the previous stage, LDS reads)
     // ------------------------------------------------------------------------------------------ stress update
     double r11[8], r12[8], r22[8];
-    stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
+    double alpha = 0., ialpha = M.ialpha; // adaptive form: this element's alpha of this sub-iteration (the centre node's h' is coefficient [0] of node 3)
+    if constexpr (AD)
+        stress_projected_adaptive(ul, vl, f.P, M.ihx, M.ihy, M.dmin2, f.c[3][0], M.AC, r11, r12, r22, alpha, ialpha);
+    else
+        stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
     __builtin_amdgcn_sched_barrier(0);
     NSDG_PHASE(1); // projected stress
     if (FIRST) {
@@ -208,7 +212,10 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
         flag_publish(flags, 3 + stage - 1, row);
     }
     NSDG_PHASE(2); // loader: ring wait, ring writes, requests of P, u, v; stages: ring read, stress read, read[] published
-    stress_relax(M.ialpha, r11, r12, r22, s11, s12, s22);
+    if constexpr (AD)
+        stress_relax_adaptive(ialpha, r11, r12, r22, s11, s12, s22);
+    else
+        stress_relax(M.ialpha, r11, r12, r22, s11, s12, s22);
     __builtin_amdgcn_sched_barrier(0);
     if (FIRST) { // stress of the next row
         const long ts = tile_off(ix, nrow, M.ntx, 8);
@@ -221,13 +228,13 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     {
         double cx[9], cy[9];
         node_contrib_all(s11, s12, s22, M.hx, M.hy, cx, cy);
-        owned_node_updates(M, row > 0, f.c, uu, vv, carry, cx, cy, un, vn);
+        owned_node_updates<AD>(M, row > 0, f.c, uu, vv, carry, cx, cy, un, vn, alpha);
         if (row < G.upd0) { // wave-uniform: the first row of a stage only feeds the carried contributions
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 un[k] = vn[k] = 0.;
         }
-        carry_top(carry, cx, cy);
+        carry_top<AD>(carry, cx, cy, alpha);
     }
     __builtin_amdgcn_sched_barrier(0);
     NSDG_PHASE(4); // contributions, node updates (the wait for the nodal coefficients is here)
@@ -273,7 +280,8 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     NSDG_PHASE(6); // outputs: slot wait, LDS writes, done[] published / global stores
 }
 
-__global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw,
+template <bool AD>
+__global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, AdaptConsts AC, int nst, int nx, int ny, int j0, int j1, int j0b, int j1b, int nsA, int R, int ncw,
     double hx, double hy, double ialpha, double dmin2, P2PReport rep, StressPtrsP S, const double* __restrict__ u_old, const double* __restrict__ v_old,
     const double* __restrict__ packed, const double* __restrict__ pg, double* __restrict__ u_new, double* __restrict__ v_new)
 {
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
     M.nplane = nodal_plane((long)M.nn * (2 * ny + 1));
     M.hx = hx, M.hy = hy, M.ihx = 1. / hx, M.ihy = 1. / hy, M.iarea = M.ihx * M.ihy;
     M.ialpha = ialpha, M.dmin2 = dmin2;
+    M.AC = AC;
     M.tbeg = M.tendA = M.tendB = 0; // (fields of the other pipelines)
 
     // a pass of nst sub-iterations (2 <= nst <= 4): stage s works on the rows y0 - nst + s .. y1 + nst - 2 - s, the last one (nst - 1)
@@ -353,10 +362,10 @@ __global__ __launch_bounds__(256) void mevp_fused4_kernel(NodalConsts K, int nst
         tile_load9_p<(NSDG_P2P_NT & 4) != 0>(pg, tile_off(M.ix, row, M.ntx, 9), M.ix & 63, f.P);
         request_c_p(M, row, f.c, packed);
         for (int row = G.first; row <= G.last; ++row)
-            p2p_row<true>(M, G, row, f, carry, lds, flags, rep, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
+            p2p_row<true, AD>(M, G, row, f, carry, lds, flags, rep, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
     } else {
         for (int row = G.first; row <= G.last; ++row)
-            p2p_row<false>(M, G, row, f, carry, lds, flags, rep, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
+            p2p_row<false, AD>(M, G, row, f, carry, lds, flags, rep, S, u_old, v_old, packed, pg, u_new, v_new NSDG_SPIN_PASS);
     }
 #ifdef NSDG_P2P_SPINSTAT
     if (lane == 0) {
@@ -417,11 +426,15 @@ int nsdg_launch_mevp_fused4_ranges(nsdg_ctx* ctx, int nst, int j0, int j1, int j
     const int nsA = nsdg_div_up(j1 - j0, R), nsB = nsdg_div_up(rowsB, R);
     const long ngroups = (long)ncw * (nsA + nsB);
     const StressPtrsP S = { s11i, s12i, s22i, s11, s12, s22 };
-    const nsdg_mevp_params& P = ctx->mevp;
-    const NodalConsts K = { P.rho_ice * P.beta / ctx->pack_dt, P.rho_ice * (1. + P.beta) / ctx->pack_dt, P.rho_ice * P.fc };
-    hipLaunchKernelGGL(mevp_fused4_kernel, dim3(ngroups), dim3(256), 0, ctx->stream, K, nst, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
-        ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, P2PReport { ctx->p2p_count_dev, ctx->p2p_flag_dev }, S, u_old, v_old, packed, pg,
-        u_new, v_new);
+    const NodalConsts K = nsdg_nodal_consts(ctx);
+    const AdaptConsts AC = nsdg_adapt_consts(ctx);
+    const P2PReport rep = { ctx->p2p_count_dev, ctx->p2p_flag_dev };
+    if (nsdg_adaptive(ctx)) // local, solution-adaptive alpha and beta (mevp_common.h)
+        hipLaunchKernelGGL(mevp_fused4_kernel<true>, dim3(ngroups), dim3(256), 0, ctx->stream, K, AC, nst, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
+            ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, rep, S, u_old, v_old, packed, pg, u_new, v_new);
+    else
+        hipLaunchKernelGGL(mevp_fused4_kernel<false>, dim3(ngroups), dim3(256), 0, ctx->stream, K, AC, nst, ctx->nx, ctx->ny, j0, j1, j0b, j1b, nsA, R, ncw, ctx->hx,
+            ctx->hy, 1. / ctx->mevp.alpha, ctx->mevp.delta_min * ctx->mevp.delta_min, rep, S, u_old, v_old, packed, pg, u_new, v_new);
     NSDG_CHECK_LAUNCH();
     return NSDG_OK;
 }

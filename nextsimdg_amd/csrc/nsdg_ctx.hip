@@ -1,5 +1,6 @@
 // nsdg_ctx.hip -- context, parameters and error reporting of libnsdg.so.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -74,7 +75,41 @@ void nsdg_mevp_default_params(nsdg_mevp_params* p)
     // physics/src/modules/NextsimPhysics.cpp:81-82, applied there as  c_new < minc || hi < minh,  :210-219)
     p->min_conc = 1e-12;
     p->min_thick = 0.01;
+    // uniform alpha, beta (bit-identical to ABI 5); nsdg_mevp_stable_params(.., NSDG_SUBCYCLE_ADAPTIVE, ..) turns the adaptive form on
+    p->aevp_c = 0.;
+    p->aevp_alpha_min = 50.;
 }
+
+int nsdg_mevp_stable_params(nsdg_mevp_params* p, int32_t mode, double h, double dt)
+{
+    NSDG_CHECK_ARG(p != nullptr, "null parameters");
+    NSDG_CHECK_ARG(h > 0 && dt > 0, "cell size and time step must be positive");
+    NSDG_CHECK_ARG(p->pstar > 0 && p->rho_ice > 0, "pstar and rho_ice must be positive");
+    const double pi = 3.14159265358979323846, margin = 2.4;
+    // alpha beta >= c zeta dt / (m h^2) with c = (margin pi)^2 and zeta / m <= pstar / (2 delta_min rho_ice)
+    const double c = margin * margin * pi * pi;
+    switch (mode) {
+    case NSDG_SUBCYCLE_ADAPTIVE:
+        p->aevp_c = c;
+        p->aevp_alpha_min = 50.;
+        return NSDG_OK;
+    case NSDG_SUBCYCLE_KEEP_ALPHA:
+        NSDG_CHECK_ARG(p->alpha > 0, "alpha must be positive");
+        p->aevp_c = 0.;
+        p->beta = p->alpha;
+        p->delta_min = std::max(p->delta_min, c * p->pstar * dt / (2. * p->rho_ice * h * h * p->alpha * p->alpha));
+        return NSDG_OK;
+    case NSDG_SUBCYCLE_KEEP_DELTA_MIN:
+        NSDG_CHECK_ARG(p->delta_min > 0, "delta_min must be positive");
+        p->aevp_c = 0.;
+        p->alpha = p->beta = std::max(1500., std::sqrt(c * p->pstar * dt / (2. * p->delta_min * p->rho_ice * h * h)));
+        return NSDG_OK;
+    }
+    nsdg_set_error("nsdg_mevp_stable_params: unknown mode %d", (int)mode);
+    return NSDG_ERR_ARG;
+}
+
+double nsdg_mevp_creep_percent_per_day(const nsdg_mevp_params* p) { return p ? p->delta_min * 86400. * 100. : 0.; }
 
 int nsdg_ctx_create(int device_id, void* stream, nsdg_ctx** out)
 {
@@ -223,6 +258,7 @@ int nsdg_mevp_params_set(nsdg_ctx* ctx, const nsdg_mevp_params* p)
 {
     NSDG_CHECK_ARG(ctx && p, "null argument");
     NSDG_CHECK_ARG(p->alpha > 0 && p->beta > 0, "alpha and beta must be positive");
+    NSDG_CHECK_ARG(p->aevp_c >= 0 && (p->aevp_c == 0 || p->aevp_alpha_min > 0), "aevp_c must be >= 0 and aevp_alpha_min positive");
     ctx->mevp = *p;
     ctx->pack_dt = 0.; // the packed nodal coefficients were built from the old parameters: repack before iterating
     return NSDG_OK;

@@ -19,9 +19,13 @@
 // Configuration keys (all optional):
 //     dynamics.domain_size   side of the square box in m        (512e3)
 //     dynamics.nsub          mEVP sub-iterations per step        (120)
-//     dynamics.alpha/.beta   mEVP parameters (0 = 1500, the BASELINE's value, with the regularisation dynamics.delta_min the mesh needs
-//                            for it -- stableDeltaMin(); with dynamics.delta_min given: the stability bound for it -- stableAlpha())
-//     dynamics.delta_min     regularisation of Delta [1/s] (0 = from the mesh; 2e-9 = the literature's value, the rounds 1-4 runs)
+//     dynamics.subcycle      how the sub-cycle satisfies its stability bound (nsdg_mevp_stable_params, include/nsdg.h): adaptive (default
+//                            since round 6: local, solution-adaptive alpha and beta at the literature's Delta_min) | keep_alpha (round 5:
+//                            uniform alpha = beta = dynamics.alpha or 1500, Delta_min raised to what the mesh needs for it) |
+//                            keep_delta_min (rounds 1-4: uniform alpha = beta from the bound for dynamics.delta_min or 2e-9)
+//     dynamics.alpha/.beta   uniform mEVP parameters (keep_alpha; 0 = 1500, the BASELINE's value); given WITHOUT dynamics.subcycle they
+//                            select keep_alpha and are used as they are
+//     dynamics.delta_min     regularisation of Delta [1/s] (0 = the literature's 2e-9)
 //     dynamics.closure       ridging cap + scaling limiter in the transport, free drift at ice-free nodes (default true)
 //     dynamics.min_conc/.min_thick   the ice-free-node rule's thresholds (defaults 1e-12, 0.01: the column model's cut-off)
 //     dynamics.thermodynamics  run the column physics first       (false)
@@ -69,8 +73,13 @@ public:
     double sumH() const { return m_sumH; }
     double sumA() const { return m_sumA; }
     int blocks() const { return (int)m_blocks.size(); }
-    static double stableAlpha(double h, double dt, double dmin = 2e-9);
-    static double stableDeltaMin(double h, double dt, double alpha = 1500.);
+    //! the sub-cycle parameters this configuration runs with on cells of size h and a time step dt (nsdg_mevp_stable_params: the one copy
+    //! of the stability rule); returns the creep threshold in percent per day beside them
+    struct SubcycleChoice {
+        std::string mode;
+        double alpha, beta, deltaMin, aevpC, aevpAlphaMin, creepPercentPerDay;
+    };
+    SubcycleChoice subcycleChoice(double h, double dt) const;
 
     //! rows [r0, r1) of block `rank` of `world` (the same split as nextsimdg_amd/rowblock.py split_rows)
     static void splitRows(int ny, int world, int rank, int& r0, int& r1);
@@ -89,10 +98,11 @@ private:
     std::vector<std::unique_ptr<DynamicsBlock>> m_blocks;
     int nxf = 0, nyf = 0; // fast / slow grid dimensions as the dynamics ABI names them
     double L = 512e3, alpha = 0, beta = 0;
-    int nsub = 120, rowBlocks = 1, passesPerExchange = 3, loopbackWorld = 0;
+    int nsub = 120, rowBlocks = 1, passesPerExchange = 2, loopbackWorld = 0;
     bool thermo = false, overlap = true, graph = false, m_inited = false;
     bool closure = true; // ridging cap + scaling limiter in the transport, free drift at ice-free nodes (dynamics.closure)
-    double deltaMin = 0; // dynamics.delta_min; 0: from the mesh, for alpha = beta = 1500
+    double deltaMin = 0; // dynamics.delta_min; 0: the literature's 2e-9 (keep_alpha: raised to what the mesh needs)
+    std::string subcycle = "adaptive"; // dynamics.subcycle
     double minConc = 1e-12, minThick = 0.01; // ice-free-node rule (dynamics.min_conc / min_thick; the column model's cut-off values)
     std::string forcing = "host", devices;
     int m_world = 1, m_rank = 0; // multi-process run (one block per process)

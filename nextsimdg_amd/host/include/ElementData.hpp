@@ -14,6 +14,29 @@
 
 namespace Nextsim {
 
+//! What a dynamics run carries from one step to the next beyond the cell means hice / cice of the FieldStore: the higher DG2 coefficients of
+//! the advected thickness and concentration, the CG2 velocity and the 24 stress coefficients.  The reference writes every prognostic field
+//! it has into its restart file (core/src/DevGridIO.cpp:169-201, read back at :101-138); its snapshot has no dynamics, so these are
+//! additional variables of the same group (names and dimensions: RectGrid.hpp).  x = the slow index of the file, y the fast one.
+struct DynamicsState {
+    bool present = false; //!< false: a run starts from rest with piecewise-constant fields (a file of the reference, or of a column-only run)
+    std::vector<double> hdg, adg; //!< coefficients 1..5 of H and A: [5][x][y]
+    std::vector<double> u, v; //!< nodal velocity on the (2x+1) x (2y+1) lattice
+    std::vector<double> s11, s12, s22; //!< stress coefficients: [8][x][y]
+    void resize(std::size_t nx, std::size_t ny)
+    {
+        hdg.assign(5 * nx * ny, 0.), adg.assign(5 * nx * ny, 0.);
+        u.assign((2 * nx + 1) * (2 * ny + 1), 0.), v.assign((2 * nx + 1) * (2 * ny + 1), 0.);
+        s11.assign(8 * nx * ny, 0.), s12.assign(8 * nx * ny, 0.), s22.assign(8 * nx * ny, 0.);
+    }
+    void clear()
+    {
+        present = false;
+        for (auto* a : { &hdg, &adg, &u, &v, &s11, &s12, &s22 })
+            a->clear();
+    }
+};
+
 //! Struct-of-arrays field container: every plane has n = nx*ny doubles, element index i*ny' ... see IStructure.
 struct FieldStore {
     std::size_t n = 0;
@@ -25,6 +48,8 @@ struct FieldStore {
     std::vector<double> tair, tdew, slp, mixrat, qsw, qlw, mld, snowfall;
     // physics input / persistent state (physics/src/include/PhysicsData.hpp:26; NextsimPhysics.hpp m_newice)
     std::vector<double> wind, newice;
+    // state of the dynamics between two steps (absent until a dynamics run has stopped, or a restart file that holds it was read)
+    DynamicsState dyn;
 
     void resize(std::size_t nElements, int nIceLayers);
 };

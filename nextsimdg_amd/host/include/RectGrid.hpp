@@ -9,6 +9,15 @@
 //     NSDG-RESTART 1 / structure.type=<name> / data.x=<nx> / data.y=<ny> / data.nLayers=<n>
 // followed by the float64 variables hice, cice, hsnow, sst, sss (x, y) and tice (x, y, nLayers) in
 // x-major order, little endian.
+//
+// The state of a DYNAMICS run (FieldStore::dyn, round 6) travels in both formats as further variables of group `data` -- the
+// reference writes every prognostic field it has (core/src/DevGridIO.cpp:169-201), its snapshot has no dynamics, a reader that does
+// not know these names never asks for them:
+//     hice_dg, cice_dg (dg2 = 5, x, y)    DG2 coefficients 1..5 of the advected thickness / concentration (coefficient 0 = hice / cice)
+//     u, v             (xnode = 2x+1, ynode = 2y+1)    CG2 nodal velocity
+//     s11, s12, s22    (stress8 = 8, x, y)             stress coefficients of the 8-function DG space
+//     newice           (x, y)              the column model's persistent new-ice volume (NextsimPhysics::m_newice)
+// (sidecar: header line data.dynamics=1, the arrays in this order after tice).  A file without them starts the dynamics from rest.
 #pragma once
 #include "Configured.hpp"
 #include "IStructure.hpp"

@@ -43,6 +43,29 @@ void checkHip(hipError_t e, const char* what)
 }
 std::atomic<long> g_localGroup { 1 }; // ids of the in-process communicator groups of this process
 
+// The stress lives on the device in the tiled layout of include/nsdg.h (tiles of 64 elements of a row, the 8 coefficients of a tile
+// together, in pairs interleaved by element); a restart file holds coefficient planes [8][rows][nx].
+inline std::size_t tiledIndex(int nx, int ix, int iy, int c)
+{
+    const std::size_t ntx = (std::size_t)(nx + 63) / 64;
+    return (((std::size_t)iy * ntx + (std::size_t)(ix >> 6)) * 8) * 64 + (std::size_t)(c / 2) * 128 + 2 * (std::size_t)(ix & 63) + (std::size_t)(c % 2);
+}
+// rows [row0, row0 + rows) of the tiled array `t` (local array of nx columns) -> planes[c * planeStride + (dstRow0 + r) * nx + ix]
+void untileRows(const std::vector<double>& t, int nx, int row0, int rows, double* planes, std::size_t planeStride, std::size_t dstRow0)
+{
+    for (int c = 0; c < 8; ++c)
+        for (int r = 0; r < rows; ++r)
+            for (int ix = 0; ix < nx; ++ix)
+                planes[c * planeStride + (dstRow0 + r) * nx + ix] = t[tiledIndex(nx, ix, row0 + r, c)];
+}
+void tileRows(const double* planes, std::size_t planeStride, std::size_t srcRow0, int nx, int rows, std::vector<double>& t)
+{
+    for (int c = 0; c < 8; ++c)
+        for (int r = 0; r < rows; ++r)
+            for (int ix = 0; ix < nx; ++ix)
+                t[tiledIndex(nx, ix, r, c)] = planes[c * planeStride + (srcRow0 + r) * nx + ix];
+}
+
 // device arrays of a block; the advected fields, the stress and the velocity exist twice (ping-pong)
 enum Arr { H0, A0, H1, A1, T2H, T2A, S11a, S12a, S22a, S11b, S12b, S22b, PG, VXDG, VYDG, UNX, UNY, Ua, Va, Ub, Vb, UA, VA, UO, VO, PACKED, COL, NARR };
 // column planes inside COL
@@ -91,25 +114,30 @@ const std::map<int, std::string> Configured<DynamicsStep>::keyMap = { { 0, "dyna
     { 2, "dynamics.alpha" }, { 3, "dynamics.beta" }, { 4, "dynamics.thermodynamics" }, { 5, "dynamics.row_blocks" },
     { 6, "dynamics.passes_per_exchange" }, { 7, "dynamics.overlap" }, { 8, "dynamics.graph" }, { 9, "dynamics.forcing" },
     { 10, "dynamics.devices" }, { 11, "dynamics.loopback_world" }, { 12, "dynamics.closure" }, { 13, "dynamics.min_conc" },
-    { 14, "dynamics.min_thick" }, { 15, "dynamics.delta_min" } };
+    { 14, "dynamics.min_thick" }, { 15, "dynamics.delta_min" }, { 16, "dynamics.subcycle" } };
 
 DynamicsStep::DynamicsStep() = default;
 DynamicsStep::~DynamicsStep() { release(); }
 
 void DynamicsStep::release() { m_blocks.clear(); }
 
-double DynamicsStep::stableAlpha(double h, double dt, double dmin)
-{ // alpha*beta >= pi^2 zeta_max dt / (m h^2), zeta_max = P* H / (2 Delta_min); same rule as synthetic.BoxTest.stable_alpha
-    const double pstar = 27.5e3, rho = 900., hice = 0.3;
-    const double zeta = pstar * hice / (2. * dmin);
-    const double pi = 3.14159265358979323846;
-    return std::max(1500., 2.4 * std::sqrt(pi * pi * zeta * dt / (rho * hice * h * h))); // 2.4: margin a one-day run needs
-}
-
-double DynamicsStep::stableDeltaMin(double h, double dt, double alpha)
-{ // the smallest Delta_min (never below 2e-9) for which alpha = beta = `alpha` meets that bound: synthetic.BoxTest.stable_delta_min
-    const double pstar = 27.5e3, rho = 900., pi = 3.14159265358979323846;
-    return std::max(2e-9, 2.4 * 2.4 * pi * pi * pstar * dt / (2. * rho * h * h * alpha * alpha));
+DynamicsStep::SubcycleChoice DynamicsStep::subcycleChoice(double h, double dt) const
+{ // the stability rule lives in the library (nsdg_mevp_stable_params): the host only says which of its three forms it wants
+    nsdg_mevp_params p;
+    nsdg_mevp_default_params(&p);
+    if (deltaMin > 0)
+        p.delta_min = deltaMin;
+    const std::string mode = subcycle;
+    if (mode == "keep_alpha") {
+        p.alpha = alpha > 0 ? alpha : 1500.;
+        check(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_ALPHA, h, dt), "nsdg_mevp_stable_params");
+        if (beta > 0)
+            p.beta = beta;
+    } else if (mode == "keep_delta_min")
+        check(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_DELTA_MIN, h, dt), "nsdg_mevp_stable_params");
+    else
+        check(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_ADAPTIVE, h, dt), "nsdg_mevp_stable_params");
+    return SubcycleChoice { mode, p.alpha, p.beta, p.delta_min, p.aevp_c, p.aevp_alpha_min, nsdg_mevp_creep_percent_per_day(&p) };
 }
 
 void DynamicsStep::splitRows(int ny, int world, int rank, int& r0, int& r1)
@@ -138,10 +166,12 @@ void DynamicsStep::configure()
     closure = getConfiguration(keyMap.at(12), true);
     minConc = getConfiguration(keyMap.at(13), 1e-12);
     minThick = getConfiguration(keyMap.at(14), 0.01);
-    // sub-cycle parameters (profiles/r05_closure.md): dynamics.alpha / beta given: used as they are; dynamics.delta_min given (and no
-    // alpha): alpha = beta from the stability bound for that regularisation (2e-9: rounds 1-4); neither: alpha = beta = 1500, the
-    // BASELINE's value, with the smallest Delta_min for which it is stable on this mesh
+    // sub-cycle parameters (include/nsdg.h: nsdg_mevp_stable_params): adaptive alpha / beta unless the configuration names a uniform
+    // alpha (then keep_alpha: round 5) or says otherwise
     deltaMin = getConfiguration(keyMap.at(15), 0.);
+    subcycle = getConfiguration(keyMap.at(16), std::string(alpha > 0 ? "keep_alpha" : "adaptive"));
+    if (subcycle != "adaptive" && subcycle != "keep_alpha" && subcycle != "keep_delta_min")
+        throw std::invalid_argument("dynamics.subcycle must be adaptive, keep_alpha or keep_delta_min");
     if (rowBlocks < 1 || passesPerExchange < 1 || nsub < 0)
         throw std::invalid_argument("dynamics.row_blocks and dynamics.passes_per_exchange must be >= 1, dynamics.nsub >= 0");
     if (forcing != "host" && forcing != "dummy" && forcing != "winter")
@@ -316,6 +346,26 @@ void DynamicsStep::start(const Iterator::TimePoint& startTime)
         const std::size_t first = (std::size_t)b.lo * b.nx;
         checkHip(hipMemcpy(b.d[H0], f.hice.data() + first, N * sizeof(double), hipMemcpyHostToDevice), "upload H");
         checkHip(hipMemcpy(b.d[A0], f.cice.data() + first, N * sizeof(double), hipMemcpyHostToDevice), "upload A");
+        if (f.dyn.present) {
+            // a restart: the state a dynamics run left (FieldStore::dyn) -- higher DG2 coefficients, velocity, stress -- for the local
+            // rows, ghost rows included (they hold what an exchange would deliver: the neighbours' own values)
+            const DynamicsState& dy = f.dyn;
+            const std::size_t NG = (std::size_t)nxf * nyf;
+            for (int c = 1; c < 6; ++c) {
+                checkHip(hipMemcpy(b.d[H0] + (long)c * N, dy.hdg.data() + (std::size_t)(c - 1) * NG + first, N * sizeof(double), hipMemcpyHostToDevice), "upload H (DG)");
+                checkHip(hipMemcpy(b.d[A0] + (long)c * N, dy.adg.data() + (std::size_t)(c - 1) * NG + first, N * sizeof(double), hipMemcpyHostToDevice), "upload A (DG)");
+            }
+            const std::size_t nn = 2 * (std::size_t)b.nx + 1, nfirst = 2 * (std::size_t)b.lo * nn;
+            checkHip(hipMemcpy(b.d[Ua], dy.u.data() + nfirst, NN * sizeof(double), hipMemcpyHostToDevice), "upload u");
+            checkHip(hipMemcpy(b.d[Va], dy.v.data() + nfirst, NN * sizeof(double), hipMemcpyHostToDevice), "upload v");
+            std::vector<double> t((std::size_t)TS, 0.);
+            const std::vector<double>* comps[3] = { &dy.s11, &dy.s12, &dy.s22 };
+            const int dst[3] = { S11a, S12a, S22a };
+            for (int k = 0; k < 3; ++k) {
+                tileRows(comps[k]->data(), NG, (std::size_t)b.lo, b.nx, b.ny, t);
+                checkHip(hipMemcpy(b.d[dst[k]], t.data(), (std::size_t)TS * sizeof(double), hipMemcpyHostToDevice), "upload stress");
+            }
+        }
         // analytic box-test forcing, evaluated on the device (ocean once, wind at the current model time every step)
         check(nsdg_boxtest_forcing(b.ctx, L, m_time, b.d[UA], b.d[VA], b.d[UO], b.d[VO]), "nsdg_boxtest_forcing");
         if (thermo) {
@@ -357,11 +407,8 @@ void DynamicsStep::iterate(const Iterator::Duration& dtSeconds)
     const double dt = dtSeconds;
     nsdg_mevp_params p;
     nsdg_mevp_default_params(&p);
-    const double hmesh = std::min(L / nxf, L / nyf);
-    const double a = alpha > 0 ? alpha : (deltaMin > 0 ? stableAlpha(hmesh, dt, deltaMin) : 1500.);
-    p.alpha = a;
-    p.beta = beta > 0 ? beta : a;
-    p.delta_min = deltaMin > 0 ? deltaMin : stableDeltaMin(hmesh, dt, a);
+    const SubcycleChoice sc = subcycleChoice(std::min(L / nxf, L / nyf), dt);
+    p.alpha = sc.alpha, p.beta = sc.beta, p.delta_min = sc.deltaMin, p.aevp_c = sc.aevpC, p.aevp_alpha_min = sc.aevpAlphaMin;
     p.min_conc = closure ? minConc : 0.;
     p.min_thick = closure ? minThick : 0.;
     const double t = m_time;
@@ -425,14 +472,34 @@ void DynamicsStep::stop(const Iterator::TimePoint&)
         // owned node rows: [2 j0, 2 j1) plus the top boundary row on the last block
         const long nn = 2L * b.nx + 1;
         const long rows = 2L * (b.j1 - b.j0) + (b.peerAbove < 0 ? 1 : 0);
-        std::vector<double> u(rows * nn);
-        checkHip(hipMemcpy(u.data(), b.curU() + 2L * b.j0 * nn, u.size() * sizeof(double), hipMemcpyDeviceToHost), "download u");
-        for (double x : u) {
-            umax[idx] = std::max(umax[idx], std::fabs(x));
-            finite = finite && std::isfinite(x);
+        // the rest of the state a restart needs (FieldStore::dyn): higher DG2 coefficients, velocity, stress of the owned rows
+        DynamicsState& dy = f.dyn;
+        const std::size_t NG = (std::size_t)nxf * nyf;
+        if (dy.hdg.size() != 5 * NG)
+            dy.resize((std::size_t)nyf, (std::size_t)nxf);
+        for (int c = 1; c < 6; ++c) {
+            checkHip(hipMemcpy(dy.hdg.data() + (std::size_t)(c - 1) * NG + first, b.curH() + (long)c * b.N + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download H (DG)");
+            checkHip(hipMemcpy(dy.adg.data() + (std::size_t)(c - 1) * NG + first, b.curA() + (long)c * b.N + skip, count * sizeof(double), hipMemcpyDeviceToHost), "download A (DG)");
+        }
+        checkHip(hipMemcpy(dy.u.data() + 2L * b.r0 * nn, b.curU() + 2L * b.j0 * nn, rows * nn * sizeof(double), hipMemcpyDeviceToHost), "download u");
+        checkHip(hipMemcpy(dy.v.data() + 2L * b.r0 * nn, b.curV() + 2L * b.j0 * nn, rows * nn * sizeof(double), hipMemcpyDeviceToHost), "download v");
+        {
+            const std::size_t TS = (std::size_t)nsdg_tiled_len(b.nx, b.ny, 8);
+            std::vector<double> t(TS);
+            std::vector<double>* comps[3] = { &dy.s11, &dy.s12, &dy.s22 };
+            const int src[3] = { b.par == 0 ? S11a : S11b, b.par == 0 ? S12a : S12b, b.par == 0 ? S22a : S22b };
+            for (int k = 0; k < 3; ++k) {
+                checkHip(hipMemcpy(t.data(), b.d[src[k]], TS * sizeof(double), hipMemcpyDeviceToHost), "download stress");
+                untileRows(t, b.nx, b.j0, b.j1 - b.j0, comps[k]->data(), NG, (std::size_t)b.r0);
+            }
+        }
+        for (long k = 2L * b.r0 * nn; k < (2L * b.r0 + rows) * nn; ++k) {
+            umax[idx] = std::max(umax[idx], std::max(std::fabs(dy.u[k]), std::fabs(dy.v[k])));
+            finite = finite && std::isfinite(dy.u[k]) && std::isfinite(dy.v[k]);
         }
         ++idx;
     }
+    f.dyn.present = true;
     m_umax = *std::max_element(umax.begin(), umax.end());
     m_sumH = m_sumA = 0;
     for (auto& bp : m_blocks)
@@ -507,12 +574,37 @@ std::vector<std::vector<double>*> DynamicsStep::restartPlanes(FieldStore& f, boo
     return planes;
 }
 
+namespace {
+// the element planes of the dynamics state (FieldStore::dyn): 5 + 5 + 3 x 8 planes of n values
+std::vector<double*> dynamicsPlanes(FieldStore& f)
+{
+    std::vector<double*> p;
+    DynamicsState& d = f.dyn;
+    for (auto* v : { &d.hdg, &d.adg })
+        for (int c = 0; c < 5; ++c)
+            p.push_back(v->data() + (std::size_t)c * f.n);
+    for (auto* v : { &d.s11, &d.s12, &d.s22 })
+        for (int c = 0; c < 8; ++c)
+            p.push_back(v->data() + (std::size_t)c * f.n);
+    return p;
+}
+// node rows a block of element rows [r0, r1) owns: [2 r0, 2 r1), and the top boundary row on the last block
+std::size_t ownedNodeRows(int r0, int r1, int ny) { return 2 * (std::size_t)(r1 - r0) + (r1 == ny ? 1 : 0); }
+} // namespace
+
 std::vector<double> DynamicsStep::packRows(FieldStore& f, bool thermodynamics, int nx, int r0, int r1)
 {
     std::vector<double> out;
     const std::size_t first = (std::size_t)r0 * nx, count = (std::size_t)(r1 - r0) * nx;
     for (auto* p : restartPlanes(f, thermodynamics))
         out.insert(out.end(), p->begin() + first, p->begin() + first + count);
+    if (f.dyn.present) { // the state of the dynamics travels with the rows: element planes, then the owned node rows of u and v
+        for (double* p : dynamicsPlanes(f))
+            out.insert(out.end(), p + first, p + first + count);
+        const std::size_t nn = 2 * (std::size_t)nx + 1, nfirst = 2 * (std::size_t)r0 * nn, ncount = ownedNodeRows(r0, r1, (int)(f.n / nx)) * nn;
+        for (auto* v : { &f.dyn.u, &f.dyn.v })
+            out.insert(out.end(), v->begin() + nfirst, v->begin() + nfirst + ncount);
+    }
     return out;
 }
 
@@ -520,11 +612,27 @@ void DynamicsStep::placeRows(FieldStore& f, bool thermodynamics, int nx, int r0,
 {
     const auto planes = restartPlanes(f, thermodynamics);
     const std::size_t first = (std::size_t)r0 * nx, rows = (std::size_t)(r1 - r0) * nx;
-    if (count != rows * planes.size())
+    const std::size_t nn = 2 * (std::size_t)nx + 1, ny = f.n / nx, nrows = ownedNodeRows(r0, r1, (int)ny) * nn;
+    const std::size_t plain = rows * planes.size(), full = plain + rows * (5 + 5 + 24) + 2 * nrows;
+    if (count != plain && count != full)
         throw std::runtime_error("DynamicsStep: a rank delivered " + std::to_string(count) + " values for its rows, expected "
-            + std::to_string(rows * planes.size()));
+            + std::to_string(plain) + " (or " + std::to_string(full) + " with the state of the dynamics)");
     for (std::size_t k = 0; k < planes.size(); ++k)
         std::copy(data + k * rows, data + (k + 1) * rows, planes[k]->begin() + first);
+    if (count == full) {
+        if (f.dyn.hdg.size() != 5 * f.n)
+            f.dyn.resize(ny, (std::size_t)nx);
+        const double* p = data + plain;
+        for (double* dst : dynamicsPlanes(f)) {
+            std::copy(p, p + rows, dst + first);
+            p += rows;
+        }
+        for (auto* v : { &f.dyn.u, &f.dyn.v }) {
+            std::copy(p, p + nrows, v->begin() + 2 * (std::size_t)r0 * nn);
+            p += nrows;
+        }
+        f.dyn.present = true;
+    }
 }
 
 } // namespace Nextsim

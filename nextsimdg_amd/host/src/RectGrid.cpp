@@ -18,6 +18,7 @@ void FieldStore::resize(std::size_t nElements, int nIceLayers)
     for (auto* v : { &hice, &cice, &hsnow, &sst, &sss, &tair, &tdew, &slp, &mixrat, &qsw, &qlw, &mld, &snowfall, &wind, &newice })
         v->assign(n, 0.);
     tice.assign(n * (std::size_t)nLayers, 0.);
+    dyn.clear();
 }
 
 ElementData& ElementData::operator=(const PrognosticGenerator& g)
@@ -90,13 +91,15 @@ void RectGrid::incrCursor()
 
 namespace {
 const char* MAGIC = "NSDG-RESTART 1";
-bool readHeader(std::istream& f, std::string& type, int& nx, int& ny, int& nl)
+bool readHeader(std::istream& f, std::string& type, int& nx, int& ny, int& nl, bool* dynamics = nullptr)
 {
     std::string line;
     if (!std::getline(f, line) || line != MAGIC)
         return false;
     type.clear();
     nx = ny = nl = 0;
+    if (dynamics)
+        *dynamics = false;
     while (std::getline(f, line) && line != "END-HEADER") {
         const auto eq = line.find('=');
         if (eq == std::string::npos)
@@ -110,6 +113,8 @@ bool readHeader(std::istream& f, std::string& type, int& nx, int& ny, int& nl)
             ny = std::stoi(v);
         else if (k == "data.nLayers")
             nl = std::stoi(v);
+        else if (k == "data.dynamics" && dynamics)
+            *dynamics = v == "1";
     }
     return nx > 0 && ny > 0 && nl > 0;
 }
@@ -169,6 +174,28 @@ void RectGrid::dump(const std::string& filePath) const
         }
         w.dataset(data + "/tice", { (std::uint64_t)m_nx, (std::uint64_t)m_ny, (std::uint64_t)m_store.nLayers }, t);
         w.attachDimensions(data + "/tice", { data + "/x", data + "/y", data + "/nLayers" }); // DevGridIO.cpp:192-201
+        if (m_store.dyn.present) { // the state of the dynamics: further variables of the same group (RectGrid.hpp)
+            const DynamicsState& d = m_store.dyn;
+            const std::uint64_t X = (std::uint64_t)m_nx, Y = (std::uint64_t)m_ny;
+            w.dimension(data, "dg2", 5, 3);
+            w.dimension(data, "stress8", 8, 4);
+            w.dimension(data, "xnode", 2 * X + 1, 5);
+            w.dimension(data, "ynode", 2 * Y + 1, 6);
+            for (const auto& v : { std::make_pair("hice_dg", &d.hdg), std::make_pair("cice_dg", &d.adg) }) {
+                w.dataset(data + "/" + v.first, { 5, X, Y }, *v.second);
+                w.attachDimensions(data + "/" + v.first, { data + "/dg2", data + "/x", data + "/y" });
+            }
+            for (const auto& v : { std::make_pair("u", &d.u), std::make_pair("v", &d.v) }) {
+                w.dataset(data + "/" + v.first, { 2 * X + 1, 2 * Y + 1 }, *v.second);
+                w.attachDimensions(data + "/" + v.first, { data + "/xnode", data + "/ynode" });
+            }
+            for (const auto& v : { std::make_pair("s11", &d.s11), std::make_pair("s12", &d.s12), std::make_pair("s22", &d.s22) }) {
+                w.dataset(data + "/" + v.first, { 8, X, Y }, *v.second);
+                w.attachDimensions(data + "/" + v.first, { data + "/stress8", data + "/x", data + "/y" });
+            }
+            w.dataset(data + "/newice", { X, Y }, m_store.newice);
+            w.attachDimensions(data + "/newice", { data + "/x", data + "/y" });
+        }
         w.write(filePath);
         return;
     }
@@ -180,10 +207,16 @@ void RectGrid::dump(const std::string& filePath) const
       << dataNodeName() << ".x=" << m_nx << "\n"
       << dataNodeName() << ".y=" << m_ny << "\n"
       << dataNodeName() << ".nLayers=" << m_store.nLayers << "\n"
-      << "variables=hice,cice,hsnow,sst,sss,tice\nEND-HEADER\n";
+      << (m_store.dyn.present ? "data.dynamics=1\nvariables=hice,cice,hsnow,sst,sss,tice,hice_dg,cice_dg,u,v,s11,s12,s22,newice\nEND-HEADER\n"
+                                : "variables=hice,cice,hsnow,sst,sss,tice\nEND-HEADER\n");
     for (const auto* v : { &m_store.hice, &m_store.cice, &m_store.hsnow, &m_store.sst, &m_store.sss })
         f.write(reinterpret_cast<const char*>(v->data()), (std::streamsize)(v->size() * sizeof(double)));
     f.write(reinterpret_cast<const char*>(t.data()), (std::streamsize)(t.size() * sizeof(double)));
+    if (m_store.dyn.present) {
+        const DynamicsState& d = m_store.dyn;
+        for (const auto* v : { &d.hdg, &d.adg, &d.u, &d.v, &d.s11, &d.s12, &d.s22, &m_store.newice })
+            f.write(reinterpret_cast<const char*>(v->data()), (std::streamsize)(v->size() * sizeof(double)));
+    }
 }
 
 void RectGrid::init(const std::string& filePath)
@@ -221,13 +254,26 @@ void RectGrid::init(const std::string& filePath)
         for (std::size_t e = 0; e < m_store.n; ++e)
             for (int l = 0; l < m_store.nLayers; ++l)
                 m_store.tice[(std::size_t)l * m_store.n + e] = t[e * m_store.nLayers + l];
+        if (h.exists(g + "s11")) { // the state of a dynamics run (all of it or none of it)
+            DynamicsState& dy = m_store.dyn;
+            dy.resize((std::size_t)m_nx, (std::size_t)m_ny);
+            for (const auto& v : { std::make_pair("hice_dg", &dy.hdg), std::make_pair("cice_dg", &dy.adg), std::make_pair("u", &dy.u), std::make_pair("v", &dy.v),
+                     std::make_pair("s11", &dy.s11), std::make_pair("s12", &dy.s12), std::make_pair("s22", &dy.s22), std::make_pair("newice", &m_store.newice) }) {
+                std::vector<double> a = h.readDoubles(g + v.first);
+                if (a.size() != v.second->size())
+                    throw std::runtime_error("restart file " + filePath + ": " + v.first + " does not have the size the grid asks for");
+                v.second->swap(a);
+            }
+            dy.present = true;
+        }
         resetCursor();
         return;
     }
     std::ifstream f(filePath, std::ios::binary);
     std::string type;
     int nx, ny, nl;
-    if (!f || !readHeader(f, type, nx, ny, nl))
+    bool dynamics = false;
+    if (!f || !readHeader(f, type, nx, ny, nl, &dynamics))
         throw std::runtime_error("cannot read restart file " + filePath);
     if (structureType() == "devgrid" && (nx != 10 || ny != 10))
         throw std::runtime_error("devgrid restart files must be 10x10");
@@ -236,6 +282,13 @@ void RectGrid::init(const std::string& filePath)
         f.read(reinterpret_cast<char*>(v->data()), (std::streamsize)(v->size() * sizeof(double)));
     std::vector<double> t(m_store.tice.size());
     f.read(reinterpret_cast<char*>(t.data()), (std::streamsize)(t.size() * sizeof(double)));
+    if (dynamics) {
+        DynamicsState& d = m_store.dyn;
+        d.resize((std::size_t)nx, (std::size_t)ny);
+        for (auto* v : { &d.hdg, &d.adg, &d.u, &d.v, &d.s11, &d.s12, &d.s22, &m_store.newice })
+            f.read(reinterpret_cast<char*>(v->data()), (std::streamsize)(v->size() * sizeof(double)));
+        d.present = true;
+    }
     if (!f)
         throw std::runtime_error("restart file " + filePath + " is truncated");
     for (std::size_t e = 0; e < m_store.n; ++e)

@@ -350,14 +350,55 @@ static void test_physics_config()
 }
 
 static void test_subcycle_policy()
-{ // alpha = beta = 1500 with the smallest Delta_min for which it is stable on the mesh, and the way back
-    for (double h : { 125., 250., 500. }) {
-        const double dmin = DynamicsStep::stableDeltaMin(h, 120., 1500.);
-        CHECK(dmin > 2e-9 && approx(DynamicsStep::stableAlpha(h, 120., dmin), 1500., 1e-9));
+{ // the stability rule of the sub-cycle lives in the library, once (nsdg_mevp_stable_params); DESIGN.md section 3.4
+    auto fresh = [] {
+        nsdg_mevp_params p;
+        nsdg_mevp_default_params(&p);
+        return p;
+    };
+    CHECK(fresh().aevp_c == 0. && fresh().delta_min == 2e-9); // a plain ABI user gets the uniform form of ABI 5
+    for (double h : { 125., 250., 500. }) { // keep alpha = 1500, raise Delta_min -- and the way back
+        nsdg_mevp_params p = fresh();
+        CHECK(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_ALPHA, h, 120.) == NSDG_OK && p.delta_min > 2e-9 && p.alpha == 1500. && p.beta == 1500. && p.aevp_c == 0.);
+        nsdg_mevp_params q = fresh();
+        q.delta_min = p.delta_min;
+        CHECK(nsdg_mevp_stable_params(&q, NSDG_SUBCYCLE_KEEP_DELTA_MIN, h, 120.) == NSDG_OK && approx(q.alpha, 1500., 1e-9));
     }
-    CHECK(approx(DynamicsStep::stableDeltaMin(250., 120.), 7.41e-7, 2e-3) && approx(DynamicsStep::stableDeltaMin(500., 120.), 1.853e-7, 2e-3));
-    CHECK(DynamicsStep::stableDeltaMin(8000., 120.) == 2e-9); // coarse meshes keep the literature's regularisation
-    CHECK(approx(DynamicsStep::stableAlpha(250., 120.), 28875., 1e-3)); // ... which on a fine mesh asks for the alpha of rounds 1-4
+    nsdg_mevp_params p = fresh();
+    nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_ALPHA, 250., 120.);
+    CHECK(approx(p.delta_min, 7.41e-7, 2e-3) && approx(nsdg_mevp_creep_percent_per_day(&p), 6.4, 1e-2)); // below 6.4 % per day the ice creeps
+    p = fresh();
+    nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_ALPHA, 500., 120.);
+    CHECK(approx(p.delta_min, 1.853e-7, 2e-3));
+    p = fresh();
+    nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_ALPHA, 8000., 120.);
+    CHECK(p.delta_min == 2e-9); // coarse meshes keep the literature's regularisation
+    p = fresh();
+    nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_DELTA_MIN, 250., 120.);
+    CHECK(approx(p.alpha, 28875., 1e-3) && p.beta == p.alpha); // ... which on a fine mesh asks for the alpha of rounds 1-4
+    p = fresh();
+    CHECK(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_ADAPTIVE, 250., 120.) == NSDG_OK && approx(p.aevp_c, 2.4 * 2.4 * 9.869604401089358, 1e-12)
+        && p.aevp_alpha_min == 50. && p.delta_min == 2e-9); // the hosts' default: local alpha / beta at the literature's Delta_min
+    CHECK(nsdg_mevp_stable_params(&p, 9, 250., 120.) == NSDG_ERR_ARG && nsdg_mevp_stable_params(nullptr, 0, 250., 120.) == NSDG_ERR_ARG);
+    // the host's configuration keys choose among the three
+    Configurator::clear();
+    DynamicsStep d0;
+    d0.configure();
+    CHECK(d0.subcycleChoice(250., 120.).mode == "adaptive" && d0.subcycleChoice(250., 120.).aevpC > 50.);
+    addConfig("[dynamics]\nalpha = 1500\n");
+    DynamicsStep d1;
+    d1.configure();
+    CHECK(d1.subcycleChoice(250., 120.).mode == "keep_alpha" && approx(d1.subcycleChoice(250., 120.).deltaMin, 7.41e-7, 2e-3) && d1.subcycleChoice(250., 120.).aevpC == 0.);
+    Configurator::clear();
+    addConfig("[dynamics]\nsubcycle = keep_delta_min\n");
+    DynamicsStep d2;
+    d2.configure();
+    CHECK(approx(d2.subcycleChoice(250., 120.).alpha, 28875., 1e-3) && d2.subcycleChoice(250., 120.).deltaMin == 2e-9);
+    Configurator::clear();
+    addConfig("[dynamics]\nsubcycle = sometimes\n");
+    DynamicsStep d3;
+    CHECK_THROWS_AS(d3.configure(), std::invalid_argument);
+    Configurator::clear();
 }
 
 static void test_structure()
@@ -788,6 +829,119 @@ static void test_restart_gather()
     CHECK_THROWS_AS(gatherToRankZero(orphan, &x, sizeof x, nullptr, 1), std::runtime_error);
 }
 
+static void fillDynamicsState(FieldStore& f, int nx, int ny, double salt)
+{ // nx = slow ("x" of the file), ny = fast
+    f.dyn.resize((std::size_t)nx, (std::size_t)ny);
+    auto fill = [&](std::vector<double>& v, double base) {
+        for (std::size_t k = 0; k < v.size(); ++k)
+            v[k] = base + salt + 1e-3 * (double)k;
+    };
+    fill(f.dyn.hdg, 1.), fill(f.dyn.adg, 2.), fill(f.dyn.u, 3.), fill(f.dyn.v, 4.), fill(f.dyn.s11, 5.), fill(f.dyn.s12, 6.), fill(f.dyn.s22, 7.);
+    f.dyn.present = true;
+}
+
+static void test_restart_with_dynamics_state()
+{ // what a dynamics run carries between steps travels in the restart file, in both formats (RectGrid.hpp), and between the ranks
+    for (const char* path : { "/tmp/nsdg_host_test_dyn_restart.nc", "/tmp/nsdg_host_test_dyn_restart.nsdg" }) {
+        RectGrid g;
+        g.resize(5, 7, 2);
+        FieldStore& f = g.fields();
+        for (std::size_t e = 0; e < f.n; ++e)
+            f.hice[e] = 0.1 * e, f.cice[e] = 0.5, f.newice[e] = 1e-5 * e;
+        fillDynamicsState(f, 5, 7, 0.25);
+        g.dump(path);
+        auto again = StructureFactory::generateFromFile(path);
+        again->init(path);
+        const FieldStore& r = again->fields();
+        CHECK(r.dyn.present && r.dyn.hdg == f.dyn.hdg && r.dyn.adg == f.dyn.adg && r.dyn.u == f.dyn.u && r.dyn.v == f.dyn.v);
+        CHECK(r.dyn.s11 == f.dyn.s11 && r.dyn.s12 == f.dyn.s12 && r.dyn.s22 == f.dyn.s22 && r.newice == f.newice && r.hice == f.hice);
+        if (Hdf5File::isHdf5(path)) { // named dimensions as the reference names its own (core/src/DevGridIO.cpp:169-172)
+            const Hdf5File h(path);
+            CHECK(h.dims("/data/hice_dg") == (std::vector<std::uint64_t> { 5, 5, 7 }) && h.dims("/data/u") == (std::vector<std::uint64_t> { 11, 15 }));
+            CHECK(h.dims("/data/s12") == (std::vector<std::uint64_t> { 8, 5, 7 }) && h.exists("/data/stress8") && h.exists("/data/xnode"));
+        }
+        // a file without the state (the reference's, a column-only run's): the dynamics start from rest
+        RectGrid plain;
+        plain.resize(5, 7, 2);
+        plain.dump(path);
+        again->init(path);
+        CHECK(!again->fields().dyn.present);
+        std::remove(path);
+    }
+    // the rows of a rank travel with their share of the state
+    const int nx = 7, ny = 10; // here nx = the fast dimension of the dynamics (row length), ny = rows
+    FieldStore a, b;
+    a.resize((std::size_t)nx * ny, 1), b.resize((std::size_t)nx * ny, 1);
+    fillDynamicsState(a, ny, nx, 0.5);
+    for (const auto& rows : { std::make_pair(3, 6), std::make_pair(6, 10) }) { // an interior block and the last one (which owns the top node row)
+        const std::vector<double> packed = DynamicsStep::packRows(a, false, nx, rows.first, rows.second);
+        const std::size_t nodeRows = 2 * (std::size_t)(rows.second - rows.first) + (rows.second == ny ? 1 : 0);
+        CHECK(packed.size() == (std::size_t)(rows.second - rows.first) * nx * (2 + 34) + 2 * nodeRows * (2 * nx + 1));
+        DynamicsStep::placeRows(b, false, nx, rows.first, rows.second, packed.data(), packed.size());
+        bool ok = b.dyn.present;
+        for (int c = 0; c < 8 && ok; ++c)
+            for (int e = rows.first * nx; e < rows.second * nx; ++e)
+                ok = ok && b.dyn.s12[(std::size_t)c * a.n + e] == a.dyn.s12[(std::size_t)c * a.n + e] && (c >= 5 || b.dyn.adg[(std::size_t)c * a.n + e] == a.dyn.adg[(std::size_t)c * a.n + e]);
+        for (std::size_t k = 2 * (std::size_t)rows.first * (2 * nx + 1); k < (2 * (std::size_t)rows.first + nodeRows) * (2 * nx + 1) && ok; ++k)
+            ok = ok && b.dyn.u[k] == a.dyn.u[k] && b.dyn.v[k] == a.dyn.v[k];
+        CHECK(ok);
+        CHECK(b.dyn.u[0] == 0. && b.dyn.s11[0] == 0.); // rows nobody delivered stay as they were
+        CHECK_THROWS_AS(DynamicsStep::placeRows(b, false, nx, rows.first, rows.second, packed.data(), packed.size() - 1), std::runtime_error);
+    }
+}
+
+static std::vector<char> fileBytes(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+static void run_dynamics_to_file(const std::string& model, const std::string& extra, const std::string& finalFile)
+{
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+    addConfig("[Modules]\nNextsim::IModelStep = Nextsim::DynamicsStep\n[model]\nstructure = rectgrid\ntime_step = 120\n" + model + "final_file = " + finalFile
+        + "\n[rectgrid]\nnx = 128\nny = 96\n[init]\nhice = 0.3\ncice = 0.9\nsst = -1.76\nhsnow = 0.05\ntice = -8\n[dynamics]\nnsub = 23\nthermodynamics = true\nforcing = winter\n" + extra);
+    ConfiguredModule::parseConfigurator();
+    {
+        Model model;
+        model.configure();
+        model.run();
+    } // ~Model writes the restart file
+    Configurator::clear();
+    ModuleLoader::getLoader().setAllDefaults();
+}
+
+static void test_dynamics_restart_is_exact()
+{ // N steps == N/2 steps + restart file + N/2 steps, byte for byte, as one block and as eight (review of round 5: the restart dropped the
+  // higher DG coefficients, the velocity and the stress -- a restarted run started from rest; the reference writes every prognostic
+  // field it has, core/src/DevGridIO.cpp:169-201, and reads them back, :101-138)
+    for (const char* ext : { ".nsdg", ".nc" }) {
+        const std::string whole = std::string("/tmp/nsdg_rst_whole") + ext, half = std::string("/tmp/nsdg_rst_half") + ext, resumed = std::string("/tmp/nsdg_rst_resumed") + ext;
+        for (const char* blocks : { "", "row_blocks = 8\npasses_per_exchange = 1\n" }) {
+            run_dynamics_to_file("start = 0\nstop = 720\n", blocks, whole); // 6 steps
+            run_dynamics_to_file("start = 0\nstop = 360\n", blocks, half); // 3 steps, restart file ...
+            run_dynamics_to_file("init_file = " + half + "\nstart = 360\nstop = 720\n", blocks, resumed); // ... and 3 more from it
+            const std::vector<char> w = fileBytes(whole), r = fileBytes(resumed), h = fileBytes(half);
+            CHECK(w.size() > 128 * 96 * 8 * 40 && w == r); // the file holds the whole state, and the resumed run reproduces it byte for byte
+            CHECK(h != w);
+        }
+        // and the decomposition does not show: the file of the 8-block run above == the file of a single block
+        const std::vector<char> eight = fileBytes(whole);
+        run_dynamics_to_file("start = 0\nstop = 720\n", "", whole);
+        CHECK(fileBytes(whole) == eight);
+        // a restart from the file of the OLD kind (cell means only) starts from rest: it must differ
+        auto plain = StructureFactory::generateFromFile(half);
+        plain->init(half);
+        plain->fields().dyn.clear();
+        plain->dump(half);
+        run_dynamics_to_file("init_file = " + half + "\nstart = 360\nstop = 720\n", "", resumed);
+        CHECK(fileBytes(resumed) != eight);
+        for (const std::string& p : { whole, half, resumed })
+            std::remove(p.c_str());
+    }
+}
+
 static FieldStore run_dynamics(const std::string& extra, double* umax)
 {
     Configurator::clear();
@@ -857,11 +1011,13 @@ int main(int argc, char** argv)
             test_restart_hdf5();
             test_rendezvous();
             test_restart_gather();
+            test_restart_with_dynamics_state();
         } else {
             test_hipstep_melting();
             test_model_dev1();
             test_dynamics_step();
             test_dynamics_row_blocks();
+            test_dynamics_restart_is_exact();
             test_dynamics_reports_a_run_that_blows_up();
         }
     } catch (const std::exception& e) {

@@ -1,5 +1,6 @@
 """Synthetic inputs: the seeded column-physics fields of SURVEY.md section 8(d) and the 512 km box
-test (cyclone wind over a circular ocean current) used for BASELINE configs 3-5.  numpy only."""
+test (cyclone wind over a circular ocean current) used for BASELINE configs 3-5.  numpy only (the sub-cycle's
+stability rule is asked of the library: it is host code, no device needed)."""
 import numpy as np
 
 from . import basis
@@ -56,40 +57,53 @@ class BoxTest:
         self.nx, self.ny, self.L = nx, ny, L
         self.hx, self.hy = L / nx, L / ny
 
-    def stable_alpha(self, dt, pstar=27.5e3, delta_min=2e-9, rho_ice=900.0, h_ice=0.3, safety=2.4, floor=1500.0):
-        """alpha = beta for which the mEVP pseudo-time iteration is linearly stable on this mesh:
-        alpha*beta >= pi^2 * zeta_max * dt / (m * h^2), zeta_max = P*H/(2 Delta_min), m = rho_i H.
-        (Measured on the MI355X, round 1: with alpha = beta = 1500 round-off differences between two
-        kernel variants grow x150 per sub-iteration at h = 250 m; the bound -- 1.2e4 there -- is sharp:
-        12000 is stable, 6000 is not.  Round 2: that is the bound of the INITIAL state; a one-day run needs margin --
-        with 1.2 x the bound the dynamics at 2048^2 / 4096^2 diverge after 21-23 model hours (deformation zones sharpen,
-        the local ratio of ice strength to nodal mass grows), with 1.8 x they start to (free-drift speeds at hour 24),
-        with 2.4 x and 3.6 x the day completes (profiles/r02_alpha_margin.txt); the default is 2.4 x.
-        The flop and byte counts do not depend on alpha.)"""
-        h = min(self.hx, self.hy)
-        zeta_max = pstar * h_ice / (2.0 * delta_min)
-        bound = np.sqrt(np.pi ** 2 * zeta_max * dt / (rho_ice * h_ice * h * h))
-        return float(max(floor, safety * bound))
+    # The stability rule of the explicit sub-cycle lives in the library, ONCE (nsdg_mevp_stable_params, include/nsdg.h; round 5 had a
+    # copy here, one in the C++ host and one in the header's comment): alpha beta >= (2.4 pi)^2 zeta dt / (m h^2).  What was measured:
+    # with alpha = beta = 1500 round-off differences between two kernel variants grow x150 per sub-iteration at h = 250 m; the bound
+    # -- 1.2e4 there -- is sharp: 12000 is stable, 6000 is not (round 1).  That is the bound of the INITIAL state; a one-day run needs
+    # margin: with 1.2 x the bound the dynamics at 2048^2 / 4096^2 diverge after 21-23 model hours, with 2.4 x the day completes
+    # (profiles/r02_alpha_margin.txt).  The flop and byte counts do not depend on any of it.
+    def _stable(self, mode, dt, **kw):
+        import ctypes as C
 
-    def stable_delta_min(self, dt, alpha=1500.0, pstar=27.5e3, rho_ice=900.0, safety=2.4, floor=2e-9):
-        """The other way round (round 5, profiles/r05_closure.md): the SMALLEST regularisation Delta_min -- never below the
-        literature's 2e-9 1/s -- for which the BASELINE's alpha = beta = 1500 satisfies the stability bound above with its margin:
-        zeta_max / m = P* / (2 Delta_min rho_i) <= alpha^2 h^2 / (safety^2 pi^2 dt).  Why the hosts choose THIS way: with the bound's
-        alpha on a fine mesh (14 438 at 500 m, 57 751 at 125 m) 120 sub-iterations move the stress and the velocity 1 % or less of
-        the way to their viscous-plastic state per model step, and a compressible cover (A0 = 0.9) then leaves the physical range
-        within a model day or two whatever closes the transport; with alpha = 1500 and the viscosity capped accordingly
-        (Delta_min 1.9e-7 at 500 m, 7.4e-7 at 250 m, 3.0e-6 at 125 m: creep below ~1 - 25 % per day) the same runs complete.
-        stable_alpha(dt, delta_min=stable_delta_min(dt, alpha)) == alpha."""
-        h = min(self.hx, self.hy)
-        return float(max(floor, safety ** 2 * np.pi ** 2 * pstar * dt / (2.0 * rho_ice * h * h * alpha * alpha)))
+        from . import abi
 
-    def subcycle_parameters(self, dt, alpha=1500.0, delta_min=None):
-        """alpha = beta and Delta_min of the mEVP sub-cycle as the hosts set them: the named alpha with the regularisation the mesh
-        needs for it (default), or -- delta_min given -- that regularisation with the alpha its stability bound asks for"""
-        if delta_min is None:
-            return dict(alpha=float(alpha), beta=float(alpha), delta_min=self.stable_delta_min(dt, alpha))
-        a = self.stable_alpha(dt, delta_min=delta_min)
-        return dict(alpha=a, beta=a, delta_min=float(delta_min))
+        p = abi.MevpParams()
+        abi.load_library().nsdg_mevp_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, float(v))
+        return abi.stable_mevp_params(p, mode, min(self.hx, self.hy), dt)
+
+    def stable_alpha(self, dt, delta_min=2e-9):
+        """uniform alpha = beta the stability bound asks for with this Delta_min (at least 1500): the configuration of rounds 1-4"""
+        from . import abi
+
+        return float(self._stable(abi.SUBCYCLE_KEEP_DELTA_MIN, dt, delta_min=delta_min).alpha)
+
+    def stable_delta_min(self, dt, alpha=1500.0):
+        """the smallest Delta_min (never below the literature's 2e-9) for which the uniform alpha = beta is stable on this mesh: the
+        configuration of round 5 (1.9e-7 at 500 m, 7.4e-7 at 250 m, 3.0e-6 at 125 m: below that strain rate the ice creeps)"""
+        from . import abi
+
+        return float(self._stable(abi.SUBCYCLE_KEEP_ALPHA, dt, alpha=alpha).delta_min)
+
+    def subcycle_parameters(self, dt, mode="adaptive", alpha=1500.0, delta_min=None):
+        """keyword arguments for Context.mevp_default_params, as the hosts set the sub-cycle:
+        "adaptive" (default since round 6): local, solution-adaptive alpha and beta with the stability bound's own constant, Delta_min
+        the literature's 2e-9 (or `delta_min`); "keep_alpha" (round 5): uniform alpha = beta = `alpha`, Delta_min raised to what the mesh
+        needs for it; "keep_delta_min" (rounds 1-4): uniform alpha = beta from the bound for `delta_min` (2e-9)"""
+        from . import abi
+
+        dm = 2e-9 if delta_min is None else float(delta_min)
+        if mode == "adaptive":
+            p = self._stable(abi.SUBCYCLE_ADAPTIVE, dt, delta_min=dm)
+        elif mode == "keep_alpha":
+            p = self._stable(abi.SUBCYCLE_KEEP_ALPHA, dt, alpha=alpha, delta_min=dm)
+        elif mode == "keep_delta_min":
+            p = self._stable(abi.SUBCYCLE_KEEP_DELTA_MIN, dt, delta_min=dm)
+        else:
+            raise ValueError("mode must be adaptive, keep_alpha or keep_delta_min")
+        return dict(alpha=float(p.alpha), beta=float(p.beta), delta_min=float(p.delta_min), aevp_c=float(p.aevp_c), aevp_alpha_min=float(p.aevp_alpha_min))
 
     def H0(self, x, y):
         return 0.3 + 0.005 * (np.sin(6e-5 * x) + np.sin(3e-5 * y))

@@ -185,6 +185,15 @@ void oracle_mevp_default_params(oracle_mevp_params* p)
     /* the column model's own cut-off values (nextsim_thermo.min_conc / min_thick, physics/src/modules/NextsimPhysics.cpp:81-82) */
     p->min_conc = 1e-12;
     p->min_thick = 0.01;
+    p->aevp_c = 0.; /* uniform alpha, beta */
+    p->aevp_alpha_min = 50.;
+}
+
+/* ice-free-node rule (dyn_oracle.h) */
+static int node_ice_free(const oracle_mevp_params* p, double cgh, double cga)
+{
+    const int rule = p->min_conc > 0. || p->min_thick > 0.;
+    return rule && (cga < p->min_conc || cgh < p->min_thick * cga || cgh <= p->h_min);
 }
 
 int oracle_dg_ncoef(int order) { return order == 0 ? 1 : (order == 1 ? 3 : 6); }
@@ -431,7 +440,8 @@ void oracle_ice_strength(int nx, int ny, int j0, int j1, const oracle_mevp_param
 
 /* ------------------------------------------------------------------ mEVP stress update */
 void oracle_mevp_stress(int nx, int ny, int k0, int k1, double hx, double hy, const oracle_mevp_params* p,
-    const double* u, const double* v, const double* pg, double* s11, double* s12, double* s22)
+    const double* u, const double* v, const double* pg, double* s11, double* s12, double* s22, double dt, const double* cgh,
+    const double* cga, double* alpha_e)
 {
     init_tables();
     const long N = (long)nx * ny;
@@ -464,6 +474,7 @@ void oracle_mevp_stress(int nx, int ny, int k0, int k1, double hx, double hy, co
                 E12[i] = 0.5 * (uyy / hy + vxx / hx);
             }
             double r11[8] = { 0 }, r12[8] = { 0 }, r22[8] = { 0 };
+            double zeta_e = 0.; /* adaptive form: the largest viscosity P / (2 Delta) of the element */
             for (int q = 0; q < 9; ++q) {
                 const double x = gp[q % 3], y = gp[q / 3], w = gw[q % 3] * gw[q / 3];
                 double e11 = 0, e12 = 0, e22 = 0;
@@ -476,6 +487,7 @@ void oracle_mevp_stress(int nx, int ny, int k0, int k1, double hx, double hy, co
                 const double P = pg[q * N + e];
                 const double delta = sqrt(dmin2 + 1.25 * (e11 * e11 + e22 * e22) + 1.5 * e11 * e22 + e12 * e12);
                 const double pd = P / delta;
+                zeta_e = fmax(zeta_e, 0.5 * pd);
                 const double t11 = pd * (0.625 * e11 + 0.375 * e22) - 0.5 * P;
                 const double t22 = pd * (0.625 * e22 + 0.375 * e11) - 0.5 * P;
                 const double t12 = pd * 0.25 * e12;
@@ -486,10 +498,19 @@ void oracle_mevp_stress(int nx, int ny, int k0, int k1, double hx, double hy, co
                     r22[i] += ps * t22;
                 }
             }
+            double ia = ialpha;
+            if (p->aevp_c > 0.) { /* local, solution-adaptive alpha (dyn_oracle.h) */
+                const long nc = (long)(2 * iy + 1) * nn + 2 * ix + 1; /* the element's centre node */
+                double a2 = p->aevp_alpha_min * p->aevp_alpha_min;
+                if (!node_ice_free(p, cgh[nc], cga[nc]))
+                    a2 = fmax(a2, p->aevp_c * zeta_e * dt / (p->rho_ice * fmax(cgh[nc], p->h_min) * hx * hy));
+                alpha_e[e] = sqrt(a2);
+                ia = 1. / alpha_e[e];
+            }
             for (int i = 0; i < 8; ++i) {
-                s11[i * N + e] = (1. - ialpha) * s11[i * N + e] + ialpha * OT.imass[i] * r11[i];
-                s12[i * N + e] = (1. - ialpha) * s12[i * N + e] + ialpha * OT.imass[i] * r12[i];
-                s22[i * N + e] = (1. - ialpha) * s22[i * N + e] + ialpha * OT.imass[i] * r22[i];
+                s11[i * N + e] = (1. - ia) * s11[i * N + e] + ia * OT.imass[i] * r11[i];
+                s12[i * N + e] = (1. - ia) * s12[i * N + e] + ia * OT.imass[i] * r12[i];
+                s22[i * N + e] = (1. - ia) * s22[i * N + e] + ia * OT.imass[i] * r22[i];
             }
         }
 }
@@ -499,7 +520,7 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
     const oracle_mevp_params* p, const double* s11, const double* s12, const double* s22,
     const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0,
     const double* v0, const double* tax, const double* tay, const double* uo, const double* vo,
-    const double* cgh, const double* cga)
+    const double* cgh, const double* cga, const double* alpha_e)
 {
     init_tables();
     const long N = (long)nx * ny;
@@ -515,6 +536,9 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
                 continue;
             }
             double divx = 0, divy = 0, lumped = 0;
+            double beta = p->beta; /* adaptive form: the largest alpha of the adjacent elements */
+            if (p->aevp_c > 0.)
+                beta = 0.;
             const int ix_hi = gx / 2, ix_lo = (gx % 2 == 0) ? gx / 2 - 1 : gx / 2;
             const int iy_hi = gy / 2, iy_lo = (gy % 2 == 0) ? gy / 2 - 1 : gy / 2;
             for (int iy = iy_lo; iy <= iy_hi; ++iy)
@@ -535,22 +559,23 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
                     divx -= hy * gx11 + hx * gy12;
                     divy -= hy * gx12 + hx * gy22;
                     lumped += hx * hy * OT.lump[a];
+                    if (p->aevp_c > 0.)
+                        beta = fmax(beta, alpha_e[e]);
                 }
             const double uu = u_old[n], vv = v_old[n];
             const double du = uo[n] - uu, dv = vo[n] - vv;
             const double absocn = sqrt(du * du + dv * dv);
             const double h = fmax(cgh[n], p->h_min);
             /* ice-free-node rule (dyn_oracle.h): free drift at full exposure, the neighbours' stress divergence weighted by 2^-100 */
-            const int rule = p->min_conc > 0. || p->min_thick > 0.;
-            const int ice_free = rule && (cga[n] < p->min_conc || cgh[n] < p->min_thick * cga[n] || cgh[n] <= p->h_min);
+            const int ice_free = node_ice_free(p, cgh[n], cga[n]);
             const double a_ = ice_free ? 1. : fmin(fmax(cga[n], 0.), 1.);
             const double wdiv = ice_free ? 0x1p-100 : 1.;
             const double mdt = p->rho_ice * h / dt;
             const double cdrag = a_ * f_ocean * absocn;
-            const double denom = 1. / (mdt * (1. + p->beta) + cdrag);
+            const double denom = 1. / (mdt * (1. + beta) + cdrag);
             const double cor = p->rho_ice * h * p->fc;
-            u_new[n] = denom * (mdt * (p->beta * uu + u0[n]) + a_ * tax[n] + cdrag * uo[n] + cor * (vv - vo[n]) + wdiv * (divx / lumped));
-            v_new[n] = denom * (mdt * (p->beta * vv + v0[n]) + a_ * tay[n] + cdrag * vo[n] - cor * (uu - uo[n]) + wdiv * (divy / lumped));
+            u_new[n] = denom * (mdt * (beta * uu + u0[n]) + a_ * tax[n] + cdrag * uo[n] + cor * (vv - vo[n]) + wdiv * (divx / lumped));
+            v_new[n] = denom * (mdt * (beta * vv + v0[n]) + a_ * tay[n] + cdrag * vo[n] - cor * (uu - uo[n]) + wdiv * (divy / lumped));
         }
     if (j1 == ny) /* the right column and the top row are boundary nodes: keep them at zero */
         for (int gx = 0; gx < nn; ++gx) {
@@ -571,13 +596,15 @@ void oracle_mevp_subcycle(int nx, int ny, double hx, double hy, double dt, int n
     const long nnodes = (long)NN(nx) * NN(ny);
     double* un = scratch;
     double* vn = scratch + nnodes;
+    double* alpha_e = p->aevp_c > 0. ? (double*)malloc(sizeof(double) * (size_t)nx * ny) : NULL;
     for (int it = 0; it < nsub; ++it) {
-        oracle_mevp_stress(nx, ny, 0, ny, hx, hy, p, u, v, pg, s11, s12, s22);
+        oracle_mevp_stress(nx, ny, 0, ny, hx, hy, p, u, v, pg, s11, s12, s22, dt, cgh, cga, alpha_e);
         oracle_mevp_velocity(nx, ny, 0, ny, hx, hy, dt, p, s11, s12, s22, u, v, un, vn, u0, v0, tax, tay,
-            uo, vo, cgh, cga);
+            uo, vo, cgh, cga, alpha_e);
         memcpy(u, un, nnodes * sizeof(double));
         memcpy(v, vn, nnodes * sizeof(double));
     }
+    free(alpha_e);
 }
 
 void oracle_wind_stress(long nnodes, const oracle_mevp_params* p, const double* ua, const double* va,

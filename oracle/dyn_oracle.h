@@ -21,6 +21,12 @@ typedef struct {
      * min_thick or whose mean thickness is at the mass floor h_min (its mass would be made up) is in free drift -- full exposure (a = 1) to wind and ocean drag, Coriolis, its floor mass -- and the stress
      * divergence of the neighbouring elements is weighted by 2^-100 there.  Both 0: rule off. */
     double min_conc, min_thick;
+    /* local, solution-adaptive alpha and beta (round 6; after Kimmritz, Danilov & Losch 2016): aevp_c > 0 replaces the uniform alpha,
+     * beta: per sub-iteration and element  zeta_e = max over its 9 Gauss points of P / (2 Delta),
+     * alpha_e = sqrt(max(aevp_alpha_min^2, aevp_c zeta_e dt / (rho_ice max(cgH_c, h_min) hx hy)))  with cgH_c the nodal mean thickness
+     * at the element's centre node (alpha_e = aevp_alpha_min if that node is ice-free by the rule above),
+     * S <- (1 - 1/alpha_e) S + (1/alpha_e) Proj sigma, and per node  beta_n = max of alpha_e over the adjacent elements. */
+    double aevp_c, aevp_alpha_min;
 } oracle_mevp_params;
 
 void oracle_dyn_init(void);
@@ -53,16 +59,18 @@ void oracle_dg_to_cg(int nx, int ny, int ncoef, const double* f_dg, double* f_cg
 void oracle_ice_strength(int nx, int ny, int j0, int j1, const oracle_mevp_params* p, const double* H,
     const double* A, double* pg);
 
-/* stress update on element rows [k0,k1) */
+/* stress update on element rows [k0,k1).  Adaptive form (p->aevp_c > 0): dt, cgh, cga are read and alpha_e[iy * nx + ix] receives the
+ * element's alpha of this sub-iteration; uniform form: they are ignored (alpha_e may be NULL). */
 void oracle_mevp_stress(int nx, int ny, int k0, int k1, double hx, double hy, const oracle_mevp_params* p,
-    const double* u, const double* v, const double* pg, double* s11, double* s12, double* s22);
+    const double* u, const double* v, const double* pg, double* s11, double* s12, double* s22, double dt, const double* cgh,
+    const double* cga, double* alpha_e);
 
 /* velocity update on the nodes owned by element rows [j0,j1) (bottom-left ownership) */
 void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, double dt,
     const oracle_mevp_params* p, const double* s11, const double* s12, const double* s22,
     const double* u_old, const double* v_old, double* u_new, double* v_new, const double* u0,
     const double* v0, const double* tax, const double* tay, const double* uo, const double* vo,
-    const double* cgh, const double* cga);
+    const double* cgh, const double* cga, const double* alpha_e);
 
 /* nsub full-domain sub-iterations, result left in u,v (scratch = 2 * nnodes doubles) */
 void oracle_mevp_subcycle(int nx, int ny, double hx, double hy, double dt, int nsub,

@@ -132,17 +132,23 @@ def wind_stress(par, ua, va):
 
 
 # ------------------------------------------------------------------------------------------------ one mEVP sub-iteration
-def mevp_stress(par, hx, hy, u, v, P, S):
-    """S <- (1 - 1/alpha) S + (1/alpha) Proj sigma(u, v); S = [3][8, ny, nx] (s11, s12, s22), returns new arrays"""
+def mevp_stress(par, hx, hy, u, v, P, S, dt=None, cgh=None, cga=None):
+    """S <- (1 - 1/alpha) S + (1/alpha) Proj sigma(u, v); S = [3][8, ny, nx] (s11, s12, s22), returns new arrays.
+    Adaptive form (par["aevp_c"] > 0; DESIGN.md section 3.5, after Kimmritz, Danilov & Losch 2016): every element relaxes with the
+    alpha its own largest viscosity of this sub-iteration asks for, alpha_e^2 = max(alpha_min^2, c zeta_e dt / (m_e |K|)), m_e the
+    nodal mass at its centre node (alpha_min where that node is ice-free); returns (new arrays, alpha_e [ny, nx])"""
     _, ny, nx = S[0].shape
     g, w = gauss_unit(3)
     Minv = np.linalg.inv(mass_matrix(8))
     out = [s.copy() for s in S]
     ia = 1.0 / par["alpha"]
+    adaptive = par.get("aevp_c", 0.0) > 0.0
+    alpha_e = np.zeros((ny, nx))
     for iy in range(ny):
         for ix in range(nx):
             ul, vl = local_nodes(u, ix, iy), local_nodes(v, ix, iy)
             rhs = np.zeros((3, 8))
+            zetas = []
             for qy in range(3):
                 for qx in range(3):
                     x, y = g[qx], g[qy]
@@ -152,23 +158,40 @@ def mevp_stress(par, hx, hy, u, v, P, S):
                     p = P[3 * qy + qx, iy, ix]
                     delta = np.sqrt(par["delta_min"] ** 2 + (e11 + e22) ** 2 + ((e11 - e22) ** 2 + 4.0 * e12 ** 2) / E_RATIO ** 2)
                     zeta = p / (2.0 * delta)
+                    zetas.append(zeta)
                     eta = zeta / E_RATIO ** 2
                     tr = e11 + e22
                     sig = (2.0 * eta * e11 + (zeta - eta) * tr - 0.5 * p, 2.0 * eta * e12, 2.0 * eta * e22 + (zeta - eta) * tr - 0.5 * p)
                     for i in range(8):
                         for c in range(3):
                             rhs[c, i] += w[qx] * w[qy] * psi(i, x, y) * sig[c]
+            if adaptive:
+                hc, ac = cgh[2 * iy + 1, 2 * ix + 1], cga[2 * iy + 1, 2 * ix + 1]  # the element's centre node
+                alpha = par["aevp_alpha_min"]
+                if not ice_free(par, hc, ac):
+                    mass = par["rho_ice"] * max(hc, par["h_min"])
+                    alpha = max(alpha, np.sqrt(par["aevp_c"] * max(zetas) * dt / (mass * hx * hy)))
+                alpha_e[iy, ix] = alpha
+                ia = 1.0 / alpha
             for c in range(3):
-                out[c][:, iy, ix] = (1.0 - ia) * S[c][:, iy, ix] + ia * (Minv @ rhs[c])
-    return out
+                out[c][:, iy, ix] = (S[c][:, iy, ix] + ia * (Minv @ rhs[c] - S[c][:, iy, ix])) if adaptive else ((1.0 - ia) * S[c][:, iy, ix] + ia * (Minv @ rhs[c]))
+    return (out, alpha_e) if adaptive else out
 
 
-def mevp_velocity(par, hx, hy, dt, S, u, v, u0, v0, tax, tay, uo, vo, cgh, cga):
-    """the momentum update of DESIGN.md section 3.2 at every interior node, v = 0 on the boundary"""
+def mevp_velocity(par, hx, hy, dt, S, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, alpha_e=None):
+    """the momentum update of DESIGN.md section 3.2 at every interior node, v = 0 on the boundary; adaptive form: beta of a node =
+    the largest alpha_e of the elements it belongs to (every element writes its alpha to its nine nodes)"""
     _, ny, nx = S[0].shape
     g, w = gauss_unit(5)
     nn, nm = 2 * nx + 1, 2 * ny + 1
     divx, divy, lump = np.zeros((nm, nn)), np.zeros((nm, nn)), np.zeros((nm, nn))
+    beta_n = np.full((nm, nn), par["beta"])
+    if par.get("aevp_c", 0.0) > 0.0:
+        beta_n[:] = 0.0
+        for iy in range(ny):
+            for ix in range(nx):
+                blk = beta_n[2 * iy:2 * iy + 3, 2 * ix:2 * ix + 3]
+                np.maximum(blk, alpha_e[iy, ix], out=blk)
     for iy in range(ny):
         for ix in range(nx):
             for ay in range(3):
@@ -195,10 +218,11 @@ def mevp_velocity(par, hx, hy, dt, S, u, v, u0, v0, tax, tay, uo, vo, cgh, cga):
             if ice_free(par, cgh[gy, gx], cga[gy, gx]):  # free drift: full exposure, no stress from the neighbours
                 a, fx, fy = 1.0, 0.0, 0.0
             c = a * par["c_ocean"] * par["rho_ocean"] * np.hypot(uo[gy, gx] - u[gy, gx], vo[gy, gx] - v[gy, gx])
-            den = (m / dt) * (1.0 + par["beta"]) + c
-            un[gy, gx] = ((m / dt) * (par["beta"] * u[gy, gx] + u0[gy, gx]) + a * tax[gy, gx] + c * uo[gy, gx]
+            beta = beta_n[gy, gx]
+            den = (m / dt) * (1.0 + beta) + c
+            un[gy, gx] = ((m / dt) * (beta * u[gy, gx] + u0[gy, gx]) + a * tax[gy, gx] + c * uo[gy, gx]
                           + m * par["fc"] * (v[gy, gx] - vo[gy, gx]) + fx) / den
-            vn[gy, gx] = ((m / dt) * (par["beta"] * v[gy, gx] + v0[gy, gx]) + a * tay[gy, gx] + c * vo[gy, gx]
+            vn[gy, gx] = ((m / dt) * (beta * v[gy, gx] + v0[gy, gx]) + a * tay[gy, gx] + c * vo[gy, gx]
                           - m * par["fc"] * (u[gy, gx] - uo[gy, gx]) + fy) / den
     return un, vn
 
@@ -311,6 +335,7 @@ def transport_stage(hx, hy, dt, a, b, phi0, phis, adv):
 # ------------------------------------------------------------------------------------------------ the fixture's case
 PARAMS = dict(rho_ice=900.0, rho_atm=1.3, rho_ocean=1026.0, c_atm=1.2e-3, c_ocean=5.5e-3, pstar=27.5e3, compaction=20.0,
               delta_min=2e-9, fc=1.46e-4, alpha=300.0, beta=300.0, h_min=1e-4, min_conc=1e-12, min_thick=0.01)
+ADAPTIVE = dict(aevp_c=(2.4 * np.pi) ** 2, aevp_alpha_min=8.0)
 CASE = dict(nx=6, ny=5, hx=700.0, hy=900.0, dt=120.0, seed=20261004, rk_a=0.75, rk_b=0.25)
 
 
@@ -366,4 +391,12 @@ def case_outputs(inp=None):
     # the closure of the transport on the case's thickness (bounded below) and concentration (both bounds, capped mean)
     out["H_limited"] = limit(inp["H"], 0.0, np.inf, False)
     out["A_limited"] = limit(inp["A"], 0.0, 1.0, True)
+    # the same sub-iteration with local, solution-adaptive alpha and beta (v3 of the fixture).  The constant is chosen so that the case
+    # has elements at the lower bound, elements far above it and the ice-free centre node of element (3, 2)
+    pa = dict(par, **ADAPTIVE)
+    Sa, alpha_e = mevp_stress(pa, c["hx"], c["hy"], inp["u"], inp["v"], out["pg"], inp["S"], dt=c["dt"], cgh=out["cgh"], cga=out["cga"])
+    out["ad_s11"], out["ad_s12"], out["ad_s22"] = Sa
+    out["ad_alpha"] = alpha_e
+    out["ad_u_new"], out["ad_v_new"] = mevp_velocity(pa, c["hx"], c["hy"], c["dt"], Sa, inp["u"], inp["v"], inp["u0"], inp["v0"], out["tax"],
+                                                     out["tay"], inp["uo"], inp["vo"], out["cgh"], out["cga"], alpha_e=alpha_e)
     return out

@@ -25,7 +25,7 @@ class ColumnParams(C.Structure):
 class MevpParams(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "rho_ice", "rho_atm", "rho_ocean", "c_atm", "c_ocean", "pstar", "compaction", "delta_min", "fc",
-        "alpha", "beta", "h_min", "min_conc", "min_thick")]
+        "alpha", "beta", "h_min", "min_conc", "min_thick", "aevp_c", "aevp_alpha_min")]
 
 
 ALBEDO = {"smu": 0, "smu2": 1, "ccsm": 2}
@@ -73,8 +73,8 @@ def lib(omp=False):
     L.oracle_transport_limit.argtypes = [C.c_int] * 5 + [c_double_p] + [C.c_double] * 2 + [C.c_int]
     L.oracle_dg_to_cg.argtypes = [C.c_int] * 3 + [c_double_p] * 2
     L.oracle_ice_strength.argtypes = [C.c_int] * 4 + [C.POINTER(MevpParams)] + [c_double_p] * 3
-    L.oracle_mevp_stress.argtypes = [C.c_int] * 4 + [C.c_double] * 2 + [C.POINTER(MevpParams)] + [c_double_p] * 6
-    L.oracle_mevp_velocity.argtypes = [C.c_int] * 4 + [C.c_double] * 3 + [C.POINTER(MevpParams)] + [c_double_p] * 15
+    L.oracle_mevp_stress.argtypes = [C.c_int] * 4 + [C.c_double] * 2 + [C.POINTER(MevpParams)] + [c_double_p] * 6 + [C.c_double] + [c_double_p] * 3
+    L.oracle_mevp_velocity.argtypes = [C.c_int] * 4 + [C.c_double] * 3 + [C.POINTER(MevpParams)] + [c_double_p] * 16
     L.oracle_mevp_subcycle.argtypes = [C.c_int] * 2 + [C.c_double] * 3 + [C.c_int, C.POINTER(MevpParams)] + [c_double_p] * 15
     L.oracle_wind_stress.argtypes = [C.c_long, C.POINTER(MevpParams)] + [c_double_p] * 4
     L.oracle_dyn_init()
@@ -157,14 +157,22 @@ def ice_strength(nx, ny, params, H, A, j0=0, j1=None):
     return pg
 
 
-def mevp_stress(nx, ny, k0, k1, hx, hy, params, u, v, pg, s11, s12, s22, omp=False):
-    lib(omp).oracle_mevp_stress(nx, ny, k0, k1, hx, hy, C.byref(params), dp(u), dp(v), dp(pg), dp(s11), dp(s12), dp(s22))
+def mevp_stress(nx, ny, k0, k1, hx, hy, params, u, v, pg, s11, s12, s22, omp=False, dt=0.0, cgh=None, cga=None, alpha_e=None):
+    """adaptive form (params.aevp_c > 0): dt, cgh, cga are needed and alpha_e [ny, nx] receives every element's alpha"""
+    if params.aevp_c > 0 and (cgh is None or cga is None or alpha_e is None or not dt > 0):
+        raise ValueError("the adaptive form needs dt, cgh, cga and alpha_e")
+    null = C.cast(None, c_double_p)
+    lib(omp).oracle_mevp_stress(nx, ny, k0, k1, hx, hy, C.byref(params), dp(u), dp(v), dp(pg), dp(s11), dp(s12), dp(s22), float(dt),
+                                null if cgh is None else dp(cgh), null if cga is None else dp(cga), null if alpha_e is None else dp(alpha_e))
 
 
-def mevp_velocity(nx, ny, j0, j1, hx, hy, dt, params, s, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, omp=False):
+def mevp_velocity(nx, ny, j0, j1, hx, hy, dt, params, s, uv_old, uv_new, u0v0, tau, ocean, cgh, cga, omp=False, alpha_e=None):
+    if params.aevp_c > 0 and alpha_e is None:
+        raise ValueError("the adaptive form needs alpha_e (from mevp_stress)")
     lib(omp).oracle_mevp_velocity(nx, ny, j0, j1, hx, hy, dt, C.byref(params), dp(s[0]), dp(s[1]), dp(s[2]),
                                   dp(uv_old[0]), dp(uv_old[1]), dp(uv_new[0]), dp(uv_new[1]), dp(u0v0[0]), dp(u0v0[1]),
-                                  dp(tau[0]), dp(tau[1]), dp(ocean[0]), dp(ocean[1]), dp(cgh), dp(cga))
+                                  dp(tau[0]), dp(tau[1]), dp(ocean[0]), dp(ocean[1]), dp(cgh), dp(cga),
+                                  C.cast(None, c_double_p) if alpha_e is None else dp(alpha_e))
 
 
 def mevp_subcycle(nx, ny, hx, hy, dt, nsub, params, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, omp=False):

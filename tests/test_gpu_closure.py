@@ -7,7 +7,7 @@
 
 PARITY UNPINNED: the reference snapshot has no dynamics (/root/reference/CMakeLists.txt:43-46) and no cap on the concentration
 either (physics/src/modules/HiblerConcentration.cpp:32-47); the oracle is this repository's own restatement, held on the CPU to
-the independent numpy restatement tests/dyn_independent.py (tests/golden/dyn_independent_v2.npz), which the HIP path meets below.
+the independent numpy restatement tests/dyn_independent.py (tests/golden/dyn_independent_v3.npz), which the HIP path meets below.
 """
 import os
 
@@ -268,11 +268,11 @@ def test_ice_free_nodes_drift_freely_and_match_the_oracle(ctx, variant):
 
 
 def test_hip_closure_matches_the_independent_restatement(ctx):
-    """the closure outputs of tests/golden/dyn_independent_v2.npz (cap + limiter on the case's H and A, and the velocity of ONE
+    """the closure outputs of tests/golden/dyn_independent_v3.npz (cap + limiter on the case's H and A, and the velocity of ONE
     sub-iteration with its ice-free nodes) from the HIP path"""
     import dyn_independent as D
 
-    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v2.npz"))
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v3.npz"))
     c, nx, ny = D.CASE, D.CASE["nx"], D.CASE["ny"]
     ctx.set_grid(nx, ny, c["hx"], c["hy"])
     ctx.set_transport_bounds(abi.H_A_BOUNDS)
@@ -326,8 +326,8 @@ def test_compressible_cover_1024_stays_in_range_for_37_hours(gpu):
     L, dt, nsub, steps = 512e3, 120.0, 120, 1100
     c = abi.Context(gpu)
     bt = synthetic.BoxTest(nx, ny, L)
-    sub = bt.subcycle_parameters(dt)
-    assert sub["alpha"] == 1500.0 and 1.5e-7 < sub["delta_min"] < 2.5e-7 and abs(bt.stable_alpha(dt, delta_min=sub["delta_min"]) - 1500.0) < 1e-6
+    sub = bt.subcycle_parameters(dt, mode="keep_alpha")  # round 5's policy; the adaptive form of round 6: test_compressible_cover_1024_adaptive below
+    assert sub["alpha"] == 1500.0 and sub["aevp_c"] == 0.0 and 1.5e-7 < sub["delta_min"] < 2.5e-7 and abs(bt.stable_alpha(dt, delta_min=sub["delta_min"]) - 1500.0) < 1e-6
     c.set_mevp_params(c.mevp_default_params(**sub))
     core = rowblock.CoupledCore(c, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, gpu, native=True, forcing="winter")
     cs, cf = synthetic.column_fields_smooth(nx, ny, L)

@@ -1035,13 +1035,13 @@ def test_hip_path_matches_the_frozen_oracle_outputs(ctx, variant):
 
 @pytest.mark.parametrize("variant", [1, abi.DEFAULT_MEVP_VARIANT])
 def test_hip_path_matches_the_independent_restatement(ctx, variant):
-    """the HIP path against tests/golden/dyn_independent_v2.npz -- the outputs of the independent dense numpy restatement of
+    """the HIP path against tests/golden/dyn_independent_v3.npz -- the outputs of the independent dense numpy restatement of
     DESIGN.md section 3 (tests/dyn_independent.py), which the oracle is held to on the CPU: ice strength, nodal means, wind
     stress, ONE mEVP sub-iteration and ONE DG2 transport stage on the 6 x 5 case, through the C ABI.  Not reference parity
     (the snapshot has no dynamics code, /root/reference/CMakeLists.txt:43-46): it removes the common mode of oracle and kernels."""
     import dyn_independent as D
 
-    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v2.npz"))
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v3.npz"))
     c, nx, ny = D.CASE, D.CASE["nx"], D.CASE["ny"]
     I = lambda k: np.ascontiguousarray(fix["in_" + k])
     W = lambda k: fix["out_" + k]

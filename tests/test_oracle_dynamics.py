@@ -323,11 +323,14 @@ def test_strengthless_cover_reaches_the_free_drift_of_the_literature():
     assert p.fc > 0 and cross < 0
 
 
-def implicit_vp_case():
-    """a small box whose cover deforms under the wind: inputs of the fixed-point test (shared with the GPU twin)"""
+def implicit_vp_case(adaptive=False):
+    """a small box whose cover deforms under the wind: inputs of the fixed-point test (shared with the GPU twin); adaptive: local,
+    solution-adaptive alpha and beta with the stability bound's own constant (no uniform alpha is stated at all)"""
     nx = ny = 8
     bt = synthetic.BoxTest(nx, ny, 40e3)  # 5 km elements: the stress divergence matters
     pk = dict(alpha=80.0, beta=80.0, delta_min=2e-7)
+    if adaptive:
+        pk = dict(delta_min=2e-7, aevp_c=(2.4 * np.pi) ** 2, aevp_alpha_min=10.0)
     p = O.mevp_params(**pk)
     H, A = bt.dg_fields()
     A[0] -= 0.15  # a cover that deforms under this wind
@@ -365,12 +368,15 @@ def check_implicit_vp_fixed_point(c, u, v, s):
     assert np.max(np.hypot(uf - u, vf - v)) > 1e-2 * scale
 
 
-def test_converged_subcycle_solves_the_implicit_vp_step():
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_converged_subcycle_solves_the_implicit_vp_step(adaptive):
     """What defines mEVP (Bouillon et al. 2013, Kimmritz et al. 2015): the pseudo-time iteration's fixed point is the solution of the
     implicit viscous-plastic step  m (u - u0) / dt = F(u, sigma(u)),  whatever alpha and beta are.  The oracle iterates to convergence;
     the INDEPENDENT restatement then evaluates one Picard sweep of the implicit equation itself (alpha = 1, beta = 0) at that state --
-    it must return the same stress and the same velocity."""
-    c = implicit_vp_case()
+    it must return the same stress and the same velocity.  adaptive (round 6): the same with local, solution-adaptive alpha and beta
+    (Kimmritz et al. 2016) -- the limit does not depend on them, so the SAME check must pass unchanged; the alphas in use at the fixed
+    point differ from element to element."""
+    c = implicit_vp_case(adaptive)
     nx, ny = c["nx"], c["ny"]
     u, v = c["u0"].copy(), c["v0"].copy()
     s = [np.zeros((8, ny, nx)) for _ in range(3)]
@@ -380,6 +386,10 @@ def test_converged_subcycle_solves_the_implicit_vp_step():
     O.mevp_subcycle(nx, ny, c["hx"], c["hy"], c["dt"], 1, c["p"], [x.copy() for x in s], up, vp, *args)
     assert np.max(np.abs(up - u)) < 1e-10 * np.max(np.hypot(u, v))  # converged
     check_implicit_vp_fixed_point(c, u, v, s)
+    if adaptive:
+        al = np.zeros((ny, nx))
+        O.mevp_stress(nx, ny, 0, ny, c["hx"], c["hy"], c["p"], u, v, c["pg"], *[x.copy() for x in s], dt=c["dt"], cgh=c["cgh"], cga=c["cga"], alpha_e=al)
+        assert float(al.min()) >= 10.0 and float(al.max()) > float(al.min()) + 3.0 and float(al.max()) < 80.0, (al.min(), al.max())  # local values, all below the uniform run's 80
 
 
 # ------------------------------------------------------------------------------------ frozen outputs (self-fixture)
@@ -501,13 +511,14 @@ def test_oracle_agrees_with_the_independent_restatement():
     """tests/dyn_independent.py restates DESIGN.md section 3 a second time, in dense numpy, from the formulas only and by
     different routes (zeta / eta form of the VP law, strain from the derivative of the biquadratic instead of the projected
     coefficients, full-mass-matrix projections, weak divergence by quadrature).  Its outputs on a 6 x 5 case are committed
-    (tests/golden/dyn_independent_v2.npz, tools/gen_dyn_independent.py); the oracle must reproduce every one of them --
+    (tests/golden/dyn_independent_v3.npz, tools/gen_dyn_independent.py); the oracle must reproduce every one of them --
     ice strength, nodal means, wind stress, ONE mEVP sub-iteration (stress and velocity, with the ice-free-node rule), advection
-    velocity, ONE DG2 transport stage, the closure of the transport (cap + scaling limiter) on H and A -- to 1e-12.  NOT reference parity: the snapshot has no dynamics code (/root/reference/CMakeLists.txt:43-46).
+    velocity, ONE DG2 transport stage, the closure of the transport (cap + scaling limiter) on H and A, and the same sub-iteration with
+    local, solution-adaptive alpha and beta (round 6: every element's alpha, the stress, the velocity) -- to 1e-12.  NOT reference parity: the snapshot has no dynamics code (/root/reference/CMakeLists.txt:43-46).
     A fresh evaluation of the restatement must equal the committed file (the file is not an opaque blob)."""
     import dyn_independent as D
 
-    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v2.npz"))
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dyn_independent_v3.npz"))
     inp = D.case_inputs()
     for k, v in inp.items():
         v = np.stack(v) if isinstance(v, list) else v
@@ -535,12 +546,25 @@ def test_oracle_agrees_with_the_independent_restatement():
     got["H_limited"], got["A_limited"] = inp["H"].copy(), inp["A"].copy()
     O.transport_limit(nx, ny, 2, got["H_limited"], 0.0, np.inf, False)
     O.transport_limit(nx, ny, 2, got["A_limited"], 0.0, 1.0, True)
+    # the sub-iteration in its adaptive form
+    pa = O.mevp_params(**dict(D.PARAMS, **D.ADAPTIVE))
+    sa = [x.copy() for x in inp["S"]]
+    alpha_e = np.zeros((ny, nx))
+    O.mevp_stress(nx, ny, 0, ny, c["hx"], c["hy"], pa, inp["u"], inp["v"], got["pg"], *sa, dt=c["dt"], cgh=got["cgh"], cga=got["cga"], alpha_e=alpha_e)
+    got["ad_s11"], got["ad_s12"], got["ad_s22"], got["ad_alpha"] = sa[0], sa[1], sa[2], alpha_e
+    una, vna = np.zeros_like(inp["u"]), np.zeros_like(inp["u"])
+    O.mevp_velocity(nx, ny, 0, ny, c["hx"], c["hy"], c["dt"], pa, sa, (inp["u"], inp["v"]), (una, vna), (inp["u0"], inp["v0"]),
+                    (got["tax"], got["tay"]), (inp["uo"], inp["vo"]), got["cgh"], got["cga"], alpha_e=alpha_e)
+    got["ad_u_new"], got["ad_v_new"] = una, vna
     assert sorted(got) == sorted(fresh)
     for k, v in got.items():
         assert rel(v, fix["out_" + k]) < 1e-12, (k, rel(v, fix["out_" + k]))
     # the case exercises the clamps and the floor: concentration above 1 and thickness below 0 at Gauss points, a node thinner than h_min
     assert float(fix["out_cga"].max()) > 1.0 and float(fix["out_cgh"].min()) < D.PARAMS["h_min"] and float(np.abs(fix["out_u_new"]).max()) > 0.05
     assert float((fix["out_pg"] == 0.0).sum()) > 0  # max(h, 0) was active
+    # the adaptive case has elements at the lower bound (among them the one with the ice-free centre node) and elements well above it
+    al = fix["out_ad_alpha"]
+    assert al[2, 3] == D.ADAPTIVE["aevp_alpha_min"] and float(al.max()) > 3 * D.ADAPTIVE["aevp_alpha_min"] and int((al == al.min()).sum()) >= 5
     # ... and the round-5 closure: ice-free nodes exist (and others do not), the cap and both sides of the limiter were active
     free = np.array([[D.ice_free(D.PARAMS, fix["out_cgh"][gy, gx], fix["out_cga"][gy, gx]) for gx in range(2 * nx + 1)] for gy in range(2 * ny + 1)])
     assert 0 < int(free[1:-1, 1:-1].sum()) < free[1:-1, 1:-1].size // 2

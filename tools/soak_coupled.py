@@ -27,21 +27,32 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 720
 nx = ny = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 forcing = sys.argv[3] if len(sys.argv) > 3 else "winter"
 L, dt, nsub = 512e3, float(os.environ.get("NSDG_SOAK_DT", "120")), int(os.environ.get("NSDG_SOAK_NSUB", "120"))  # NSDG_SOAK_DT: model time step (experiments on the strength / concentration coupling); NSDG_SOAK_NSUB: sub-iterations per step (how far the sub-cycle is from converged)
-# NSDG_SOAK_DELTA_MIN: the regularisation of Delta, alpha = beta then follow from the stability bound (2e-9: rounds 1-4); default: the
-# hosts' policy -- alpha = beta = 1500 with the Delta_min the mesh needs for it (synthetic.BoxTest.subcycle_parameters)
+# NSDG_SOAK_SUBCYCLE: how the sub-cycle satisfies its stability bound (synthetic.BoxTest.subcycle_parameters = nsdg_mevp_stable_params):
+# "adaptive" (default, the hosts' policy since round 6: local alpha / beta, Delta_min 2e-9), "keep_alpha" (round 5: alpha = beta = 1500
+# and the Delta_min the mesh needs for it), "keep_delta_min" (rounds 1-4: Delta_min 2e-9 and the alpha of the bound).
+# NSDG_SOAK_DELTA_MIN: another regularisation than 2e-9.  NSDG_AEVP_C / NSDG_AEVP_ALPHA_MIN: the adaptive form's constants.
 delta_min = float(os.environ["NSDG_SOAK_DELTA_MIN"]) if os.environ.get("NSDG_SOAK_DELTA_MIN") else None
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
-sub = bt.subcycle_parameters(dt, delta_min=delta_min)
+sub = bt.subcycle_parameters(dt, mode=os.environ.get("NSDG_SOAK_SUBCYCLE", "adaptive"), delta_min=delta_min)
+if sub["aevp_c"] > 0:
+    sub["aevp_c"] = float(os.environ.get("NSDG_AEVP_C", sub["aevp_c"]))
+    sub["aevp_alpha_min"] = float(os.environ.get("NSDG_AEVP_ALPHA_MIN", sub["aevp_alpha_min"]))
 delta_min = sub["delta_min"]
 alpha = sub["alpha"] * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # NSDG_ALPHA_SCALE: a wider stability margin than the default 2.4 x the bound
 # NSDG_SOAK_CLOSURE: 1 (default) the closure of the product -- ridging cap + scaling limiter in the transport, free drift at ice-free
 # nodes; 0 the bare scheme of rounds 1-4; "transport" / "nodes": only one of the two halves (which one a run needs)
 mode = os.environ.get("NSDG_SOAK_CLOSURE", "1")
 rule = {} if mode in ("1", "nodes") else dict(min_conc=0.0, min_thick=0.0)
-ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha, delta_min=delta_min, **rule))
-print("nsub %d, alpha = beta = %.0f, Delta_min %.1e: the sub-cycle relaxes %.1f %% of the way per model step" % (nsub, alpha, delta_min, 100.0 * min(1.0, nsub / alpha)), flush=True)
+pm = ctx.mevp_default_params(alpha=alpha, beta=alpha, delta_min=delta_min, aevp_c=sub["aevp_c"], aevp_alpha_min=sub["aevp_alpha_min"], **rule)
+ctx.set_mevp_params(pm)
+if sub["aevp_c"] > 0:
+    print("nsub %d, adaptive alpha / beta (c = %.2f, alpha_min = %.0f), Delta_min %.1e (creep below %.3g %% per day)" % (
+        nsub, sub["aevp_c"], sub["aevp_alpha_min"], delta_min, abi.creep_percent_per_day(pm)), flush=True)
+else:
+    print("nsub %d, alpha = beta = %.0f, Delta_min %.1e (creep below %.3g %% per day): the sub-cycle relaxes %.1f %% of the way per model step" % (
+        nsub, alpha, delta_min, abi.creep_percent_per_day(pm), 100.0 * min(1.0, nsub / alpha)), flush=True)
 blk = rowblock.RowBlock(nx, ny, 0, 1)
 core = rowblock.CoupledCore(ctx, blk, L / nx, L / ny, dt, nsub, dev, native=True, forcing=None if forcing == "host" else forcing,
                             closure=mode in ("1", "transport"))

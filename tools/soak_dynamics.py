@@ -13,9 +13,13 @@ L, dt, nsub = 512e3, 120.0, 120
 dev = torch.device("cuda:0")
 ctx = abi.Context(dev)
 bt = synthetic.BoxTest(nx, ny, L)
-sub = bt.subcycle_parameters(dt, delta_min=float(os.environ["NSDG_SOAK_DELTA_MIN"]) if os.environ.get("NSDG_SOAK_DELTA_MIN") else None)
+sub = bt.subcycle_parameters(dt, mode=os.environ.get("NSDG_SOAK_SUBCYCLE", "adaptive"),  # adaptive (the hosts' policy) / keep_alpha (round 5) / keep_delta_min (rounds 1-4)
+                             delta_min=float(os.environ["NSDG_SOAK_DELTA_MIN"]) if os.environ.get("NSDG_SOAK_DELTA_MIN") else None)
 alpha = sub["alpha"] * float(os.environ.get("NSDG_ALPHA_SCALE", "1"))  # experiment: margin over the stability bound
-ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha, delta_min=sub["delta_min"]))
+pm = ctx.mevp_default_params(**dict(sub, alpha=alpha, beta=alpha))
+ctx.set_mevp_params(pm)
+print("sub-cycle: %s, Delta_min %.1e (creep below %.3g %% per day)" % ("adaptive alpha / beta (c = %.2f, alpha_min = %.0f)" % (sub["aevp_c"], sub["aevp_alpha_min"])
+                                                                       if sub["aevp_c"] > 0 else "alpha = beta = %.0f" % alpha, sub["delta_min"], abi.creep_percent_per_day(pm)), flush=True)
 core = rowblock.DynamicsCore(ctx, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, dev, native=True)
 H, A = bt.dg_fields()
 uo, vo = bt.ocean()
