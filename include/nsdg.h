@@ -259,7 +259,10 @@ int nsdg_transport_step_oop_rows(nsdg_ctx* ctx, int32_t order, int32_t j0, int32
 /* Closure of a transport step (see "INPUT DOMAIN AND CLOSURE" above): bounds of the advected fields, in the order in which the
  * step entry points receive them.  nfields = 0 (default): no closure.  Once set, nsdg_transport_step, nsdg_transport_step_oop[_rows]
  * and nsdg_rb_transport_run apply cap + limiter to the new state before they return it (the marching launch in its epilogue, at
- * no extra memory traffic); they then require the same number of fields.  nsdg_transport_stage never limits. */
+ * no extra memory traffic); they then require the same number of fields.  nsdg_transport_stage never limits.
+ * The bounds are STATE OF THE CONTEXT: they apply to every later step call on it, whatever fields that call advances, until they are
+ * set again (nfields = 0 clears them).  A row-block plan can carry its own instead (nsdg_rb_transport_desc.own_bounds), which then
+ * neither reads nor changes the context's. */
 typedef struct {
     double lo, hi; /* bounds at the quadrature points; hi = +infinity (HUGE_VAL): no upper bound */
     int32_t cap_mean; /* != 0: a cell mean above hi is set to hi (needs a finite hi) */
@@ -511,6 +514,12 @@ typedef struct {
     double* t1[NSDG_RB_MAX_FIELDS]; /* same size: stage buffer; receives the new state */
     double* t2[NSDG_RB_MAX_FIELDS]; /* same size: stage buffer */
     const double *vx_dg, *vy_dg, *un_x, *un_y; /* nsdg_prepare_advection output of this step */
+    /* closure of the step (nsdg_field_bounds below "INPUT DOMAIN AND CLOSURE").  own_bounds = 0: whatever nsdg_transport_bounds_set has
+     * stated on the context when the plan RUNS (ABI 5); own_bounds != 0: the plan's own -- nbounds of them (0 = none, or nfields) --
+     * whatever the context says: a context that also steps other fields (a snow layer, a damage field) does not leak its bounds into
+     * this plan, nor this plan's into those calls. */
+    int32_t own_bounds, nbounds;
+    nsdg_field_bounds bounds[NSDG_RB_MAX_FIELDS];
 } nsdg_rb_transport_desc;
 int nsdg_rb_transport_create(nsdg_ctx* ctx, const nsdg_rb_transport_desc* desc, nsdg_rb_transport** out);
 int nsdg_rb_transport_destroy(nsdg_rb_transport* plan);

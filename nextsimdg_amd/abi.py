@@ -71,7 +71,8 @@ class RbMevpDesc(C.Structure):
 class RbTransportDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nx", "ny", "j0", "j1", "depth_below", "depth_above", "rank_below", "rank_above", "order",
                                           "nfields")] + [
-        (n, C.c_void_p * RB_MAX_FIELDS) for n in ("phi", "t1", "t2")] + [(n, C.c_void_p) for n in ("vx_dg", "vy_dg", "un_x", "un_y")]
+        (n, C.c_void_p * RB_MAX_FIELDS) for n in ("phi", "t1", "t2")] + [(n, C.c_void_p) for n in ("vx_dg", "vy_dg", "un_x", "un_y")] + [
+        ("own_bounds", C.c_int32), ("nbounds", C.c_int32), ("bounds", FieldBounds * RB_MAX_FIELDS)]
 
 
 class NsdgError(RuntimeError):
@@ -449,11 +450,17 @@ class Context:
         run.close = close
         return run, per_pass.value, group.value
 
-    def rb_transport(self, blk, peers, phi, t1, t2, adv):
-        """native SSP-RK3 transport driver of a row block; returns run(dt, parity) -> parity of the new state"""
+    def rb_transport(self, blk, peers, phi, t1, t2, adv, bounds=None):
+        """native SSP-RK3 transport driver of a row block; returns run(dt, parity) -> parity of the new state.  bounds: the closure of the
+        step as the plan's OWN (one (lo, hi, cap_mean) per field, () = none), whatever set_transport_bounds says on the context; None:
+        the context's bounds of the moment the plan runs"""
         d = RbTransportDesc()
         self._geometry(d, blk, peers)
         d.order, d.nfields = 2, len(phi)
+        if bounds is not None:
+            d.own_bounds, d.nbounds = 1, len(bounds)
+            for k, (lo, hi, cap) in enumerate(bounds):
+                d.bounds[k].lo, d.bounds[k].hi, d.bounds[k].cap_mean = float(lo), float(hi), int(bool(cap))
         ts = list(phi) + list(t1) + list(t2) + list(adv)
         _check_f64(*ts)
         for i in range(len(phi)):
@@ -494,6 +501,15 @@ class Context:
     @staticmethod
     def private_rows(f, j0, j1):
         return f[j0:j1]
+
+    @staticmethod
+    def private_to_planes(f, nx):
+        """tiled private array -> coefficient planes [nc, ny, nx] (checkpoints, gathers)"""
+        return untile(f, nx)
+
+    @staticmethod
+    def planes_to_private(a):
+        return tile(a)
 
     # ---- column physics
     def column_default_params(self, **kw):

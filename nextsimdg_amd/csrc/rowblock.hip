@@ -513,6 +513,11 @@ int nsdg_rb_transport_create(nsdg_ctx* ctx, const nsdg_rb_transport_desc* desc, 
     for (int f = 0; f < d.nfields; ++f)
         NSDG_CHECK_ARG(d.phi[f] && d.t1[f] && d.t2[f], "null field pointer");
     NSDG_CHECK_ARG(d.vx_dg && d.vy_dg && d.un_x && d.un_y, "null velocity pointer");
+    if (d.own_bounds) {
+        NSDG_CHECK_ARG(d.nbounds == 0 || d.nbounds == d.nfields, "own bounds: none, or one per advected field");
+        for (int f = 0; f < d.nbounds; ++f)
+            NSDG_CHECK_ARG(d.bounds[f].lo <= d.bounds[f].hi, "bounds need lo <= hi (hi = +infinity: no upper bound)");
+    }
     NSDG_CHECK_ARG(!g.multi() || g.depth_above >= 1, "transport needs a ghost row on both interior sides");
     if (g.multi() && !ctx->comm) {
         nsdg_set_error("nsdg_rb_transport_create: a block with neighbours needs nsdg_comm_init* first");
@@ -569,10 +574,31 @@ int nsdg_rb_transport_run(nsdg_ctx* ctx, nsdg_rb_transport* p, double dt, int32_
     NSDG_CHECK_ARG(parity == 0 || parity == 1, "parity must be 0 or 1");
     NSDG_NEED_GRID(ctx);
     NSDG_CHECK_ARG(ctx->nx == p->g.nx && ctx->ny == p->g.ny, "nsdg_grid_set does not match the plan's local array");
-    NSDG_CHECK_ARG(ctx->nbounds == 0 || ctx->nbounds == p->d.nfields,
-        "nsdg_transport_bounds_set was given a different number of fields than this plan advances"); // before anything is advanced
     const Geometry& g = p->g;
     const nsdg_rb_transport_desc& d = p->d;
+    // the closure the step runs with: the plan's own bounds, or the context's of this moment (own_bounds = 0).  The kernels read them from
+    // the context, so a plan with its own swaps them in for the duration of the call
+    struct BoundsSwap {
+        nsdg_ctx* ctx;
+        int n;
+        nsdg_field_bounds b[4];
+        bool on;
+        ~BoundsSwap()
+        {
+            if (on) {
+                ctx->nbounds = n;
+                std::memcpy(ctx->bounds, b, sizeof b);
+            }
+        }
+    } swap { ctx, ctx->nbounds, {}, d.own_bounds != 0 };
+    if (swap.on) {
+        std::memcpy(swap.b, ctx->bounds, sizeof swap.b);
+        ctx->nbounds = d.nbounds;
+        for (int f = 0; f < d.nbounds; ++f)
+            ctx->bounds[f] = d.bounds[f];
+    }
+    NSDG_CHECK_ARG(ctx->nbounds == 0 || ctx->nbounds == p->d.nfields,
+        "the bounds (the plan's own, or nsdg_transport_bounds_set's) were given for a different number of fields than this plan advances"); // before anything is advanced
     double* const* cur = parity == 0 ? d.phi : d.t1; // the state
     double* const* nxt = parity == 0 ? d.t1 : d.phi; // receives the new state (used as stage buffer 1 on the way)
     auto exchange = [&](nsdg_halo* plan) {

@@ -391,10 +391,11 @@ void DynamicsStep::start(const Iterator::TimePoint& startTime)
         t.order = 2, t.nfields = 2;
         t.phi[0] = b.d[H0], t.phi[1] = b.d[A0], t.t1[0] = b.d[H1], t.t1[1] = b.d[A1], t.t2[0] = b.d[T2H], t.t2[1] = b.d[T2A];
         t.vx_dg = b.d[VXDG], t.vy_dg = b.d[VYDG], t.un_x = b.d[UNX], t.un_y = b.d[UNY];
+        // the closure travels with the plan (its own bounds, not the context's): mean thickness H >= 0; concentration in [0, 1] with the
+        // cell mean capped at 1
+        t.own_bounds = 1, t.nbounds = closure ? 2 : 0;
+        t.bounds[0] = nsdg_field_bounds { 0., HUGE_VAL, 0, 0 }, t.bounds[1] = nsdg_field_bounds { 0., 1., 1, 0 };
         check(nsdg_rb_transport_create(b.ctx, &t, &b.transport), "nsdg_rb_transport_create");
-        // bounds of the two advected fields: mean thickness H >= 0; concentration in [0, 1] with the cell mean capped at 1
-        const nsdg_field_bounds bounds[2] = { { 0., HUGE_VAL, 0, 0 }, { 0., 1., 1, 0 } };
-        check(nsdg_transport_bounds_set(b.ctx, closure ? 2 : 0, bounds), "nsdg_transport_bounds_set");
         b.par = b.tpar = 0;
     });
 }

@@ -272,6 +272,9 @@ class DynamicsCore:
         # closure: cap + scaling limiter at the end of every transport step (the ice-free-node rule is a parameter of the
         # sub-cycle, on by default).  False: the bare scheme of rounds 1-4 (frozen fixtures of that scheme)
         self.closure = closure
+        # the native driver's plan carries the bounds itself (nsdg_rb_transport_desc.own_bounds); the Python sequence of step calls reads
+        # them from the context: stated here, put back by close() (they apply to EVERY later step call on the context: include/nsdg.h)
+        self._bounds_before = getattr(ops, "transport_bounds", ())
         ops.set_transport_bounds(self.BOUNDS if closure else ())
         # native: the sub-cycle and the transport of a step are ONE C call each (csrc/rowblock.hip runs the same
         # sequence of passes and exchanges as subcycle() / transport() below); needs the C-ABI ops and, with
@@ -320,7 +323,7 @@ class DynamicsCore:
                                                            self.packed, self.pg)
         assert (per_pass, group) == (self.per_pass, self.group_passes), "native plan and driver disagree on the pass structure"
         self._fbuf, self._tpar = ((self.H, self.A), (self.t1[0], self.t1[1])), 0
-        self._run_transport = self.ops.rb_transport(b, peers, self._fbuf[0], self._fbuf[1], self.t2, self.adv)
+        self._run_transport = self.ops.rb_transport(b, peers, self._fbuf[0], self._fbuf[1], self.t2, self.adv, bounds=self.BOUNDS if self.closure else ())
 
     def close(self):
         """releases the native driver plans (device buffers and events of their ghost exchanges); call it before the
@@ -330,6 +333,9 @@ class DynamicsCore:
             if run is not None and hasattr(run, "close"):
                 run.close()
             setattr(self, name, None)
+        if self._bounds_before is not None:  # the context is as this core found it
+            self.ops.set_transport_bounds(self._bounds_before)
+            self._bounds_before = None
 
     def load_global(self, H, A, uo, vo, ua, va, u=None, v=None):
         """fill the local arrays (ghost rows included) from global numpy arrays"""
@@ -546,6 +552,53 @@ class DynamicsCore:
             return f[:, b.j0:b.j1]
         top = 2 * b.j1 + (1 if b.above is None else 0)
         return f[2 * b.j0:top]
+
+
+    # ---- checkpoint / resume (round 6).  The state a run carries from one step to the next: the DG2 fields H and A, the velocity and the
+    # stress -- what the C++ host writes into its restart file (host/include/RectGrid.hpp: hice, cice, hice_dg, cice_dg, u, v, s11, s12,
+    # s22), which the reference's restart files are the model for (core/src/DevGridIO.cpp:169-201: every prognostic field it has).
+    def state_dict(self):
+        """numpy arrays of the rows this rank OWNS (H, A: [6, rows, nx]; u, v: owned node rows; s11, s12, s22: [8, rows, nx] coefficient
+        planes) and the position of the rows in the global domain: concatenating the ranks' dictionaries along the row axis gives the
+        global state, load_state_dict takes either"""
+        b = self.blk
+        nx = b.nx
+        out = {"rows": (b.r0, b.r1), "ny_global": b.ny_glob, "nx": nx}
+        for name, f in (("H", self.H), ("A", self.A), ("u", self.u), ("v", self.v)):
+            out[name] = self.owned(f).detach().cpu().numpy().copy()
+        for name, f in zip(("s11", "s12", "s22"), self.s):
+            out[name] = self.ops.private_to_planes(f, nx)[:, b.j0:b.j1].detach().cpu().numpy().copy()
+        return out
+
+    def load_state_dict(self, state):
+        """resume from a GLOBAL state (rows (0, ny_global): e.g. the ranks' state_dict()s concatenated): fills the local arrays, ghost rows
+        included, and the current ping-pong buffers; forcing (load_global) and column fields are loaded as for a fresh run"""
+        import numpy as np
+
+        b = self.blk
+        if tuple(state["rows"]) != (0, b.ny_glob) or state["nx"] != b.nx:
+            raise ValueError("load_state_dict needs the state of the whole domain (rows (0, %d)), got rows %s" % (b.ny_glob, (state["rows"],)))
+        es, ns = b.elem_slice(), b.node_slice()
+        put = lambda dst, src: dst.copy_(torch.from_numpy(np.ascontiguousarray(src)).to(dst.device))
+        put(self.H, state["H"][:, es])
+        put(self.A, state["A"][:, es])
+        put(self.u, state["u"][ns])
+        put(self.v, state["v"][ns])
+        for f, name in zip(self.s, ("s11", "s12", "s22")):
+            f.copy_(self.ops.planes_to_private(torch.from_numpy(np.ascontiguousarray(state[name][:, es])).to(f.device)))
+
+    @staticmethod
+    def merge_states(states):
+        """the ranks' state_dict()s (any order) -> the state of the whole domain"""
+        import numpy as np
+
+        states = sorted(states, key=lambda s: s["rows"][0])
+        out = {"rows": (states[0]["rows"][0], states[-1]["rows"][1]), "ny_global": states[0]["ny_global"], "nx": states[0]["nx"]}
+        for k in ("H", "A", "s11", "s12", "s22"):
+            out[k] = np.concatenate([s[k] for s in states], axis=1)
+        for k in ("u", "v"):
+            out[k] = np.concatenate([s[k] for s in states], axis=0)
+        return out
 
 
 class CoupledCore(DynamicsCore):

@@ -16,6 +16,20 @@ class OracleOps:
         self.p = O.mevp_params(**mevp)
         self.cp = O.column_params()
         self.mevp_variant = mevp_variant  # 2: the driver uses mevp_iterate2 (two sub-iterations per pass)
+        self._alpha_e = None
+
+    # adaptive alpha / beta (params.aevp_c > 0): the stress update needs the step's dt and nodal means and leaves every element's alpha
+    # for the velocity update of the same sub-iteration
+    def _ad_stress(self):
+        if not self.p.aevp_c > 0:
+            return {}
+        dt, _, _, _, cgh, cga = self.nodal
+        if self._alpha_e is None or self._alpha_e.shape != (self.ny, self.nx):
+            self._alpha_e = np.zeros((self.ny, self.nx))
+        return dict(dt=dt, cgh=cgh, cga=cga, alpha_e=self._alpha_e)
+
+    def _ad_velocity(self):
+        return dict(alpha_e=self._alpha_e) if self.p.aevp_c > 0 else {}
 
     def column_step(self, dt, state, forcing, newice, diag=None):
         # plane views ([ny, nx] slices of the DG arrays) are contiguous: flatten without copying
@@ -31,6 +45,14 @@ class OracleOps:
     @staticmethod
     def private_rows(f, j0, j1):
         return f[:, j0:j1]
+
+    @staticmethod
+    def private_to_planes(f, nx):
+        return f
+
+    @staticmethod
+    def planes_to_private(a):
+        return a
 
     def set_grid(self, nx, ny, hx, hy):
         self.nx, self.ny, self.hx, self.hy = nx, ny, hx, hy
@@ -62,9 +84,9 @@ class OracleOps:
         for a, b in zip(s_in, s_out):  # the oracle's stress update is in place: seed the output rows
             _np(b)[:, k0:j1] = _np(a)[:, k0:j1]
         so = [_np(x) for x in s_out]
-        O.mevp_stress(self.nx, self.ny, k0, j1, self.hx, self.hy, self.p, _np(uv_old[0]), _np(uv_old[1]), _np(pg), *so)
+        O.mevp_stress(self.nx, self.ny, k0, j1, self.hx, self.hy, self.p, _np(uv_old[0]), _np(uv_old[1]), _np(pg), *so, **self._ad_stress())
         O.mevp_velocity(self.nx, self.ny, j0, j1, self.hx, self.hy, dt, self.p, so, [_np(x) for x in uv_old],
-                        [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga)
+                        [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga, **self._ad_velocity())
 
     def mevp_iterate2(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         """two sub-iterations on the owned rows [j0, j1), reading two rows below / one above, exactly the
@@ -74,14 +96,14 @@ class OracleOps:
         a0, a1 = max(j0 - 2, 0), min(j1, ny - 1)  # rows of sub-iteration p
         sp = [_np(x).copy() for x in s_in]
         uo = [_np(x) for x in uv_old]
-        O.mevp_stress(self.nx, ny, a0, a1 + 1, self.hx, self.hy, self.p, uo[0], uo[1], _np(pg), *sp)
+        O.mevp_stress(self.nx, ny, a0, a1 + 1, self.hx, self.hy, self.p, uo[0], uo[1], _np(pg), *sp, **self._ad_stress())
         up = [x.copy() for x in uo]
-        O.mevp_velocity(self.nx, ny, max(j0 - 1, 0), a1 + 1, self.hx, self.hy, dt, self.p, sp, uo, up, u0v0, tau, ocean, cgh, cga)
-        O.mevp_stress(self.nx, ny, max(j0 - 1, 0), j1, self.hx, self.hy, self.p, up[0], up[1], _np(pg), *sp)
+        O.mevp_velocity(self.nx, ny, max(j0 - 1, 0), a1 + 1, self.hx, self.hy, dt, self.p, sp, uo, up, u0v0, tau, ocean, cgh, cga, **self._ad_velocity())
+        O.mevp_stress(self.nx, ny, max(j0 - 1, 0), j1, self.hx, self.hy, self.p, up[0], up[1], _np(pg), *sp, **self._ad_stress())
         for a, b in zip(sp, s_out):
             _np(b)[:, j0:j1] = a[:, j0:j1]
         O.mevp_velocity(self.nx, ny, j0, j1, self.hx, self.hy, dt, self.p, sp, up, [_np(x) for x in uv_new], u0v0, tau, ocean,
-                        cgh, cga)
+                        cgh, cga, **self._ad_velocity())
 
     def mevp_iterate3(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         """three sub-iterations on the owned rows [j0, j1), reading three rows below / two above, exactly the
@@ -92,16 +114,16 @@ class OracleOps:
         sp = [_np(x).copy() for x in s_in]
         uo = [_np(x) for x in uv_old]
         args = (self.nx, ny)
-        O.mevp_stress(*args, max(j0 - 3, 0), top(j1 + 1), self.hx, self.hy, self.p, uo[0], uo[1], _np(pg), *sp)
+        O.mevp_stress(*args, max(j0 - 3, 0), top(j1 + 1), self.hx, self.hy, self.p, uo[0], uo[1], _np(pg), *sp, **self._ad_stress())
         up = [x.copy() for x in uo]
-        O.mevp_velocity(*args, max(j0 - 2, 0), top(j1 + 1), self.hx, self.hy, dt, self.p, sp, uo, up, u0v0, tau, ocean, cgh, cga)
-        O.mevp_stress(*args, max(j0 - 2, 0), top(j1), self.hx, self.hy, self.p, up[0], up[1], _np(pg), *sp)
+        O.mevp_velocity(*args, max(j0 - 2, 0), top(j1 + 1), self.hx, self.hy, dt, self.p, sp, uo, up, u0v0, tau, ocean, cgh, cga, **self._ad_velocity())
+        O.mevp_stress(*args, max(j0 - 2, 0), top(j1), self.hx, self.hy, self.p, up[0], up[1], _np(pg), *sp, **self._ad_stress())
         up2 = [x.copy() for x in up]
-        O.mevp_velocity(*args, max(j0 - 1, 0), top(j1), self.hx, self.hy, dt, self.p, sp, up, up2, u0v0, tau, ocean, cgh, cga)
-        O.mevp_stress(*args, max(j0 - 1, 0), j1, self.hx, self.hy, self.p, up2[0], up2[1], _np(pg), *sp)
+        O.mevp_velocity(*args, max(j0 - 1, 0), top(j1), self.hx, self.hy, dt, self.p, sp, up, up2, u0v0, tau, ocean, cgh, cga, **self._ad_velocity())
+        O.mevp_stress(*args, max(j0 - 1, 0), j1, self.hx, self.hy, self.p, up2[0], up2[1], _np(pg), *sp, **self._ad_stress())
         for a, b in zip(sp, s_out):
             _np(b)[:, j0:j1] = a[:, j0:j1]
-        O.mevp_velocity(*args, j0, j1, self.hx, self.hy, dt, self.p, sp, up2, [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga)
+        O.mevp_velocity(*args, j0, j1, self.hx, self.hy, dt, self.p, sp, up2, [_np(x) for x in uv_new], u0v0, tau, ocean, cgh, cga, **self._ad_velocity())
 
     def mevp_iterate4(self, j0, j1, s_in, s_out, uv_old, uv_new, packed, pg):
         """four sub-iterations on the owned rows [j0, j1), reading four rows below / three above, exactly the
@@ -117,12 +139,12 @@ class OracleOps:
         for k in range(v):
             last = k == v - 1
             end = j1 if last else top(j1 + (v - 2 - k))
-            O.mevp_stress(*args, max(j0 - (v - k), 0), end, self.hx, self.hy, self.p, u[0], u[1], _np(pg), *sp)
+            O.mevp_stress(*args, max(j0 - (v - k), 0), end, self.hx, self.hy, self.p, u[0], u[1], _np(pg), *sp, **self._ad_stress())
             if last:
                 for a, b in zip(sp, s_out):
                     _np(b)[:, j0:j1] = a[:, j0:j1]
             un = [_np(x) for x in uv_new] if last else [x.copy() for x in u]
-            O.mevp_velocity(*args, max(j0 - (v - 1 - k), 0), end, self.hx, self.hy, dt, self.p, sp, u, un, u0v0, tau, ocean, cgh, cga)
+            O.mevp_velocity(*args, max(j0 - (v - 1 - k), 0), end, self.hx, self.hy, dt, self.p, sp, u, un, u0v0, tau, ocean, cgh, cga, **self._ad_velocity())
             u = un
 
     def prepare_advection(self, order, u, v, vx, vy, unx, uny):

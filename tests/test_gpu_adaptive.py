@@ -201,3 +201,90 @@ def test_adaptive_converged_subcycle_solves_the_implicit_vp_step(ctx):
     ctx.mevp_subcycle(c["dt"], 2500, s, u, v, dev(c["u0"]), dev(c["v0"]), dev(c["tax"]), dev(c["tay"]), dev(c["uo"]), dev(c["vo"]),
                       dev(c["cgh"]), dev(c["cga"]), tdev(c["pg"]), scratch)
     check_implicit_vp_fixed_point(c, host(u), host(v), [thost(x, nx) for x in s])
+
+
+def test_checkpoint_and_resume_on_the_device_is_exact(gpu):
+    """the Python driver's checkpoint (DynamicsCore.state_dict / load_state_dict) with the real kernels and the native row-block driver:
+    4 steps == 2 steps + checkpoint + a FRESH context and core resumed from it + 2 steps, bit for bit -- H and A with their higher DG2
+    coefficients, velocity and stress (tiled on the device, coefficient planes in the checkpoint)"""
+    from nextsimdg_amd import rowblock
+
+    nx, ny, dt, nsub = 150, 96, 120.0, 24
+    bt = synthetic.BoxTest(nx, ny)
+    H, A = bt.dg_fields()
+    A[0] -= 0.1
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+
+    def fresh():
+        c = abi.Context(gpu)
+        c.set_mevp_params(c.mevp_default_params(**bt.subcycle_parameters(dt)))
+        core = rowblock.DynamicsCore(c, rowblock.RowBlock(nx, ny, 0, 1), bt.hx, bt.hy, dt, nsub, gpu, native=True)
+        core.load_global(H, A, uo, vo, 3.0 * ua, 3.0 * va)
+        return c, core
+
+    c0, ref = fresh()
+    for _ in range(4):
+        ref.step()
+    c1, first = fresh()
+    for _ in range(2):
+        first.step()
+    state = rowblock.DynamicsCore.merge_states([first.state_dict()])
+    assert state["H"].shape == (6, ny, nx) and state["s22"].shape == (8, ny, nx) and float(np.abs(state["H"][1:]).max()) > 0 and float(np.abs(state["s11"]).max()) > 0
+    first.close()
+    c1.close()
+    c2, second = fresh()
+    second.load_state_dict(state)
+    for _ in range(2):
+        second.step()
+    torch.cuda.synchronize()
+    for name in ("H", "A", "u", "v"):
+        assert torch.equal(getattr(second, name), getattr(ref, name)), name
+    for a, b in zip(second.s, ref.s):
+        assert torch.equal(a, b)
+    assert float(ref.u.abs().max()) > 1e-4
+    for core, c in ((ref, c0), (second, c2)):
+        core.close()
+        c.close()
+
+
+def test_compressible_cover_1024_at_the_literatures_delta_min(gpu):
+    """The run that left the physical range in rounds 3-5 (profiles/r04_soak_divergence_cause.md, profiles/r05_closure.md): a uniform cover
+    A0 = 0.9, H0 = 0.3 on 1024 x 1024 (500 m), winter forcing, dynamics + column thermodynamics, dt = 120 s, 120 sub-iterations.  With the
+    uniform alpha = beta of the stability bound at the literature's Delta_min = 2e-9 (14 438) it fails between step 1000 and 1100 with or
+    without the closure; round 5 kept alpha = 1500 and raised Delta_min 90-fold instead (tests/test_gpu_closure.py).  With LOCAL, solution-
+    adaptive alpha and beta (round 6, the hosts' default) the run passes that point at Delta_min = 2e-9 itself: 1100 steps = 36.7 model
+    hours here, the full 1600 steps in profiles/r06_soak_1024_A09_adaptive_1600_steps.txt."""
+    from nextsimdg_amd import rowblock
+    from test_gpu_closure import point_values
+
+    nx = ny = 1024
+    L, dt, nsub, steps = 512e3, 120.0, 120, 1100
+    c = abi.Context(gpu)
+    bt = synthetic.BoxTest(nx, ny, L)
+    sub = bt.subcycle_parameters(dt)
+    assert sub["delta_min"] == 2e-9 and sub["aevp_c"] > 50.0
+    c.set_mevp_params(c.mevp_default_params(**sub))
+    core = rowblock.CoupledCore(c, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, gpu, native=True, forcing="winter")
+    cs, cf = synthetic.column_fields_smooth(nx, ny, L)
+    cs = {"hsnow": np.full((ny, nx), 0.05), "tice0": np.full((ny, nx), -8.0)}
+    cf["sst"], cf["sss"] = np.full((ny, nx), -1.76), np.full((ny, nx), 32.0)
+    core.load_column({**cs, **cf})
+    H, A = np.zeros((6, ny, nx)), np.zeros((6, ny, nx))
+    H[0], A[0] = 0.3, 0.9
+    uo, vo = bt.ocean()
+    ua, va = bt.wind(0.0)
+    core.load_global(H, A, uo, vo, ua, va)
+    for step in range(steps):
+        core.device_wind(L, step * dt)
+        core.step()
+    c.synchronize()  # (also the status of the pipeline's bounded waits)
+    for f in (core.u, core.v, core.H, core.A):
+        assert bool(torch.isfinite(f).all())
+    assert 0.01 < float(core.u.abs().max()) < 0.3
+    assert 0.2 < float(core.H[0].min()) and float(core.H[0].max()) < 0.45
+    assert 0.6 < float(core.A[0].min()) and float(core.A[0].max()) <= 1.0
+    vA = point_values(host(core.A[:, ::8, ::8]))
+    assert vA.min() >= -1e-15 and vA.max() <= 1.0 + 1e-15
+    core.close()
+    c.close()

@@ -38,7 +38,7 @@ def column_fields_2d(seed=5):
     return f
 
 
-def run_core(rank, world, overlap=True, coupled=False, variant=1, group=1, nsub=NSUB):
+def run_core(rank, world, overlap=True, coupled=False, variant=1, group=1, nsub=NSUB, steps=NSTEPS, resume=None, adaptive=False):
     from oracle_ops import OracleOps
 
     bt = synthetic.BoxTest(NX, NY)
@@ -51,22 +51,24 @@ def run_core(rank, world, overlap=True, coupled=False, variant=1, group=1, nsub=
     depth = (variant * group, variant * group - 1) if variant >= 2 else (1, 1)  # `group` passes of `variant` sub-iterations between two ghost exchanges
     blk = rowblock.RowBlock(NX, NY, rank, world, *depth)
     cls = rowblock.CoupledCore if coupled else rowblock.DynamicsCore
-    core = cls(OracleOps(mevp_variant=variant, alpha=200.0, beta=200.0), blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cpu"),
-               overlap=overlap)
+    pk = dict(aevp_c=(2.4 * np.pi) ** 2, aevp_alpha_min=3.0, delta_min=2e-7) if adaptive else dict(alpha=200.0, beta=200.0)
+    core = cls(OracleOps(mevp_variant=variant, **pk), blk, bt.hx, bt.hy, 120.0, nsub, torch.device("cpu"), overlap=overlap)
     core.load_global(H, A, uo, vo, 3.0 * ua, 3.0 * va)
     if coupled:
         core.load_column(column_fields_2d())
-    for _ in range(NSTEPS):
+    if resume is not None:  # the state of the whole domain (DynamicsCore.merge_states of the ranks' state_dict()s)
+        core.load_state_dict(resume)
+    for _ in range(steps):
         core.step()
     return core
 
 
-def worker(rank, world, port, outdir, overlap=True, coupled=False, variant=1, group=1, nsub=NSUB):
+def worker(rank, world, port, outdir, overlap=True, coupled=False, variant=1, group=1, nsub=NSUB, adaptive=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        core = run_core(rank, world, overlap, coupled, variant, group, nsub)
+        core = run_core(rank, world, overlap, coupled, variant, group, nsub, adaptive=adaptive)
         if variant >= 2 and world > 1:
             assert core.per_pass == variant and core.group_passes == group
         out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
@@ -78,6 +80,66 @@ def worker(rank, world, port, outdir, overlap=True, coupled=False, variant=1, gr
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def worker_checkpoint(rank, world, port, outdir, variant, adaptive):
+    """half of the steps, checkpoint (every rank's state_dict, gathered and merged), a FRESH core resumed from it, the other half"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        group = 1
+        first = run_core(rank, world, variant=variant, group=group, nsub=9, steps=1, adaptive=adaptive)
+        states = [None] * world
+        dist.all_gather_object(states, first.state_dict())
+        merged = rowblock.DynamicsCore.merge_states(states)
+        assert merged["rows"] == (0, NY) and merged["u"].shape == (2 * NY + 1, 2 * NX + 1) and merged["s12"].shape == (8, NY, NX)
+        dist.barrier()
+        core = run_core(rank, world, variant=variant, group=group, nsub=9, steps=1, resume=merged, adaptive=adaptive)
+        out = {k: core.owned(getattr(core, k)).clone() for k in ("H", "A", "u", "v")}
+        out["s11"] = core.owned(core.s[0]).clone()
+        torch.save(out, os.path.join(outdir, "rank%d.pt" % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,variant,adaptive", [(2, 4, False), (3, 2, True)])
+def test_checkpoint_and_resume_is_exact(world, variant, adaptive, tmp_path):
+    """2 steps == 1 step + checkpoint + resume on fresh cores + 1 step, bit for bit, across ranks (the Python driver's state_dict /
+    load_state_dict: H, A with their higher DG coefficients, the velocity, the stress -- round-5 review: the driver had no checkpoint);
+    adaptive: with local, solution-adaptive alpha and beta, which carry no state of their own from step to step"""
+    ref = run_core(0, 1, variant=variant, nsub=9, steps=2, adaptive=adaptive)
+    assert float(ref.u.abs().max()) > 1e-5
+    port = free_port()
+    mp.spawn(worker_checkpoint, args=(world, port, str(tmp_path), variant, adaptive), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
+        assert torch.equal(torch.cat([p[key] for p in parts], dim=1), full), key
+    for key, full in (("u", ref.u), ("v", ref.v)):
+        assert torch.equal(torch.cat([p[key] for p in parts], dim=0), full), key
+    # a resume from cell means alone (what the hosts wrote before round 6) is NOT the same run
+    lossy = rowblock.DynamicsCore.merge_states([run_core(0, 1, variant=variant, nsub=9, steps=1, adaptive=adaptive).state_dict()])
+    lossy["u"][:] = 0.0
+    lossy["s11"][:] = 0.0
+    other = run_core(0, 1, variant=variant, nsub=9, steps=1, resume=lossy, adaptive=adaptive)
+    assert not torch.equal(other.u, ref.u)
+
+
+@pytest.mark.parametrize("world,variant", [(2, 1), (2, 4)])
+def test_adaptive_row_blocks_equal_single_domain_bitwise(world, variant, tmp_path):
+    """local, solution-adaptive alpha and beta (round 6): an element's alpha depends on its own nodes, a node's beta on its adjacent
+    elements -- the decomposed run still equals the single domain bit for bit"""
+    ref = run_core(0, 1, variant=variant, nsub=9, adaptive=True)
+    uniform = run_core(0, 1, variant=variant, nsub=9)
+    assert float(ref.u.abs().max()) > 1e-5 and not torch.equal(ref.u, uniform.u)
+    port = free_port()
+    mp.spawn(worker, args=(world, port, str(tmp_path), True, False, variant, 1, 9, True), nprocs=world, join=True)
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for key, full in (("H", ref.H), ("A", ref.A), ("s11", ref.s[0])):
+        assert torch.equal(torch.cat([p[key] for p in parts], dim=1), full), key
+    for key, full in (("u", ref.u), ("v", ref.v)):
+        assert torch.equal(torch.cat([p[key] for p in parts], dim=0), full), key
 
 
 def test_rowblock_index_bookkeeping():

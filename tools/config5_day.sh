@@ -2,7 +2,7 @@
 # once as a single block and once as 8 row blocks (threads of one process, in-process transport, one GPU): the two restart
 # files must be identical byte for byte, and the fields finite.  usage: [CICE=1.0] bash tools/config5_day.sh [n=4096] [stop=86400]
 # (rounds 3-4: CICE=0.9 on 4096 x 4096 left the physical range after 22-23 model hours with alpha = beta from the stability bound at
-# Delta_min = 2e-9; since round 5 the host runs alpha = beta = 1500 with the mesh's Delta_min and the closure, and that day completes:
+# Delta_min = 2e-9; round 5 ran alpha = beta = 1500 with the mesh's Delta_min and the closure (--dynamics.subcycle=keep_alpha), round 6 runs local, adaptive alpha and beta at Delta_min = 2e-9 (the default):
 # profiles/r05_closure.md, profiles/r05_config5_one_day_host.txt.  --dynamics.delta_min=2e-9 restores the old configuration)
 set -o pipefail
 N=${1:-4096}; STOP=${2:-86400}
