@@ -37,7 +37,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from nextsimdg_amd import abi, rowblock, synthetic  # noqa: E402
+from nextsimdg_amd import basis, abi, rowblock, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_ELEM_SUBITER = 896  # byte model of ONE mEVP sub-iteration per HBM round trip
@@ -47,8 +47,11 @@ BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
 # fp64 flops of one element-sub-iteration, counted in the ISA of mevp_fused4_kernel (tools/isa_flops.py: 373 v_fma_f64 x 2 + 336
 # v_add / v_mul + 17 v_rcp / v_rsq per lane and march step; min / max / compares / moves count 0); tests/test_bench_launch.py
 # re-counts it when hipcc is present
-FP64_FLOPS_PER_ELEMENT_SUBITER = 1099
-FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER = 373 + 336 + 4 * 17 + 6  # full-rate fp64 instructions + the quarter-rate rcp / rsq as four slots each
+# ISA counts of one march step of mevp_fused4_kernel (tools/isa_flops.py; re-counted by tests/test_bench_launch.py): uniform alpha, beta /
+# the adaptive form (index: adaptive)
+FP64_FLOPS_PER_ELEMENT_SUBITER = {False: 1099, True: 1132}
+FP64_FMA_PER_ELEMENT_SUBITER = {False: 373, True: 379}
+FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER = {False: 373 + 336 + 4 * 17 + 6, True: 379 + 355 + 4 * 19 + 26}  # full-rate fp64 instructions + the quarter-rate rcp / rsq as four slots each
 # v_fma_f64 flat out with ONE wave per SIMD -- this kernel's occupancy -- on an MI355X of this pool: 63.6 TFLOP/s at 2.4 GHz and
 # 1245 W (profiles/r04_fp64_energy_valu_vs_mfma.txt; 70.6 / 73.2 with 2 / 4 waves per SIMD); the arithmetic peak is
 # 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz = 78.6
@@ -158,59 +161,82 @@ def copy_peak_gbs(ctx, device, mib=1024, reps=10):
     return 2.0 * n * 8 / (ms * 1e-3) / 1e9
 
 
-def cpu_baseline(nsub_full, nx, ny, budget_s=12.0):
-    """Time the CPU oracle (the tests' checker; here only as the reported baseline) on a BOUNDED sample of the SAME workload: the
-    nx x ny box test of the bench (capped at 2048 x 2048), as many of the step's mEVP sub-iterations as fit into the budget (at
-    least two) and one DG2 RK3 transport step of H and A, single thread (the reference itself is single-threaded, SURVEY.md
-    section 5); the step's cost is t_step = nsub * t_subiteration + t_transport.  Then the same with the OpenMP build on the
-    host cores the box grants."""
+def cpu_baseline(nsub_full, nx, ny, budget_s=5.0, adaptive=False):
+    """Time the CPU oracle (the tests' checker; here only as the reported baseline) on a BOUNDED sample of the SAME workload, in about
+    `budget_s` seconds (round-5 review: the CPU leg dominated the run and hid the GPU's 0.5 s from the driver's monitor): the bench's own
+    nx x ny box test (capped at 2048 x 2048), a BAND of its element rows in the middle of the domain -- the oracle's entry points take
+    row ranges, every row costs the same arithmetic -- as many mEVP sub-iterations on the band as fit (at least two) and the three
+    Runge-Kutta stages of the DG2 transport of H and A on it, single thread (the reference itself is single-threaded, SURVEY.md section 5);
+    the step's cost per element is t_step = nsub * t_subiteration + t_transport.  Then the same with the OpenMP build on the host cores
+    the box grants.  adaptive: the sub-iterations in the adaptive form of alpha, beta, as the device runs them."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
     cores = set_omp_threads(host_cores())
     nx, ny = min(nx, 2048), min(ny, 2048)
+    ny_full = ny
     bt = synthetic.BoxTest(nx, ny)
-    p = O.mevp_params()
-    H, A = bt.dg_fields()
+    p = O.mevp_params(**({k: v for k, v in bt.subcycle_parameters(120.0).items() if k.startswith("aevp")} if adaptive else {}))
+    # the band, as an array of its own (rows k0 .. k1 of the box test: the same cells, the same fields, evaluated where the band lies;
+    # the oracle treats the band's edges as walls, which costs the same arithmetic)
+    band = min(ny, max(8, (1 << 18) // nx))  # ~0.26 M elements: a sub-iteration takes ~0.15-0.3 s on one core
+    y0 = ((ny - band) // 2) * bt.hy
+    H = basis.project_dg(lambda x, y: bt.H0(x, y + y0), nx, band, bt.L, band * bt.hy, 6, nq=3)
+    A = basis.project_dg(lambda x, y: bt.A0(x, y + y0), nx, band, bt.L, band * bt.hy, 6, nq=3)
+    A[1:] = 0.0
+    X, Y = basis.node_coords(nx, band, bt.L, band * bt.hy)
+    Y = Y + y0
+    uo, vo = np.ascontiguousarray(0.01 * (2 * Y - bt.L) / bt.L), np.ascontiguousarray(0.01 * (bt.L - 2 * X) / bt.L)  # BoxTest.ocean
+    ua, va = np.ascontiguousarray(5.0 + 0 * X), np.ascontiguousarray(-3.0 + 0 * X)  # a wind of the cyclone's strength
+    k0, k1, ny = 0, band, band
     pg = O.ice_strength(nx, ny, p, H, A)
     cgh, cga = O.dg_to_cg(nx, ny, H), O.dg_to_cg(nx, ny, A)
-    uo, vo = [np.ascontiguousarray(a) for a in bt.ocean()]
-    ua, va = [np.ascontiguousarray(a) for a in bt.wind(0.0)]
     tax, tay = O.wind_stress(p, ua, va)
     u, v = np.zeros_like(uo), np.zeros_like(uo)
+    un, vn = np.zeros_like(uo), np.zeros_like(uo)
     s = [np.zeros((8, ny, nx)) for _ in range(3)]
-    n_el = nx * ny
+    alpha_e = np.zeros((ny, nx))
+    n_el = nx * band
+    adv = O.prepare_advection(nx, ny, 2, u, v)
+    # one untimed sub-iteration: first touch of the arrays, the oracle's tables
+    O.mevp_stress(nx, ny, k0, k1, bt.hx, bt.hy, p, u, v, pg, *s, dt=120.0, cgh=cgh, cga=cga, alpha_e=alpha_e)
+    O.mevp_velocity(nx, ny, k0, k1, bt.hx, bt.hy, 120.0, p, s, (u, v), (un, vn), (u, v), (tax, tay), (uo, vo), cgh, cga, alpha_e=alpha_e)
+    u, un, v, vn = un, u, vn, v
     out = {}
     for omp in (False, True):
         try:
             O.lib(omp)
         except Exception:
             continue
-        share = 0.6 if not omp else 0.15  # of the budget: sub-iterations; the transport step comes on top
+        share = 0.45 if not omp else 0.12  # of the budget: sub-iterations; the transport stages come on top
         t0 = time.perf_counter()
         k = 0
         while k < 2 or time.perf_counter() - t0 < budget_s * share:
-            O.mevp_subcycle(nx, ny, bt.hx, bt.hy, 120.0, 1, p, s, u, v, u.copy(), v.copy(), tax, tay, uo, vo, cgh, cga, pg, omp=omp)
+            O.mevp_stress(nx, ny, k0, k1, bt.hx, bt.hy, p, u, v, pg, *s, omp=omp, dt=120.0, cgh=cgh, cga=cga, alpha_e=alpha_e)
+            O.mevp_velocity(nx, ny, k0, k1, bt.hx, bt.hy, 120.0, p, s, (u, v), (un, vn), (u, v), (tax, tay), (uo, vo), cgh, cga, omp=omp, alpha_e=alpha_e)
+            u, un, v, vn = un, u, vn, v
             k += 1
         t_sub = (time.perf_counter() - t0) / (k * n_el)
-        adv = O.prepare_advection(nx, ny, 2, u, v)
         t0 = time.perf_counter()
-        for f in (H.copy(), A.copy()):
-            O.transport_step(nx, ny, bt.hx, bt.hy, 2, 120.0, f, adv, omp=omp)
+        for f in (H, A):  # SSP-RK3: three stages per field
+            t1, t2 = np.zeros_like(f), np.zeros_like(f)
+            O.transport_stage(nx, ny, k0, k1, bt.hx, bt.hy, 2, 120.0, 0.0, 1.0, f, f, t1, adv, omp=omp)
+            O.transport_stage(nx, ny, k0, k1, bt.hx, bt.hy, 2, 120.0, 0.75, 0.25, f, t1, t2, adv, omp=omp)
+            O.transport_stage(nx, ny, k0, k1, bt.hx, bt.hy, 2, 120.0, 1.0 / 3.0, 2.0 / 3.0, f, t2, t1, adv, omp=omp)
         t_tr = (time.perf_counter() - t0) / n_el
         out[omp] = (1.0 / (nsub_full * t_sub + t_tr), 1.0 / t_sub, k)
-    what = "oracle/dyn_oracle.c on the bench's own %dx%d box test: %d of the step's %d mEVP sub-iterations + the DG2 RK3 transport step of H and A, " \
-           "the sub-iteration cost scaled to %d per step (a bounded sample of the same workload, not a smaller grid); own CPU restatement -- the " \
-           "reference snapshot has no dynamics code to time"
+    what = "oracle/dyn_oracle.c on a band of %d element rows in the middle of the bench's own %dx%d box test: %d mEVP sub-iterations%s + the three Runge-Kutta " \
+           "stages of the DG2 transport of H and A on the band, the cost per element scaled to %d sub-iterations per step (a bounded sample of the same " \
+           "workload: every row costs the same arithmetic); own CPU restatement -- the reference snapshot has no dynamics code to time"
     res = {"value": out[False][0], "unit": "element-steps/s", "cores": 1, "kind": "port", "extrapolated": True,
-           "scaled_from_sample": {"subiterations_timed": out[False][2], "subiterations_per_step": nsub_full, "factor": nsub_full / out[False][2],
+           "scaled_from_sample": {"subiterations_timed": out[False][2], "subiterations_per_step": nsub_full, "rows_timed": band, "rows": ny_full,
                                   "how": "value = 1 / (subiterations_per_step x measured seconds per element-sub-iteration + measured seconds per "
-                                         "element of the transport step): every sub-iteration costs the same arithmetic, the grid is the full one"},
-           "sample": what % (nx, ny, out[False][2], nsub_full, nsub_full), "subiters_per_s": out[False][1]}
+                                         "element of the transport step), both measured on the band of rows"},
+           "sample": what % (band, nx, ny_full, out[False][2], " (adaptive alpha, beta)" if adaptive else "", nsub_full), "subiters_per_s": out[False][1]}
     if True in out:
         res["all_cores"] = {"value": out[True][0], "cores": cores, "subiters_per_s": out[True][1], "extrapolated": True,
-                            "scaled_from_sample": {"subiterations_timed": out[True][2], "subiterations_per_step": nsub_full, "factor": nsub_full / out[True][2]},
-                            "sample": "OpenMP build, the same %dx%d sample, %d sub-iterations + the transport step" % (nx, ny, out[True][2])}
+                            "scaled_from_sample": {"subiterations_timed": out[True][2], "subiterations_per_step": nsub_full, "rows_timed": band, "rows": ny_full},
+                            "sample": "OpenMP build, the same band of %d rows of the %dx%d grid, %d sub-iterations + the transport stages" % (band, nx, ny_full, out[True][2])}
     return res
 
 
@@ -604,6 +630,7 @@ def main():
         # sub-cycle, transport), with HIP events on the context's stream around the sub-cycle for the dominant kernel
         where = "timed region"
         ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
+        epoch0 = time.time()  # wall-clock start of the timed region: lets a monitor's samples (rocm-smi) be matched to it
         t0 = time.perf_counter()
         for k in range(args.steps):
             ev[k][0].record(ctx.stream)
@@ -618,6 +645,7 @@ def main():
             ev[k][3].record(ctx.stream)
         sync()
         elapsed = time.perf_counter() - t0
+        epoch1 = time.time()
         where = "reduction over the ranks"
         own_elapsed = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
@@ -683,7 +711,8 @@ def main():
         off = optional("offline_counters", offline_counters, nx, ny, fused_kernel) if eff_world == 1 else None
         copy_peak = optional("copy_peak_gbs", copy_peak_gbs, ctx, device)
         traffic_gbs = (off["traffic"] / (launch_ms * 1e-3) / 1e9) if off else None  # L2 -> fabric bytes per second (Infinity-Cache hits included)
-        flops = own_elems * per_launch * FP64_FLOPS_PER_ELEMENT_SUBITER
+        adaptive = sub["aevp_c"] > 0
+        flops = own_elems * per_launch * FP64_FLOPS_PER_ELEMENT_SUBITER[adaptive]
         tflops = flops / (launch_ms * 1e-3) / 1e12
         roof = {"bound": "fp64-valu/power",
                 "bound_note": "what the counters and the power probe support (DESIGN.md section 5): vector-ALU issue of fp64 arithmetic at the socket's power "
@@ -721,14 +750,14 @@ def main():
                                        "(round 4 called the first figure hbm_physical_frac: renamed)",
                 "fp64_flops_per_launch": flops, "fp64_tflops": tflops,
                 "fp64_flops_model": "%d fp64 flops per element and sub-iteration (ISA count, tools/isa_flops.py: v_fma_f64 = 2) x %d sub-iterations x owned "
-                                    "elements; the lanes and rows recomputed at the edges of a strip are not counted" % (FP64_FLOPS_PER_ELEMENT_SUBITER, per_launch),
+                                    "elements; the lanes and rows recomputed at the edges of a strip are not counted" % (FP64_FLOPS_PER_ELEMENT_SUBITER[adaptive], per_launch),
                 "fp64_valu_ceiling_tflops": FP64_VALU_CEILING_TFLOPS,
                 "frac_fp64_valu": tflops / FP64_VALU_CEILING_TFLOPS,
                 "frac_fp64_valu_note": "against v_fma_f64 flat out at this kernel's occupancy (one wave per SIMD) measured on this pool: 63.6 TFLOP/s at 2.4 GHz, "
                                        "1245 W (profiles/r04_fp64_energy_valu_vs_mfma.txt); arithmetic peak 78.6.  Only %d of the kernel's %d fp64 issue slots "
                                        "per element-sub-iteration are FMAs: a flat-out run of ITS instruction mix would reach %.1f" % (
-                                           373, FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER,
-                                           FP64_VALU_PEAK_TFLOPS * FP64_FLOPS_PER_ELEMENT_SUBITER / (2.0 * FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER)),
+                                           FP64_FMA_PER_ELEMENT_SUBITER[adaptive], FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER[adaptive],
+                                           FP64_VALU_PEAK_TFLOPS * FP64_FLOPS_PER_ELEMENT_SUBITER[adaptive] / (2.0 * FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER[adaptive])),
                 "valu_issue_frac": valu_issue_frac(off["valu_insts"], launch_ms, ctx) if off and off.get("valu_insts") else None}
         line = {
             "metric": "element-steps/sec (dynamics+transport)", "value": None if (loop_world or args.no_guard) else value, "unit": "element-steps/s",
@@ -757,6 +786,8 @@ def main():
                        "parity": "dynamics parity unpinned (the reference snapshot has no DG/mEVP code); self-check of this run: "
                                  + ("fused pass == single sub-iterations bitwise on the live state" if guard else "finite fields")},
             "roofline": roof,
+            "timed_region_epoch": {"start": epoch0, "end": epoch1, "note": "seconds since the Unix epoch on rank 0 around the %d timed steps: the GPU is busy "
+                                   "between them and nowhere else for long (the CPU baseline leg that follows takes ~5 s on the host cores)" % args.steps},
             "mevp_element_subiters_per_s": own_elems * nsub / (cycle_ms * 1e-3),
         }
         if use_dist or loop_world:  # N > 1 (and the one-rank rehearsals, which exercise the same code)
@@ -765,7 +796,7 @@ def main():
             line["rehearsal"] = ("NOT A MEASUREMENT OF THE METRIC: one GPU plays the interior block %d of %d, both neighbours are the rank itself (real "
                                  "RCCL send/recv groups, values wrap around); ms_per_step is this block's share of the step" % (eff_rank, eff_world))
         if eff_world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = optional("cpu_baseline", cpu_baseline, nsub, nx, ny)
+            line["cpu_baseline"] = optional("cpu_baseline", cpu_baseline, nsub, nx, ny, adaptive=sub["aevp_c"] > 0)
         if args.no_guard:
             line["timing_only"] = "--no-guard: NOT A MEASUREMENT OF THE METRIC (value null): the validity checks of the run were skipped (timing experiments with builds that compute on wrong values)"
         if DIAGNOSTICS_FAILED:

@@ -129,9 +129,12 @@ def test_roofline_labels_say_what_was_measured():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import isa_flops
 
-        loops = isa_flops.loops(isa_flops.listing())
-        assert len(loops) == 2
-        for _, ins in loops:  # the stages 1-3 and the loader run the same arithmetic
-            c = isa_flops.flops(ins)
-            assert c["flops"] == bench.FP64_FLOPS_PER_ELEMENT_SUBITER, c
-            assert c["fma"] + c["addmul"] + 4 * c["trans"] + c["other_f64"] == bench.FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER, c
+        text = isa_flops.listing()
+        for adaptive in (False, True):  # uniform alpha, beta / the local, solution-adaptive form (two instantiations of the kernel)
+            loops = isa_flops.loops(text, adaptive)
+            assert len(loops) == 2
+            for _, ins in loops:  # the stages 1-3 and the loader run the same arithmetic
+                c = isa_flops.flops(ins)
+                assert c["flops"] == bench.FP64_FLOPS_PER_ELEMENT_SUBITER[adaptive], c
+                assert c["fma"] == bench.FP64_FMA_PER_ELEMENT_SUBITER[adaptive], c
+                assert c["fma"] + c["addmul"] + 4 * c["trans"] + c["other_f64"] == bench.FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER[adaptive], c

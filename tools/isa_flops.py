@@ -4,8 +4,9 @@ The kernel has two loops: the stages 1-3 (first `Inner Loop Header` of the listi
 instruction between its header label and the backward branch, so wave-uniform side paths (first row of a stage, boundary
 stores) are counted although most steps skip them: they hold no fp64 arithmetic worth mentioning.  v_fma_f64 = 2 flops,
 v_add / v_mul = 1, v_rcp / v_rsq = 1 (they feed Newton steps that are counted as what they are); min / max / compares / moves = 0.
-bench.py's `fp64_flops_per_launch` = the stage-loop figure x 64 lanes x element-sub-iterations: the number is kept in bench.py
-(FP64_FLOPS_PER_ELEMENT_SUBITER) with the hash of the sources it was counted on."""
+bench.py's `fp64_flops_per_launch` = the stage-loop figure x 64 lanes x element-sub-iterations: the numbers are kept in bench.py
+(FP64_FLOPS_PER_ELEMENT_SUBITER, one for the uniform and one for the adaptive form of alpha and beta) and re-counted by
+tests/test_bench_launch.py whenever the compiler is present."""
 import collections
 import os
 import re
@@ -27,10 +28,11 @@ def listing(path=None):
         return open(out).read()
 
 
-def loops(text):
-    """[(header label, [instructions])] of the depth-1 loops of the first kernel of the listing"""
+def loops(text, adaptive=False):
+    """[(header label, [instructions])] of the depth-1 loops of one instantiation of the kernel: uniform alpha / beta (mevp_fused4_kernel<false>)
+    or the adaptive form (<true>)"""
     lines = text.split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*mevp_fused4_kernel\w*:", l))
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*mevp_fused4_kernelILb%dE\w*:" % int(adaptive), l))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     body = lines[start:end]
     heads = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l]
@@ -66,7 +68,10 @@ def flops(ins):
 
 
 if __name__ == "__main__":
-    for label, ins in loops(listing(sys.argv[1] if len(sys.argv) > 1 else None)):
+    text = listing(sys.argv[1] if len(sys.argv) > 1 else None)
+    for adaptive in (False, True):
+      print("mevp_fused4_kernel<%s> (%s alpha, beta)" % (str(adaptive).lower(), "local, solution-adaptive" if adaptive else "uniform"))
+      for label, ins in loops(text, adaptive):
         c = flops(ins)
         print("%-10s %5d instructions, %4d VALU: fma %d, add/mul %d, rcp/rsq %d, other f64 (min/max/cmp/cvt) %d -> %d fp64 flops per lane and march step"
               % (label, len(ins), c["valu"], c["fma"], c["addmul"], c["trans"], c["other_f64"], c["flops"]))
