@@ -240,7 +240,7 @@ def cpu_baseline(nsub_full, nx, ny, budget_s=5.0, adaptive=False):
     return res
 
 
-KERNEL_SOURCES = ("mevp_fused4.hip", "mevp_pipeline.h", "mevp_fused.hip", "mevp_common.h", "transport.hip")
+KERNEL_SOURCES = ("mevp_fused4.hip", "mevp_p2p.h", "mevp_pipeline.h", "mevp_fused.hip", "mevp_common.h", "transport.hip")
 
 
 def kernel_source_hash():

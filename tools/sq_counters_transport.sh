@@ -8,9 +8,9 @@
 # BUILD = default or the name of an alt build under nextsimdg_amd/lib/alt)
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 TAG=$1; N=$2; shift; shift
-cd /tmp && export TMPDIR=/tmp
+. "$ROOT/tools/rocprof_guard.sh"
 PY="$(command -v python3)"
-OUT="$ROOT/gpurun_out/${NSDG_ROUND:-r05}/sqt_$TAG"; rm -rf "$OUT"; mkdir -p "$OUT"
+OUT="$ROOT/gpurun_out/${NSDG_ROUND:-r06}/sqt_$TAG"; rm -rf "$OUT"; mkdir -p "$OUT"
 if [ "$N" != default ]; then export NSDG_LIB="$ROOT/nextsimdg_amd/lib/alt/$N/libnsdg.so"; else unset NSDG_LIB; fi
 i=0; failed=0
 if [ -n "$NSDG_PMC_SETS" ]; then mapfile -t SETS < "$ROOT/$NSDG_PMC_SETS"; else SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
@@ -19,15 +19,13 @@ if [ -n "$NSDG_PMC_SETS" ]; then mapfile -t SETS < "$ROOT/$NSDG_PMC_SETS"; else 
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"); fi
 for set in "${SETS[@]}"; do
   i=$((i+1))
-  case "$set" in *TCP_*|*TA_*|*TD_*) echo "pass $i: refusing a set with TCP / TA / TD counters ($set)"; failed=1; continue;; esac
-  timeout -k 10 180 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -- "$PY" "$ROOT/bench.py" --workload transport --steps 20 --warmup 2 --no-cpu-baseline "$@" > "$OUT/p$i.json" 2> "$OUT/p$i.err" \
-    || { echo "pass $i FAILED (status $?): $(grep -m1 -i 'error code\|Could not' "$OUT/p$i.err")"; tail -3 "$OUT/p$i.err"; failed=1; break; }
+  guarded_rocprof p$i "$OUT" 180 --kernel-trace --pmc $set -- "$PY" "$ROOT/bench.py" --workload transport --steps 20 --warmup 2 --no-cpu-baseline "$@" || { failed=1; break; }
 done
 "$PY" - "$OUT" "$TAG" <<'PYEOF'
 import csv, glob, sys, collections
 d, name = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(list)
-for f in glob.glob(d + "/p*/*/*_counter_collection.csv"):
+for f in glob.glob(d + "/p*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "transport_march" in r["Kernel_Name"] or "transport_fused" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
