@@ -145,14 +145,17 @@ int nsdg_column_step(nsdg_ctx* ctx, int64_t n, double dt, double* hice, double* 
  *   3. ice-free nodes (nsdg_mevp_params.min_conc / min_thick) are in free drift and do not feel their neighbours' stress.
  * 1 and 2 are per-field properties the host states with nsdg_transport_bounds_set (they are OFF until it does: the library does
  * not know which field is a concentration); 3 is ON by default.
- * What the closure does NOT replace is a sub-cycle that can follow the forcing (profiles/r05_closure.md): alpha = beta must satisfy
- * alpha beta >= 2.4^2 pi^2 P* dt / (2 delta_min rho_ice h^2) (linear stability, with the margin a one-day run needs), and with the
+ * What the closure does NOT replace is a sub-cycle that can follow the forcing (profiles/r05_closure.md): a UNIFORM alpha = beta must satisfy
+ * alpha beta >= (2.4 pi)^2 P* dt / (2 delta_min rho_ice h^2) (linear stability, with the margin a one-day run needs), and with the
  * literature's delta_min = 2e-9 on a mesh finer than ~2 km that is an alpha of 10^4 ... 10^5, under which 120 sub-iterations
  * move stress and velocity less than 1 % of the way per model step -- a compressible cover (A < 1) then leaves the physical range
- * within a model day or two with or without the closure.  The hosts of this repository therefore keep alpha = beta = 1500 and
- * raise delta_min to the smallest value for which that is stable on the mesh (DynamicsStep::stableDeltaMin,
- * synthetic.BoxTest.subcycle_parameters): 1.9e-7 / 7.4e-7 / 3.0e-6 1/s at 500 / 250 / 125 m.  With that, a uniform cover A = 0.9
- * completes 53 model hours at 1024 x 1024 and the model day at 4096 x 4096.  The calls do not check any of this; both hosts stop
+ * within a model day or two with or without the closure.  Round 5's hosts kept alpha = beta = 1500 and raised delta_min to the smallest
+ * value for which that is stable on the mesh (1.9e-7 / 7.4e-7 / 3.0e-6 1/s at 500 / 250 / 125 m: a viscosity capped 90 to 1500 times
+ * lower than the literature's).  Since round 6 the hosts run LOCAL, SOLUTION-ADAPTIVE alpha and beta (nsdg_mevp_params.aevp_c) at
+ * delta_min = 2e-9: a uniform cover A = 0.9 then completes 53 model hours at 1024 x 1024 and the model day at 4096 x 4096
+ * (profiles/r06_soak_1024_A09_adaptive_1600_steps.txt, r06_config5_one_day_A09_adaptive_host.txt).  nsdg_mevp_stable_params holds the
+ * rule and its three forms; the defaults of nsdg_mevp_default_params -- uniform alpha = beta = 1500, delta_min = 2e-9 -- are the
+ * literature's and are UNSTABLE below ~2 km: call nsdg_mevp_stable_params.  The calls do not check any of this; both hosts stop
  * loudly on non-finite fields. */
 typedef struct {
     double rho_ice, rho_atm, rho_ocean;
