@@ -51,7 +51,7 @@ def run(world, kpass, nx=GRID, ny=GRID, nsub=NSUB, steps=3, overlap=True, loopba
     ctx = abi.Context(dev)
     L, dt = 512e3, 120.0
     bt = synthetic.BoxTest(nx, ny, L)
-    ctx.set_mevp_params(ctx.mevp_default_params(**bt.subcycle_parameters(dt)))  # the hosts' policy: alpha = beta = 1500 + the mesh's Delta_min
+    ctx.set_mevp_params(ctx.mevp_default_params(**bt.subcycle_parameters(dt, mode=os.environ.get("NSDG_SHARE_SUBCYCLE", "adaptive"))))  # the hosts' policy: adaptive alpha / beta (keep_alpha: round 5)
     if os.environ.get("NSDG_SHARE_VARIANT"):  # A/B of the mEVP kernel variants
         ctx.set_mevp_variant(int(os.environ["NSDG_SHARE_VARIANT"]))
     rank = world // 2
