@@ -194,6 +194,7 @@ for step in range(steps):
         if not fin or float(core.u.abs().max()) > 5.0:
             raise SystemExit("the coupled run left the physical range")
 torch.cuda.synchronize()
+ctx.synchronize()  # also the status of the pipeline's bounded waits: raises if one gave up (the fields would be wrong)
 wall = time.perf_counter() - t0
 print("%d steps of %d x %d (%.1f model hours) in %.1f s wall: %.1f ms per step, %.3g element-steps/s; ice volume change %.3e (thermodynamic growth)"
       % (steps, nx, ny, steps * dt / 3600.0, wall, 1e3 * wall / steps, nx * ny * steps / wall, float(core.H[0].sum()) / m0 - 1.0))

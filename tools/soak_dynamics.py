@@ -37,3 +37,4 @@ for step in range(720):
             float(core.A[0].max()), float(core.H[0].sum()) / m0 - 1.0), flush=True)
         if not ok:
             break
+ctx.synchronize()  # also the status of the pipeline's bounded waits: raises if one gave up (the fields would be wrong)
