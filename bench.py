@@ -49,9 +49,9 @@ BYTES_TRANSPORT = 1008  # DG2, 2 fields, RK3
 # re-counts it when hipcc is present
 # ISA counts of one march step of mevp_fused4_kernel (tools/isa_flops.py; re-counted by tests/test_bench_launch.py): uniform alpha, beta /
 # the adaptive form (index: adaptive)
-FP64_FLOPS_PER_ELEMENT_SUBITER = {False: 1099, True: 1132}
+FP64_FLOPS_PER_ELEMENT_SUBITER = {False: 1099, True: 1133}
 FP64_FMA_PER_ELEMENT_SUBITER = {False: 373, True: 379}
-FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER = {False: 373 + 336 + 4 * 17 + 6, True: 379 + 355 + 4 * 19 + 26}  # full-rate fp64 instructions + the quarter-rate rcp / rsq as four slots each
+FP64_ISSUE_SLOTS_PER_ELEMENT_SUBITER = {False: 373 + 336 + 4 * 17 + 6, True: 379 + 356 + 4 * 19 + 32}  # full-rate fp64 instructions + the quarter-rate rcp / rsq as four slots each
 # v_fma_f64 flat out with ONE wave per SIMD -- this kernel's occupancy -- on an MI355X of this pool: 63.6 TFLOP/s at 2.4 GHz and
 # 1245 W (profiles/r04_fp64_energy_valu_vs_mfma.txt; 70.6 / 73.2 with 2 / 4 waves per SIMD); the arithmetic peak is
 # 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz = 78.6

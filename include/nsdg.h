@@ -178,7 +178,8 @@ typedef struct {
      *     alpha_e = sqrt(max(aevp_alpha_min^2, aevp_c zeta_e dt / (rho_ice h'_c hx hy))),
      * h'_c = max(nodal mean thickness at the element's centre node, h_min) (alpha_e = aevp_alpha_min where that node is ice-free), the
      * stress relaxes with 1 / alpha_e, and every node takes beta_n = the largest alpha_e of its adjacent elements.  aevp_c is the
-     * stability bound's constant: (2.4 pi)^2 = 56.85 is the bound DESIGN.md section 3.4 states with its margin.  Where the ice
+     * stability bound's constant: (2.4 pi)^2 = 56.85 is the bound DESIGN.md section 3.4 states with its margin; aevp_alpha_min must not be
+     * chosen small on a fine mesh (nsdg_mevp_stable_params sets both).  Where the ice
      * deforms alpha is small and the stress follows the strain rate within a few sub-iterations, where it is rigid alpha is what the
      * uniform form needs everywhere; the converged sub-cycle solves the same implicit step.  aevp_c = 0 (the default of
      * nsdg_mevp_default_params): uniform alpha, beta -- bit-identical to ABI 5.  The adaptive form exists in the marching kernels
@@ -193,13 +194,23 @@ int nsdg_mevp_params_set(nsdg_ctx* ctx, const nsdg_mevp_params* p);
  * for a model time step dt the sub-cycle is linearly stable where  alpha beta >= (2.4 pi)^2 zeta dt / (m h^2)  (2.4: the margin a
  * one-day run needs, profiles/r02_alpha_margin.txt), zeta / m <= pstar / (2 delta_min rho_ice).  Three ways to satisfy it, chosen by
  * `mode`; the other members of *p are read (pstar, rho_ice, and what the mode keeps) and left alone:
- *   NSDG_SUBCYCLE_ADAPTIVE       aevp_c = (2.4 pi)^2, aevp_alpha_min = 50: alpha_e, beta_n follow the local viscosity of every
- *                                sub-iteration; delta_min stays (the literature's 2e-9 by default).  The hosts' default since round 6.
+ *   NSDG_SUBCYCLE_ADAPTIVE       aevp_c = (2.4 pi)^2: alpha_e, beta_n follow the local viscosity of every sub-iteration; delta_min stays (the
+ *                                literature's 2e-9 by default); aevp_alpha_min = 50, the constant Kimmritz et al. (2016) publish.  The
+ *                                hosts' default since round 6.  On meshes finer than 1 km every deforming element then sits AT its
+ *                                stability limit and 120 sub-iterations do not converge: the velocity is noisy at element scale
+ *                                (profiles/r06_adaptive_noise.md) -- the runs complete, the noise acts as a viscosity.
+ *   NSDG_SUBCYCLE_ADAPTIVE_CONVERGED  the same with aevp_alpha_min = the bound's alpha for the reference strain rate NSDG_AEVP_DELTA_REF
+ *                                (500 / 1000 / 2000 at 500 / 250 / 125 m, dt = 120 s; never below 50): the sub-cycle converges (0.1 % /
+ *                                2 % of the maximum speed left after 120 sub-iterations at 1024^2 / 2048^2).  A converged plastic
+ *                                solution exposes the time-step limit of the explicit strength / transport splitting (Lipscomb et al.
+ *                                2007): dt = 120 s is too long for it at 250 m and below (2048^2 leaves the physical range after 11 model
+ *                                hours, with dt = 60 s or 30 s it does not: profiles/r06_adaptive_noise.md) -- choose dt with the mesh.
  *   NSDG_SUBCYCLE_KEEP_ALPHA     uniform alpha = beta = p->alpha; delta_min is raised to the smallest value for which that is stable
  *                                (never lowered): the viscosity is capped -- below a strain rate of delta_min the ice creeps
  *                                (nsdg_mevp_creep_percent_per_day).  The hosts' default of round 5.
  *   NSDG_SUBCYCLE_KEEP_DELTA_MIN uniform alpha = beta = the bound's value for p->delta_min (at least 1500): rounds 1-4. */
-enum { NSDG_SUBCYCLE_ADAPTIVE = 0, NSDG_SUBCYCLE_KEEP_ALPHA = 1, NSDG_SUBCYCLE_KEEP_DELTA_MIN = 2 };
+enum { NSDG_SUBCYCLE_ADAPTIVE = 0, NSDG_SUBCYCLE_KEEP_ALPHA = 1, NSDG_SUBCYCLE_KEEP_DELTA_MIN = 2, NSDG_SUBCYCLE_ADAPTIVE_CONVERGED = 3 };
+#define NSDG_AEVP_DELTA_REF 1.67e-6 /* 1/s: 14 % per day */
 int nsdg_mevp_stable_params(nsdg_mevp_params* p, int32_t mode, double h, double dt);
 /* strain rate below which the ice creeps instead of staying rigid (= delta_min), in percent per day */
 double nsdg_mevp_creep_percent_per_day(const nsdg_mevp_params* p);

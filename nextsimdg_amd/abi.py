@@ -34,7 +34,7 @@ class MevpParams(C.Structure):
         "alpha", "beta", "h_min", "min_conc", "min_thick", "aevp_c", "aevp_alpha_min")]
 
 
-SUBCYCLE_ADAPTIVE, SUBCYCLE_KEEP_ALPHA, SUBCYCLE_KEEP_DELTA_MIN = 0, 1, 2  # modes of nsdg_mevp_stable_params
+SUBCYCLE_ADAPTIVE, SUBCYCLE_KEEP_ALPHA, SUBCYCLE_KEEP_DELTA_MIN, SUBCYCLE_ADAPTIVE_CONVERGED = 0, 1, 2, 3  # modes of nsdg_mevp_stable_params
 
 
 class FieldBounds(C.Structure):
@@ -186,7 +186,7 @@ TILE = 64
 
 def stable_mevp_params(p, mode, h, dt):
     """nsdg_mevp_stable_params: the sub-cycle's stability rule (one copy, in the library) applied to the MevpParams `p` in place for cells
-    of size h and a model time step dt; mode = SUBCYCLE_ADAPTIVE / SUBCYCLE_KEEP_ALPHA / SUBCYCLE_KEEP_DELTA_MIN"""
+    of size h and a model time step dt; mode = SUBCYCLE_ADAPTIVE / SUBCYCLE_ADAPTIVE_CONVERGED / SUBCYCLE_KEEP_ALPHA / SUBCYCLE_KEEP_DELTA_MIN"""
     rc = load_library().nsdg_mevp_stable_params(C.byref(p), int(mode), float(h), float(dt))
     if rc != 0:
         raise NsdgError("nsdg error %d: %s" % (rc, load_library().nsdg_last_error().decode()))

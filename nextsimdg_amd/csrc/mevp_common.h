@@ -433,16 +433,19 @@ __device__ __forceinline__ void stress_update(const double (&ul)[9], const doubl
 //     zeta_e = max_q P_q / (2 Delta_q),   alpha_e = sqrt(max(alpha_min^2, c zeta_e dt / (rho_i h'_c |K|))),
 // h'_c = the mass-floor-limited nodal mean thickness at the element's centre node (the packed coefficient [0] of that node: an
 // ice-free centre node stores it scaled by 2^100, which gives alpha_min exactly as the oracle's rule states it), and every node takes
-// beta_n = the largest alpha of its adjacent elements.  Where the ice deforms alpha is small and the stress follows the strain rate
+//     beta_n = max(alpha_min, max over its adjacent elements of alpha_e h'_c(e) / h'_n)     (alpha_min at an ice-free node):
+// alpha_e scaled by the ratio of the element's mass to the node's, so that alpha_e beta_n meets the stability bound of EVERY element-node
+// pair -- a light node beside a strong element (the edge of a lead) is what ran away without it (profiles/r06_adaptive_noise.md).  The
+// kernels never divide: an element offers q_e = alpha_e h'_c, the node update needs only beta_n h'_n = max(alpha_min h'_n, max q_e).  Where the ice deforms alpha is small and the stress follows the strain rate
 // within a few sub-iterations; where it is rigid alpha is the old global value and the ice stays rigid.  Same limit as the uniform form.
 struct AdaptConsts {
     double G; // c dt / (rho_i |K|)
-    double amin2; // alpha_min^2
+    double amin2, amin; // alpha_min^2, alpha_min
 };
 
-// (1 / alpha_e) Proj sigma(v) of one element and the element's alpha and 1 / alpha
+// (1 / alpha_e) Proj sigma(v) of one element, 1 / alpha_e, and what the element offers its nine nodes: q_e = alpha_e h'_c
 __device__ __forceinline__ void stress_projected_adaptive(const double (&ul)[9], const double (&vl)[9], const double (&P)[9], double ihx,
-    double ihy, double dmin2, double hc, const AdaptConsts& AC, double (&r11)[8], double (&r12)[8], double (&r22)[8], double& alpha, double& ialpha)
+    double ihy, double dmin2, double hc, const AdaptConsts& AC, double (&r11)[8], double (&r12)[8], double (&r22)[8], double& q, double& ialpha)
 {
     double E11[8], E12[8], E22[8];
     {
@@ -477,7 +480,7 @@ __device__ __forceinline__ void stress_projected_adaptive(const double (&ul)[9],
     }
     const double a2 = __builtin_fmax(AC.amin2, (AC.G * zmax) * fast_rcp(hc));
     ialpha = fast_rsqrt(a2);
-    alpha = a2 * ialpha;
+    q = (a2 * ialpha) * (hc > 0x1p50 ? hc * 0x1p-100 : hc); // alpha_e times the centre node's h' (stored scaled by 2^100 where that node is ice-free)
     const ProjScale F = proj_scale(ialpha); // 1 / alpha_e rides on the projection's constants
     sf_project_scaled(t11, F, r11);
     sf_project_scaled(t12, F, r12);
@@ -591,15 +594,16 @@ __device__ __forceinline__ void node_update_packed(const NodalConsts& K, const d
     vn = denom * (c1 * vv + c[3] + drag * c[5] - cor * uu + divy * ilumped);
 }
 
-// the same with the node's own beta (adaptive form)
+// the same with the node's own beta (adaptive form): qmax = the largest offer alpha_e h'_c of the adjacent elements, beta_n h'_n = max(alpha_min
+// h'_n, qmax) -- at an ice-free node c[0] is h'_n scaled by 2^100 and the first argument wins: beta_n = alpha_min
 __device__ __forceinline__ void node_update_packed_adaptive(const NodalConsts& K, const double (&c)[6], double uu, double vv, double divx,
-    double divy, double ilumped, double beta, double& un, double& vn)
+    double divy, double ilumped, double qmax, double amin, double& un, double& vn)
 {
     const double du = c[4] - uu, dv = c[5] - vv;
     const double drag = c[1] * fast_sqrt(du * du + dv * dv);
-    const double rb = K.rdt * beta;
-    const double denom = fast_rcp((rb + K.rdt) * c[0] + drag);
-    const double c1 = rb * c[0], cor = K.k3 * c[0];
+    const double bh = __builtin_fmax(amin * c[0], qmax); // beta_n h'_n
+    const double denom = fast_rcp(__builtin_fma(K.rdt, bh + c[0], drag));
+    const double c1 = K.rdt * bh, cor = K.k3 * c[0];
     un = denom * (c1 * uu + c[2] + drag * c[4] + cor * vv + divx * ilumped);
     vn = denom * (c1 * vv + c[3] + drag * c[5] - cor * uu + divy * ilumped);
 }
@@ -614,7 +618,7 @@ static inline bool nsdg_adaptive(const nsdg_ctx* ctx) { return ctx->mevp.aevp_c 
 static inline AdaptConsts nsdg_adapt_consts(const nsdg_ctx* ctx)
 {
     const nsdg_mevp_params& P = ctx->mevp;
-    return AdaptConsts { P.aevp_c * ctx->pack_dt / (P.rho_ice * ctx->hx * ctx->hy), P.aevp_alpha_min * P.aevp_alpha_min };
+    return AdaptConsts { P.aevp_c * ctx->pack_dt / (P.rho_ice * ctx->hx * ctx->hy), P.aevp_alpha_min * P.aevp_alpha_min, P.aevp_alpha_min };
 }
 
 // plane = nodal_plane(number of nodes of the local array)

@@ -174,7 +174,7 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     NSDG_PHASE(0); // inputs of the row (stages >= 1: the wait for the previous stage, LDS reads)
     // ------------------------------------------------------------------------------------------ stress update
     double r11[8], r12[8], r22[8];
-    double alpha = 0., ialpha = M.ialpha; // adaptive form: this element's alpha of this sub-iteration (the centre node's h' is coefficient [0] of node 3)
+    double alpha = 0., ialpha = M.ialpha; // adaptive form: this element's offer q_e = alpha_e h'_c of this sub-iteration (the centre node's h' is coefficient [0] of node 3)
     if constexpr (AD)
         stress_projected_adaptive(ul, vl, f.P, M.ihx, M.ihy, M.dmin2, f.c[3][0], M.AC, r11, r12, r22, alpha, ialpha);
     else

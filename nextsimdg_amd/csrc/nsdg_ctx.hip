@@ -89,9 +89,19 @@ int nsdg_mevp_stable_params(nsdg_mevp_params* p, int32_t mode, double h, double 
     // alpha beta >= c zeta dt / (m h^2) with c = (margin pi)^2 and zeta / m <= pstar / (2 delta_min rho_ice)
     const double c = margin * margin * pi * pi;
     switch (mode) {
-    case NSDG_SUBCYCLE_ADAPTIVE:
+    case NSDG_SUBCYCLE_ADAPTIVE: // the published constant
         p->aevp_c = c;
         p->aevp_alpha_min = 50.;
+        return NSDG_OK;
+    case NSDG_SUBCYCLE_ADAPTIVE_CONVERGED:
+        // The lower bound of alpha_e = the uniform bound's alpha for a reference strain rate of active deformation (NSDG_AEVP_DELTA_REF,
+        // 1.67e-6 1/s = 14 % per day): 500 / 1000 / 2000 at 500 / 250 / 125 m with dt = 120 s, never below 50.  Measured
+        // (profiles/r06_adaptive_noise.md): with 50 every deforming element sits AT its stability limit and the iteration is noisy at
+        // element scale on meshes finer than 1 km (a tenth of the nodes change by > 1 mm/s per model step, the largest by a third of the
+        // maximum speed); from this floor on the same momentum problem converges to a steady state -- and the coupled model then needs
+        // a time step that fits the mesh (include/nsdg.h).
+        p->aevp_c = c;
+        p->aevp_alpha_min = std::max(50., std::sqrt(c * p->pstar * dt / (2. * NSDG_AEVP_DELTA_REF * p->rho_ice * h * h)));
         return NSDG_OK;
     case NSDG_SUBCYCLE_KEEP_ALPHA:
         NSDG_CHECK_ARG(p->alpha > 0, "alpha must be positive");

@@ -20,7 +20,9 @@
 //     dynamics.domain_size   side of the square box in m        (512e3)
 //     dynamics.nsub          mEVP sub-iterations per step        (120)
 //     dynamics.subcycle      how the sub-cycle satisfies its stability bound (nsdg_mevp_stable_params, include/nsdg.h): adaptive (default
-//                            since round 6: local, solution-adaptive alpha and beta at the literature's Delta_min) | keep_alpha (round 5:
+//                            since round 6: local, solution-adaptive alpha and beta at the literature's Delta_min, alpha_min = 50) |
+//                            adaptive_converged (alpha_min from the mesh so that the sub-cycle converges; wants a time step that fits
+//                            the mesh) | keep_alpha (round 5:
 //                            uniform alpha = beta = dynamics.alpha or 1500, Delta_min raised to what the mesh needs for it) |
 //                            keep_delta_min (rounds 1-4: uniform alpha = beta from the bound for dynamics.delta_min or 2e-9)
 //     dynamics.alpha/.beta   uniform mEVP parameters (keep_alpha; 0 = 1500, the BASELINE's value); given WITHOUT dynamics.subcycle they

@@ -122,7 +122,7 @@ DynamicsStep::~DynamicsStep() { release(); }
 void DynamicsStep::release() { m_blocks.clear(); }
 
 DynamicsStep::SubcycleChoice DynamicsStep::subcycleChoice(double h, double dt) const
-{ // the stability rule lives in the library (nsdg_mevp_stable_params): the host only says which of its three forms it wants
+{ // the stability rule lives in the library (nsdg_mevp_stable_params): the host only says which of its forms it wants
     nsdg_mevp_params p;
     nsdg_mevp_default_params(&p);
     if (deltaMin > 0)
@@ -136,7 +136,7 @@ DynamicsStep::SubcycleChoice DynamicsStep::subcycleChoice(double h, double dt) c
     } else if (mode == "keep_delta_min")
         check(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_KEEP_DELTA_MIN, h, dt), "nsdg_mevp_stable_params");
     else
-        check(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_ADAPTIVE, h, dt), "nsdg_mevp_stable_params");
+        check(nsdg_mevp_stable_params(&p, mode == "adaptive_converged" ? NSDG_SUBCYCLE_ADAPTIVE_CONVERGED : NSDG_SUBCYCLE_ADAPTIVE, h, dt), "nsdg_mevp_stable_params");
     return SubcycleChoice { mode, p.alpha, p.beta, p.delta_min, p.aevp_c, p.aevp_alpha_min, nsdg_mevp_creep_percent_per_day(&p) };
 }
 
@@ -170,8 +170,8 @@ void DynamicsStep::configure()
     // alpha (then keep_alpha: round 5) or says otherwise
     deltaMin = getConfiguration(keyMap.at(15), 0.);
     subcycle = getConfiguration(keyMap.at(16), std::string(alpha > 0 ? "keep_alpha" : "adaptive"));
-    if (subcycle != "adaptive" && subcycle != "keep_alpha" && subcycle != "keep_delta_min")
-        throw std::invalid_argument("dynamics.subcycle must be adaptive, keep_alpha or keep_delta_min");
+    if (subcycle != "adaptive" && subcycle != "adaptive_converged" && subcycle != "keep_alpha" && subcycle != "keep_delta_min")
+        throw std::invalid_argument("dynamics.subcycle must be adaptive, adaptive_converged, keep_alpha or keep_delta_min");
     if (rowBlocks < 1 || passesPerExchange < 1 || nsub < 0)
         throw std::invalid_argument("dynamics.row_blocks and dynamics.passes_per_exchange must be >= 1, dynamics.nsub >= 0");
     if (forcing != "host" && forcing != "dummy" && forcing != "winter")

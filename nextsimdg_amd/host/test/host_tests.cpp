@@ -379,12 +379,22 @@ static void test_subcycle_policy()
     p = fresh();
     CHECK(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_ADAPTIVE, 250., 120.) == NSDG_OK && approx(p.aevp_c, 2.4 * 2.4 * 9.869604401089358, 1e-12)
         && p.aevp_alpha_min == 50. && p.delta_min == 2e-9); // the hosts' default: local alpha / beta at the literature's Delta_min
+    p = fresh();
+    CHECK(nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_ADAPTIVE_CONVERGED, 500., 120.) == NSDG_OK && p.aevp_c > 56. && p.delta_min == 2e-9);
+    CHECK(approx(p.aevp_alpha_min, 500., 1e-2)); // the converging form's floor = the bound's alpha at NSDG_AEVP_DELTA_REF: 500 / 1000 / 2000 at 500 / 250 / 125 m ...
+    nsdg_mevp_stable_params(&p, NSDG_SUBCYCLE_ADAPTIVE_CONVERGED, 8000., 120.);
+    CHECK(p.aevp_alpha_min == 50.); // ... and never below the literature's 50
     CHECK(nsdg_mevp_stable_params(&p, 9, 250., 120.) == NSDG_ERR_ARG && nsdg_mevp_stable_params(nullptr, 0, 250., 120.) == NSDG_ERR_ARG);
     // the host's configuration keys choose among the three
     Configurator::clear();
     DynamicsStep d0;
     d0.configure();
-    CHECK(d0.subcycleChoice(250., 120.).mode == "adaptive" && d0.subcycleChoice(250., 120.).aevpC > 50.);
+    CHECK(d0.subcycleChoice(250., 120.).mode == "adaptive" && d0.subcycleChoice(250., 120.).aevpC > 50. && d0.subcycleChoice(250., 120.).aevpAlphaMin == 50.);
+    addConfig("[dynamics]\nsubcycle = adaptive_converged\n");
+    DynamicsStep d4;
+    d4.configure();
+    CHECK(d4.subcycleChoice(250., 120.).aevpC > 50. && approx(d4.subcycleChoice(250., 120.).aevpAlphaMin, 1000., 1e-2));
+    Configurator::clear();
     addConfig("[dynamics]\nalpha = 1500\n");
     DynamicsStep d1;
     d1.configure();

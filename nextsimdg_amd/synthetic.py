@@ -90,19 +90,22 @@ class BoxTest:
     def subcycle_parameters(self, dt, mode="adaptive", alpha=1500.0, delta_min=None):
         """keyword arguments for Context.mevp_default_params, as the hosts set the sub-cycle:
         "adaptive" (default since round 6): local, solution-adaptive alpha and beta with the stability bound's own constant, Delta_min
-        the literature's 2e-9 (or `delta_min`); "keep_alpha" (round 5): uniform alpha = beta = `alpha`, Delta_min raised to what the mesh
+        the literature's 2e-9 (or `delta_min`), alpha_min = 50; "adaptive_converged": the same with the lower bound of alpha that lets 120
+        sub-iterations converge on the mesh (include/nsdg.h: needs a time step that fits the mesh); "keep_alpha" (round 5): uniform alpha = beta = `alpha`, Delta_min raised to what the mesh
         needs for it; "keep_delta_min" (rounds 1-4): uniform alpha = beta from the bound for `delta_min` (2e-9)"""
         from . import abi
 
         dm = 2e-9 if delta_min is None else float(delta_min)
         if mode == "adaptive":
             p = self._stable(abi.SUBCYCLE_ADAPTIVE, dt, delta_min=dm)
+        elif mode == "adaptive_converged":
+            p = self._stable(abi.SUBCYCLE_ADAPTIVE_CONVERGED, dt, delta_min=dm)
         elif mode == "keep_alpha":
             p = self._stable(abi.SUBCYCLE_KEEP_ALPHA, dt, alpha=alpha, delta_min=dm)
         elif mode == "keep_delta_min":
             p = self._stable(abi.SUBCYCLE_KEEP_DELTA_MIN, dt, delta_min=dm)
         else:
-            raise ValueError("mode must be adaptive, keep_alpha or keep_delta_min")
+            raise ValueError("mode must be adaptive, adaptive_converged, keep_alpha or keep_delta_min")
         return dict(alpha=float(p.alpha), beta=float(p.beta), delta_min=float(p.delta_min), aevp_c=float(p.aevp_c), aevp_alpha_min=float(p.aevp_alpha_min))
 
     def H0(self, x, y):

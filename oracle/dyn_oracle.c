@@ -559,8 +559,10 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
                     divx -= hy * gx11 + hx * gy12;
                     divy -= hy * gx12 + hx * gy22;
                     lumped += hx * hy * OT.lump[a];
-                    if (p->aevp_c > 0.)
-                        beta = fmax(beta, alpha_e[e]);
+                    if (p->aevp_c > 0.) { /* alpha_e times the mass ratio (element's centre node : this node): alpha_e beta_n >= the pair's bound */
+                        const long nce = (long)(2 * iy + 1) * nn + 2 * ix + 1;
+                        beta = fmax(beta, alpha_e[e] * fmax(cgh[nce], p->h_min) / fmax(cgh[n], p->h_min));
+                    }
                 }
             const double uu = u_old[n], vv = v_old[n];
             const double du = uo[n] - uu, dv = vo[n] - vv;
@@ -568,6 +570,8 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
             const double h = fmax(cgh[n], p->h_min);
             /* ice-free-node rule (dyn_oracle.h): free drift at full exposure, the neighbours' stress divergence weighted by 2^-100 */
             const int ice_free = node_ice_free(p, cgh[n], cga[n]);
+            if (p->aevp_c > 0.)
+                beta = ice_free ? p->aevp_alpha_min : fmax(beta, p->aevp_alpha_min); /* (an ice-free node does not feel its neighbours' stress) */
             const double a_ = ice_free ? 1. : fmin(fmax(cga[n], 0.), 1.);
             const double wdiv = ice_free ? 0x1p-100 : 1.;
             const double mdt = p->rho_ice * h / dt;

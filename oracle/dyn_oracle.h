@@ -25,7 +25,10 @@ typedef struct {
      * beta: per sub-iteration and element  zeta_e = max over its 9 Gauss points of P / (2 Delta),
      * alpha_e = sqrt(max(aevp_alpha_min^2, aevp_c zeta_e dt / (rho_ice max(cgH_c, h_min) hx hy)))  with cgH_c the nodal mean thickness
      * at the element's centre node (alpha_e = aevp_alpha_min if that node is ice-free by the rule above),
-     * S <- (1 - 1/alpha_e) S + (1/alpha_e) Proj sigma, and per node  beta_n = max of alpha_e over the adjacent elements. */
+     * S <- (1 - 1/alpha_e) S + (1/alpha_e) Proj sigma, and per node, with h'_n = max(cgH_n, h_min),
+     * beta_n = max(aevp_alpha_min, max over the adjacent elements of alpha_e h'_c(e) / h'_n)  -- alpha_e scaled by the ratio of the element's
+     * mass to the node's, so that alpha_e beta_n satisfies the stability bound of EVERY element-node pair (a light node beside a strong
+     * element: the edge of a lead) -- and beta_n = aevp_alpha_min at an ice-free node. */
     double aevp_c, aevp_alpha_min;
 } oracle_mevp_params;
 

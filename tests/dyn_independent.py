@@ -179,19 +179,27 @@ def mevp_stress(par, hx, hy, u, v, P, S, dt=None, cgh=None, cga=None):
 
 
 def mevp_velocity(par, hx, hy, dt, S, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, alpha_e=None):
-    """the momentum update of DESIGN.md section 3.2 at every interior node, v = 0 on the boundary; adaptive form: beta of a node =
-    the largest alpha_e of the elements it belongs to (every element writes its alpha to its nine nodes)"""
+    """the momentum update of DESIGN.md section 3.2 at every interior node, v = 0 on the boundary; adaptive form: beta of a node from the
+    alphas of the elements it belongs to, scaled by the mass ratios"""
     _, ny, nx = S[0].shape
     g, w = gauss_unit(5)
     nn, nm = 2 * nx + 1, 2 * ny + 1
     divx, divy, lump = np.zeros((nm, nn)), np.zeros((nm, nn)), np.zeros((nm, nn))
     beta_n = np.full((nm, nn), par["beta"])
     if par.get("aevp_c", 0.0) > 0.0:
-        beta_n[:] = 0.0
+        # every element offers its nine nodes alpha_e times ITS mass (at its centre node); a node divides the largest offer by its own mass:
+        # alpha_e beta_n then meets the stability bound of every element-node pair
+        hn = np.maximum(cgh, par["h_min"])
+        offer = np.zeros((nm, nn))
         for iy in range(ny):
             for ix in range(nx):
-                blk = beta_n[2 * iy:2 * iy + 3, 2 * ix:2 * ix + 3]
-                np.maximum(blk, alpha_e[iy, ix], out=blk)
+                blk = offer[2 * iy:2 * iy + 3, 2 * ix:2 * ix + 3]
+                np.maximum(blk, alpha_e[iy, ix] * hn[2 * iy + 1, 2 * ix + 1], out=blk)
+        beta_n = np.maximum(offer / hn, par["aevp_alpha_min"])
+        for gy in range(nm):
+            for gx in range(nn):
+                if ice_free(par, cgh[gy, gx], cga[gy, gx]):
+                    beta_n[gy, gx] = par["aevp_alpha_min"]
     for iy in range(ny):
         for ix in range(nx):
             for ay in range(3):

@@ -45,6 +45,10 @@ def test_stable_params_is_the_one_copy_of_the_rule(ctx):
     bt = synthetic.BoxTest(2048, 2048)
     p = abi.stable_mevp_params(ctx.mevp_default_params(), abi.SUBCYCLE_ADAPTIVE, bt.hx, 120.0)
     assert abs(p.aevp_c - (2.4 * np.pi) ** 2) < 1e-12 and p.aevp_alpha_min == 50.0 and p.delta_min == 2e-9
+    # the converging form: alpha_min = the bound's alpha at a strain rate of 1.67e-6 1/s on the mesh (1000 at 250 m), never below 50
+    for n, want in ((2048, 1000.0), (1024, 500.0), (4096, 2000.0), (64, 50.0)):
+        q = abi.stable_mevp_params(ctx.mevp_default_params(), abi.SUBCYCLE_ADAPTIVE_CONVERGED, 512e3 / n, 120.0)
+        assert abs(q.aevp_alpha_min / want - 1) < 0.01 and q.aevp_c == p.aevp_c and q.delta_min == 2e-9, (n, q.aevp_alpha_min)
     p = abi.stable_mevp_params(ctx.mevp_default_params(alpha=1500.0), abi.SUBCYCLE_KEEP_ALPHA, bt.hx, 120.0)
     assert p.aevp_c == 0.0 and p.alpha == p.beta == 1500.0 and abs(p.delta_min / bt.stable_delta_min(120.0) - 1) < 1e-12
     assert abs(abi.creep_percent_per_day(p) - p.delta_min * 8.64e6) < 1e-12 and 5.0 < abi.creep_percent_per_day(p) < 8.0  # 7.4e-7 1/s = 6.4 % per day
@@ -263,7 +267,7 @@ def test_compressible_cover_1024_at_the_literatures_delta_min(gpu):
     c = abi.Context(gpu)
     bt = synthetic.BoxTest(nx, ny, L)
     sub = bt.subcycle_parameters(dt)
-    assert sub["delta_min"] == 2e-9 and sub["aevp_c"] > 50.0
+    assert sub["delta_min"] == 2e-9 and sub["aevp_c"] > 50.0 and sub["aevp_alpha_min"] == 50.0
     c.set_mevp_params(c.mevp_default_params(**sub))
     core = rowblock.CoupledCore(c, rowblock.RowBlock(nx, ny, 0, 1), L / nx, L / ny, dt, nsub, gpu, native=True, forcing="winter")
     cs, cf = synthetic.column_fields_smooth(nx, ny, L)

@@ -352,3 +352,55 @@ def test_compressible_cover_1024_stays_in_range_for_37_hours(gpu):
     assert vA.min() >= -1e-15 and vA.max() <= 1.0 + 1e-15
     core.close()
     c.close()
+
+
+def test_a_transport_plan_with_its_own_bounds_neither_reads_nor_changes_the_contexts(gpu):
+    """nsdg_rb_transport_desc.own_bounds (round 6; advisor of round 5: the closure's bounds were sticky state of the shared context, so a
+    later step of two OTHER fields on that context was silently limited to H's and A's ranges): a plan that carries its own bounds applies
+    them whatever nsdg_transport_bounds_set says -- and a plain step call on the same context afterwards sees the context's bounds only"""
+    from nextsimdg_amd import rowblock, synthetic
+
+    nx, ny, dt = 96, 64, 120.0
+    c = abi.Context(gpu)
+    bt = synthetic.BoxTest(nx, ny)
+    c.set_grid(nx, ny, bt.hx, bt.hy)
+    rng = np.random.default_rng(77)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    X, Y = np.meshgrid(np.arange(2 * nx + 1), np.arange(2 * ny + 1))
+    u = 0.3 * np.sin(0.11 * X) * np.cos(0.07 * Y)
+    v = 0.3 * np.cos(0.05 * X) * np.sin(0.13 * Y)
+    for a in (u, v):
+        a[0] = a[-1] = 0
+        a[:, 0] = a[:, -1] = 0
+    adv = tuple(torch.zeros(*s, dtype=torch.float64, device="cuda") for s in ((6, ny, nx), (6, ny, nx), (3, ny, nx + 1), (3, ny + 1, nx)))
+    c.prepare_advection(2, dev(u), dev(v), *adv)
+    F = np.zeros((6, ny, nx))
+    F[0] = 0.95 + 0.2 * rng.random((ny, nx))  # cell means above 1: the cap and the limiter have work to do
+    F[1:3] = 0.1 * rng.standard_normal((2, ny, nx))
+    G = F.copy()
+    blk = rowblock.RowBlock(nx, ny, 0, 1)
+    z = lambda: torch.zeros(6, ny, nx, dtype=torch.float64, device="cuda")
+
+    def run(plan_bounds, ctx_bounds):
+        c.set_transport_bounds(ctx_bounds)
+        phi, t1, t2 = [dev(F), dev(G)], [z(), z()], [z(), z()]
+        tr = c.rb_transport(blk, (None, None), phi, t1, t2, adv, bounds=plan_bounds)
+        assert tr(dt, 0) == 1
+        torch.cuda.synchronize()
+        tr.close()
+        return [x.clone() for x in t1]
+
+    HA = abi.H_A_BOUNDS
+    own = run(HA, ())  # the plan's own bounds, nothing on the context
+    ctxb = run(None, HA)  # no own bounds: the context's (ABI 5 behaviour)
+    assert all(torch.equal(a, b) for a, b in zip(own, ctxb))
+    other = ((0.0, float("inf"), False), (0.0, float("inf"), False))
+    shielded = run(HA, other)  # the context says something else: the plan does not care ...
+    assert all(torch.equal(a, b) for a, b in zip(own, shielded))
+    assert c.transport_bounds == other  # ... and leaves it alone
+    bare = run((), HA)  # a plan that states NO closure is not limited by the context's bounds either
+    assert float(bare[1][0].max()) > 1.0 and float(own[1][0].max()) <= 1.0 and not torch.equal(bare[1], own[1])
+    with pytest.raises(abi.NsdgError, match="own bounds"):
+        c.rb_transport(blk, (None, None), [dev(F), dev(G)], [z(), z()], [z(), z()], adv, bounds=(HA[0],))
+    c.set_transport_bounds(())
+    c.close()

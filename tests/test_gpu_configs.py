@@ -40,12 +40,21 @@ def check_physical(res, mass0, nx, ny):
         assert -1e-6 * abs(mass0[1]) <= float(A[0].sum()) - mass0[1] <= 1e-12 * abs(mass0[1])
 
 
-def test_config3_1024_transport_and_mevp_120_subiterations(gpu):
+SUBCYCLE = ["keep_delta_min", "adaptive"]  # uniform alpha = beta of the stability bound (rounds 1-4) / the hosts' adaptive form (round 6)
+
+
+def subcycle(bt, mode):
+    """what run_world takes as `alpha`: the uniform value, or the parameter set of the adaptive form"""
+    return bt.stable_alpha(120.0) if mode == "keep_delta_min" else bt.subcycle_parameters(120.0, mode=mode)
+
+
+@pytest.mark.parametrize("mode", SUBCYCLE)
+def test_config3_1024_transport_and_mevp_120_subiterations(gpu, mode):
     """config 3: 1024x1024 DG2 transport (H, A; SSP-RK3) + mEVP with 120 sub-iterations, 3 model steps, default
     kernel (four sub-iterations per pass, one pipeline stage per wave) against one sub-iteration per pass: bit-identical; mass, walls"""
     n, nsub, nsteps = 1024, 120, 3
     data = fields(n, n, wind_scale=1.0)
-    alpha = data[0].stable_alpha(120.0)
+    alpha = subcycle(data[0], mode)
     mass0 = (float(np.sum(data[1][0])), float(np.sum(data[2][0])))
     res = {}
     for variant in (V, 1):
@@ -58,14 +67,15 @@ def test_config3_1024_transport_and_mevp_120_subiterations(gpu):
     free()
 
 
-def test_config4_2048_four_row_blocks_equal_single_domain_bitwise(gpu):
+@pytest.mark.parametrize("mode", SUBCYCLE)
+def test_config4_2048_four_row_blocks_equal_single_domain_bitwise(gpu, mode):
     """config 4: 2048x2048 DG2 full dynamics, 4 row blocks of 512 rows, 120 sub-iterations, 3 passes of the default
     (four-iteration) kernel between two ghost-row exchanges (ghost depth 12 / 11: the default of bench.py and of the C++
     host; config 5 below runs 6 passes per exchange), overlap split on, 2 model steps:
     every owned row of every block equals the single-domain run (Python sequence of launches) bit for bit"""
-    n, nsub, nsteps, world, group = 2048, 120, 2, 4, 3
+    n, nsub, nsteps, world, group = 2048, 120, 2, 4, (3 if mode == "keep_delta_min" else 2)  # 2 passes per exchange: the hosts' default since round 6
     data = fields(n, n, wind_scale=1.0)
-    alpha = data[0].stable_alpha(120.0)
+    alpha = subcycle(data[0], mode)
     mass0 = (float(np.sum(data[1][0])), float(np.sum(data[2][0])))
     ref = run_world(1, V, False, n, n, nsub, nsteps, data=data, alpha=alpha)[0]
     check_physical(ref, mass0, n, n)
@@ -80,7 +90,8 @@ def test_config4_2048_four_row_blocks_equal_single_domain_bitwise(gpu):
     free()
 
 
-def test_config5_4096_coupled_eight_row_blocks_equal_single_domain_bitwise(gpu):
+@pytest.mark.parametrize("mode", SUBCYCLE)
+def test_config5_4096_coupled_eight_row_blocks_equal_single_domain_bitwise(gpu, mode):
     """config 5: 4096x4096 DG2 dynamics + column thermodynamics, 8 row blocks of 512 rows, 120 sub-iterations,
     3 model steps with the smooth winter forcing of the coupled bench: bit-identical to the single domain, fields
     in their physical ranges.  (The one-day run of this configuration is tools/soak_coupled.py; its record is in
@@ -93,7 +104,7 @@ def test_config5_4096_coupled_eight_row_blocks_equal_single_domain_bitwise(gpu):
     data = (bt, H, A, uo, vo, ua, va)
     cs, cf = synthetic.column_fields_smooth(n, n)
     column = {**cs, **cf}
-    alpha = bt.stable_alpha(120.0)
+    alpha = subcycle(bt, mode)
     keep = ("H", "A", "u", "v")
     ref = run_world(1, V, True, n, n, nsub, nsteps, data=data, column=column, alpha=alpha, keep=keep)[0]
     check_physical(ref, None, n, n)

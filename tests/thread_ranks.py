@@ -74,7 +74,9 @@ def run_rank(rank, world, variant, coupled, nx, ny, nsub, nsteps, mailbox, out, 
     try:
         ctx = abi.Context(torch.device("cuda:0"))
         ctx.set_mevp_variant(variant)
-        ctx.set_mevp_params(ctx.mevp_default_params(alpha=alpha, beta=alpha))
+        # alpha: a number = uniform alpha = beta; a dict = keyword arguments of mevp_default_params (e.g. BoxTest.subcycle_parameters(dt): the
+        # hosts' adaptive form)
+        ctx.set_mevp_params(ctx.mevp_default_params(**alpha) if isinstance(alpha, dict) else ctx.mevp_default_params(alpha=alpha, beta=alpha))
         bt, H, A, uo, vo, ua, va = data if data is not None else fields(nx, ny)
         depth = (variant * group, variant * group - 1) if variant >= 2 else (1, 1)  # `group` passes of `variant` sub-iterations between two exchanges
         blk = rowblock.RowBlock(nx, ny, rank, world, *depth)
