@@ -460,9 +460,10 @@ def main():
                     "deliberately wrong diagnostic builds only; the line then says 'finite fields' as its self-check)")
     ap.add_argument("--no-closure", action="store_true", help="the bare scheme of rounds 1-4: no ridging cap / scaling limiter in the transport, no "
                     "ice-free-node rule (A/B of what the closure costs; the default run has it ON, as the hosts do)")
-    ap.add_argument("--subcycle", choices=["adaptive", "keep_alpha", "keep_delta_min"], default="adaptive",
+    ap.add_argument("--subcycle", choices=["adaptive", "adaptive_converged", "keep_alpha", "keep_delta_min"], default="adaptive",
                     help="how the sub-cycle satisfies its stability bound (nsdg_mevp_stable_params): adaptive (default since round 6) = local, "
-                         "solution-adaptive alpha and beta (Kimmritz et al. 2016) at the literature's Delta_min = 2e-9; keep_alpha (round 5) = uniform "
+                         "solution-adaptive alpha and beta (Kimmritz et al. 2016) at the literature's Delta_min = 2e-9, alpha_min = 50; adaptive_converged = the same "
+                         "with the alpha_min that lets 120 sub-iterations converge on the mesh; keep_alpha (round 5) = uniform "
                          "alpha = beta = 1500 with the Delta_min the mesh needs for it; keep_delta_min (rounds 1-4) = uniform alpha = beta from the "
                          "bound for Delta_min = 2e-9")
     ap.add_argument("--delta-min", type=float, default=None, help="regularisation of Delta [1/s] instead of 2e-9 (adaptive, keep_delta_min) / as a floor (keep_alpha)")
@@ -766,8 +767,8 @@ def main():
             "config": {"workload": ("column thermodynamics + " if coupled else "") + "%dx%d DG2 transport (H,A; SSP-RK3) + mEVP (%d sub-iterations, CG2 velocity, DG8 stress), "
                                    "512 km box test, dt=120 s, %s, Delta_min=%.2e 1/s (creep below %.3g %% per day)" % (
                                        nx, ny, nsub,
-                                       ("local, solution-adaptive alpha and beta (Kimmritz et al. 2016: alpha_e^2 = max(%.0f^2, %.2f zeta_e dt / (m_e |K|)), beta_n = max over "
-                                        "the adjacent elements) at the standard parameters of SURVEY 8(d)" % (sub["aevp_alpha_min"], sub["aevp_c"])) if sub["aevp_c"] > 0 else
+                                       ("local, solution-adaptive alpha and beta (Kimmritz et al. 2016: alpha_e^2 = max(%.0f^2, %.2f zeta_e dt / (m_e |K|)), beta_n = max(alpha_min, max over "
+                                        "the adjacent elements of alpha_e m_e / m_n)) at the standard parameters of SURVEY 8(d)" % (sub["aevp_alpha_min"], sub["aevp_c"])) if sub["aevp_c"] > 0 else
                                        ("uniform alpha=beta=%.0f (%s; the %d sub-iterations move the sub-cycle %.1f %% of the way per model step)" % (
                                            alpha, "SURVEY 8(d)'s alpha with the smallest regularisation for which it satisfies the sub-cycle's stability bound on this mesh"
                                            if args.subcycle == "keep_alpha" else "alpha from the stability bound of the sub-cycle on this mesh", nsub, 100.0 * min(1.0, nsub / alpha))),
