@@ -252,6 +252,50 @@ def test_checkpoint_and_resume_on_the_device_is_exact(gpu):
         c.close()
 
 
+def test_the_converging_form_converges_where_the_published_floor_is_noisy(gpu):
+    """What the round's own convergence check found (profiles/r06_adaptive_noise.md), as a regression: the momentum equation of the box test on
+    1024 x 1024 (500 m; H, A fixed at 0.3 / 0.9, cyclone wind of t = 0), 150 model steps of 120 sub-iterations from rest.  With alpha_min from
+    the mesh (NSDG_SUBCYCLE_ADAPTIVE_CONVERGED: 500 here) the velocity then changes by < 0.5 % of its maximum per model step and by more than 1 mm/s
+    nowhere; with the published alpha_min = 50 (the default) every deforming element sits at its stability limit and the step-to-step change stays
+    above a tenth of the maximum -- bounded (nothing grows), which is what the coupled runs live on."""
+    n, L, dt = 1024, 512e3, 120.0
+    bt = synthetic.BoxTest(n, n, L)
+    H, A = np.zeros((6, n, n)), np.zeros((6, n, n))
+    H[0], A[0] = 0.3, 0.9
+    dH, dA = dev(H), dev(A)
+    uo, vo = [dev(a) for a in bt.ocean()]
+    ua, va = [dev(a) for a in bt.wind(0.0)]
+    z = lambda: torch.zeros((2 * n + 1, 2 * n + 1), dtype=torch.float64, device=gpu)
+    change = {}
+    for mode in ("adaptive_converged", "adaptive"):
+        c = abi.Context(gpu)
+        sub = bt.subcycle_parameters(dt, mode=mode)
+        assert sub["aevp_alpha_min"] == (50.0 if mode == "adaptive" else pytest.approx(500.0, rel=0.01))
+        c.set_mevp_params(c.mevp_default_params(**sub))
+        c.set_grid(n, n, bt.hx, bt.hy)
+        cgh, cga, tax, tay = z(), z(), z(), z()
+        c.dg_to_cg(dH, cgh)
+        c.dg_to_cg(dA, cga)
+        c.wind_stress(ua, va, tax, tay)
+        pg = c.private_zeros(9, n, n, gpu)
+        c.ice_strength(dH, dA, pg)
+        u, v, u0, v0 = z(), z(), z(), z()
+        s = [c.private_zeros(8, n, n, gpu) for _ in range(3)]
+        scratch = torch.zeros(10 * u.numel() + 3 * s[0].numel(), dtype=torch.float64, device=gpu)
+        for _ in range(150):
+            u0.copy_(u)
+            v0.copy_(v)
+            c.mevp_subcycle(dt, 120, s, u, v, u0, v0, tax, tay, uo, vo, cgh, cga, pg, scratch)
+        c.synchronize()
+        d = torch.maximum((u - u0).abs(), (v - v0).abs())
+        umax = float(torch.maximum(u.abs().max(), v.abs().max()))
+        assert bool(torch.isfinite(u).all()) and 0.05 < umax < 0.12
+        change[mode] = (float(d.max()) / umax, int((d > 1e-3).sum()))
+        c.close()
+    assert change["adaptive_converged"][0] < 5e-3 and change["adaptive_converged"][1] == 0, change
+    assert 0.1 < change["adaptive"][0] < 1.0 and change["adaptive"][1] > 10000, change
+
+
 def test_compressible_cover_1024_at_the_literatures_delta_min(gpu):
     """The run that left the physical range in rounds 3-5 (profiles/r04_soak_divergence_cause.md, profiles/r05_closure.md): a uniform cover
     A0 = 0.9, H0 = 0.3 on 1024 x 1024 (500 m), winter forcing, dynamics + column thermodynamics, dt = 120 s, 120 sub-iterations.  With the
