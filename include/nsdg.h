@@ -177,7 +177,8 @@ typedef struct {
      *     zeta_e = max over its 9 Gauss points of P / (2 Delta),
      *     alpha_e = sqrt(max(aevp_alpha_min^2, aevp_c zeta_e dt / (rho_ice h'_c hx hy))),
      * h'_c = max(nodal mean thickness at the element's centre node, h_min) (alpha_e = aevp_alpha_min where that node is ice-free), the
-     * stress relaxes with 1 / alpha_e, and every node takes beta_n = the largest alpha_e of its adjacent elements.  aevp_c is the
+     * stress relaxes with 1 / alpha_e, and every node takes beta_n = max(aevp_alpha_min, max over its adjacent elements of alpha_e h'_c(e) / h'_n)
+     * (alpha_e weighted by the ratio of the element's mass to the node's: the bound of every element-node pair; alpha_min at an ice-free node).  aevp_c is the
      * stability bound's constant: (2.4 pi)^2 = 56.85 is the bound DESIGN.md section 3.4 states with its margin; aevp_alpha_min must not be
      * chosen small on a fine mesh (nsdg_mevp_stable_params sets both).  Where the ice
      * deforms alpha is small and the stress follows the strain rate within a few sub-iterations, where it is rigid alpha is what the

@@ -536,7 +536,7 @@ void oracle_mevp_velocity(int nx, int ny, int j0, int j1, double hx, double hy, 
                 continue;
             }
             double divx = 0, divy = 0, lumped = 0;
-            double beta = p->beta; /* adaptive form: the largest alpha of the adjacent elements */
+            double beta = p->beta; /* adaptive form: the largest alpha_e h'_c(e) / h'_n of the adjacent elements, at least alpha_min */
             if (p->aevp_c > 0.)
                 beta = 0.;
             const int ix_hi = gx / 2, ix_lo = (gx % 2 == 0) ? gx / 2 - 1 : gx / 2;
