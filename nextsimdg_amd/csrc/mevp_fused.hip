@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
     // contributions of the row below to its top-row nodes: b6 (top-left), b7 (top-mid) of my column and
     // bl8 = top-right of the column to my left
     double b6x = 0., b6y = 0., b7x = 0., b7y = 0., bl8x = 0., bl8y = 0.;
-    double ba = 0., bal = 0.; // adaptive form: the offers q of the element below and below-left
+    double qb = 0., qbl = 0.; // adaptive form: the offers q_e of the element below and below-left
 
     for (int iy = (y0 > k0 ? y0 - 1 : y0); iy < y1; ++iy) {
         const bool prologue = iy < y0; // recomputed row owned by the strip below: nothing is stored
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
             vl[a] = v_old[n];
         }
         tile_load9(pg, tp, ix & 63, Pq);
-        double alpha = 0.; // adaptive form: this element's offer q_e = alpha_e h'_c of this sub-iteration (mevp_common.h)
+        double qe = 0.; // adaptive form: this element's offer q_e = alpha_e h'_c of this sub-iteration (mevp_common.h)
         if constexpr (AD) {
             // local, solution-adaptive alpha (mevp_common.h); h' of the element's centre node is its packed coefficient [0]
             const double hc = packed[nodal_off(nV + nn + 1, nplane)];
             double r11[8], r12[8], r22[8], ialpha;
-            stress_projected_adaptive(ul, vl, Pq, ihx, ihy, dmin2, hc, AC, r11, r12, r22, alpha, ialpha);
+            stress_projected_adaptive(ul, vl, Pq, ihx, ihy, dmin2, hc, AC, r11, r12, r22, qe, ialpha);
             tile_load8(S.i11, ts, s11);
             tile_load8(S.i12, ts, s12);
             tile_load8(S.i22, ts, s22);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
         // wavefront-level edge exchange: right-column contributions of the element to my left
         const double l2x = shift_up(cx[2]), l2y = shift_up(cy[2]);
         const double l5x = shift_up(cx[5]), l5y = shift_up(cy[5]);
-        const double al = AD ? shift_up(alpha) : 0.;
+        const double ql = AD ? shift_up(qe) : 0.;
 
         if (!prologue && iy >= j0) { // wave-uniform
             const bool hasB = iy > 0;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
                 load_nodal(packed, nplane, nV, c);
                 if constexpr (AD)
                     node_update_packed_adaptive(K, c, ul[0], vl[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea,
-                        __builtin_fmax(__builtin_fmax(bal, ba), __builtin_fmax(al, alpha)), AC.amin, un, vn);
+                        __builtin_fmax(__builtin_fmax(qbl, qb), __builtin_fmax(ql, qe)), AC.amin, un, vn);
                 else
                     node_update_packed(K, c, ul[0], vl[0], ((bl8x + b6x) + l2x) + cx[0], ((bl8y + b6y) + l2y) + cy[0], 9. * iarea, un, vn);
             } else
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
             if (hasB) {
                 load_nodal(packed, nplane, nV + 1, c);
                 if constexpr (AD)
-                    node_update_packed_adaptive(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, __builtin_fmax(ba, alpha), AC.amin, un, vn);
+                    node_update_packed_adaptive(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, __builtin_fmax(qb, qe), AC.amin, un, vn);
                 else
                     node_update_packed(K, c, ul[1], vl[1], b7x + cx[1], b7y + cy[1], 4.5 * iarea, un, vn);
             } else
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
             if (hasL) {
                 load_nodal(packed, nplane, nV + nn, c);
                 if constexpr (AD)
-                    node_update_packed_adaptive(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, __builtin_fmax(al, alpha), AC.amin, un, vn);
+                    node_update_packed_adaptive(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, __builtin_fmax(ql, qe), AC.amin, un, vn);
                 else
                     node_update_packed(K, c, ul[3], vl[3], l5x + cx[3], l5y + cy[3], 4.5 * iarea, un, vn);
             } else
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
             // centre: own
             load_nodal(packed, nplane, nV + nn + 1, c);
             if constexpr (AD)
-                node_update_packed_adaptive(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, alpha, AC.amin, un, vn);
+                node_update_packed_adaptive(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, qe, AC.amin, un, vn);
             else
                 node_update_packed(K, c, ul[4], vl[4], cx[4], cy[4], 2.25 * iarea, un, vn);
             if (own) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, MINW) void mevp_fused_kernel(NodalConsts K, Ad
         b6x = cx[6], b6y = cy[6], b7x = cx[7], b7y = cy[7];
         bl8x = shift_up(cx[8]), bl8y = shift_up(cy[8]);
         if constexpr (AD)
-            ba = alpha, bal = al;
+            qb = qe, qbl = ql;
     }
 }
 

@@ -174,9 +174,9 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     NSDG_PHASE(0); // inputs of the row (stages >= 1: the wait for the previous stage, LDS reads)
     // ------------------------------------------------------------------------------------------ stress update
     double r11[8], r12[8], r22[8];
-    double alpha = 0., ialpha = M.ialpha; // adaptive form: this element's offer q_e = alpha_e h'_c of this sub-iteration (the centre node's h' is coefficient [0] of node 3)
+    double qe = 0., ialpha = M.ialpha; // adaptive form: this element's offer q_e = alpha_e h'_c and 1 / alpha_e of this sub-iteration (the centre node's h' is coefficient [0] of node 3)
     if constexpr (AD)
-        stress_projected_adaptive(ul, vl, f.P, M.ihx, M.ihy, M.dmin2, f.c[3][0], M.AC, r11, r12, r22, alpha, ialpha);
+        stress_projected_adaptive(ul, vl, f.P, M.ihx, M.ihy, M.dmin2, f.c[3][0], M.AC, r11, r12, r22, qe, ialpha);
     else
         stress_projected(ul, vl, f.P, M.ihx, M.ihy, M.ialpha, M.dmin2, r11, r12, r22);
     __builtin_amdgcn_sched_barrier(0);
@@ -228,13 +228,13 @@ __device__ __forceinline__ void p2p_row(const MarchConst3& M, const StageP& G, i
     {
         double cx[9], cy[9];
         node_contrib_all(s11, s12, s22, M.hx, M.hy, cx, cy);
-        owned_node_updates<AD>(M, row > 0, f.c, uu, vv, carry, cx, cy, un, vn, alpha);
+        owned_node_updates<AD>(M, row > 0, f.c, uu, vv, carry, cx, cy, un, vn, qe);
         if (row < G.upd0) { // wave-uniform: the first row of a stage only feeds the carried contributions
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 un[k] = vn[k] = 0.;
         }
-        carry_top<AD>(carry, cx, cy, alpha);
+        carry_top<AD>(carry, cx, cy, qe);
     }
     __builtin_amdgcn_sched_barrier(0);
     NSDG_PHASE(4); // contributions, node updates (the wait for the nodal coefficients is here)
